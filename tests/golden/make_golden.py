@@ -1,0 +1,140 @@
+"""Generates the golden fixtures in this directory.  RUNS ONLY IN THE BUILD CONTAINER
+(needs /root/reference); the fixtures it writes are plain data and are committed.
+
+What it does (SURVEY.md §8c "Oracle plan", Appendix D recipe):
+  * puts oracle/ on sys.path so that `import MinkowskiEngine` resolves to the build's CPU
+    stand-in (oracle/MinkowskiEngine — NOT the real ME, which is absent from the image);
+  * shadows the HuggingFace `datasets` package with the reference's namespace package;
+  * imports the REFERENCE's own misc.utils.ModelParams / models.model_factory /
+    datasets.quantization and runs its graph code on seeded clouds + seeded weights;
+  * stores inputs, outputs and the state_dict key/shape table as .npz / .json.
+
+No reference source text is stored — only arrays the reference code computed.
+
+    python tests/golden/make_golden.py            # rewrite all fixtures
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def bootstrap_reference():
+    assert os.path.isdir(REF), "fixture generation needs /root/reference (build container only)"
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    sys.path.insert(0, REF)
+    sys.path.insert(0, REPO)
+    for name, path in [("datasets", "datasets"), ("datasets.kitti", "datasets/kitti"),
+                       ("datasets.mulran", "datasets/mulran"), ("datasets.southbay", "datasets/southbay")]:
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF, path)]
+        sys.modules[name] = m
+
+
+def model_params(coordinates: str, step):
+    from misc.utils import ModelParams
+    f = tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False)
+    f.write(f"[MODEL]\nmodel = egonn\ncoordinates = {coordinates}\nquantization_step = {step}\n")
+    f.close()
+    mp = ModelParams(f.name)
+    os.unlink(f.name)
+    return mp
+
+
+def kitti_like_filter(pc):
+    """drop all-zero points, keep z > -1.5 (reference datasets/kitti/kitti_raw.py:12-14,
+    misc/point_clouds.py:103-109) — applied to the synthetic cloud of the C0 case."""
+    import numpy as np
+    mask = ~np.all(pc == 0, axis=1)
+    pc = pc[mask]
+    return pc[pc[:, 2] > -1.5]
+
+
+CASES = [
+    # name,            coordinates, step,            scans [(seed, n_points)],  weight seed, filter
+    ("egonn_cart01_b1", "cartesian", "0.1",          [(3, 12000)],              11, False),
+    ("egonn_cart01_b2", "cartesian", "0.1",          [(5, 8000), (6, 6000)],    12, False),
+    ("egonn_cart03_b1", "cartesian", "0.3",          [(1, 40000)],              13, True),
+    ("egonn_polar_b1",  "polar",     "1., 0.3, 0.2", [(1, 40000)],              14, True),
+]
+
+
+def main():
+    bootstrap_reference()
+    import numpy as np
+    import torch
+    import MinkowskiEngine as ME
+    from models.model_factory import model_factory
+    from egonn_amd.synth import lidar_scan, seeded_state_dict
+
+    torch.manual_seed(0)
+    shapes_written = False
+    for name, coordinates, step, scans, wseed, filt in CASES:
+        mp = model_params(coordinates, step)
+        model = model_factory(mp)
+        model.eval()
+        sd = model.state_dict()
+        shapes = {k: [int(s) for s in v.shape] for k, v in sd.items()}
+        if not shapes_written:
+            with open(os.path.join(HERE, "egonn_state_dict_shapes.json"), "w") as f:
+                json.dump(shapes, f, indent=0, sort_keys=True)
+            shapes_written = True
+        new = seeded_state_dict(wseed, {k: tuple(v) for k, v in shapes.items()})
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()})
+
+        out = {"weight_seed": np.int64(wseed), "coordinates": np.array(coordinates),
+               "quantization_step": np.array([float(s) for s in step.split(",")], dtype=np.float64),
+               "n_scans": np.int64(len(scans))}
+        coords_list = []
+        for b, (seed, n) in enumerate(scans):
+            pc = lidar_scan(seed, n_points=n)
+            if filt:
+                pc = kitti_like_filter(pc)
+            out[f"points_{b}"] = pc
+            coords, idx = mp.quantizer(torch.from_numpy(pc))          # REFERENCE quantiser
+            out[f"quant_coords_{b}"] = coords.numpy().astype(np.int32)
+            out[f"quant_index_{b}"] = idx.numpy().astype(np.int64)
+            coords_list.append(coords)
+        bc = ME.utils.batched_coordinates(coords_list)
+        feats = torch.ones((bc.shape[0], 1), dtype=torch.float32)
+        with torch.no_grad():
+            x = ME.SparseTensor(feats, coordinates=bc)
+            levels = model.trunk(x)                                     # REFERENCE trunk
+            y = model({"coords": bc, "features": feats})                # REFERENCE forward
+        out["coords"] = bc.numpy().astype(np.int32)
+        for lvl, t in levels.items():
+            c = t.C.numpy().astype(np.int32)
+            order = np.lexsort((c[:, 3], c[:, 2], c[:, 1], c[:, 0]))
+            out[f"level{lvl}_coords"] = c[order]
+            if lvl in (3, 7):
+                out[f"level{lvl}_feats"] = t.F.numpy()[order]
+        out["global"] = y["global"].numpy()
+        # keypoint coordinates: rows of the local map, split exactly as the reference splits them
+        xl = model.local_head(levels)
+        kc = xl.C.numpy().astype(np.int32)
+        for b, rows in enumerate(xl._batchwise_row_indices):
+            out[f"kp_coords_{b}"] = kc[rows.numpy()]
+            out[f"keypoints_{b}"] = y["keypoints"][b].numpy()
+            out[f"descriptors_{b}"] = y["descriptors"][b].numpy()
+            out[f"sigma_{b}"] = y["sigma"][b].numpy()
+            # reference eval/evaluate.py:352-361 selection (torch.topk, ascending sigma)
+            s = y["sigma"][b].squeeze(1)
+            n_k = min(len(s), 128)
+            _, ndx = torch.topk(s, dim=0, k=n_k, largest=False)
+            out[f"topk_sigma_{b}"] = s[ndx].numpy()
+            out[f"topk_coords_{b}"] = kc[rows.numpy()][ndx.numpy()]
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(name, "voxels", bc.shape[0], "keypoints", [len(k) for k in y["keypoints"]],
+              f"{os.path.getsize(path) / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
