@@ -1,0 +1,239 @@
+"""ctypes binding of libegonn_hip.so (C ABI: include/egonn_hip.h).
+
+The product path has NO fallback: if the HIP library is missing, or no MI355X is visible, every entry
+point raises.  PyTorch is used only as the owner of device memory and of the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libegonn_hip.so")
+
+QUANT_CARTESIAN, QUANT_POLAR = 0, 1
+FLAG_DISABLE_GLOBAL, FLAG_DISABLE_LOCAL, FLAG_IGNORE_KP_REGRESSOR = 1, 2, 4
+
+# every symbol include/egonn_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_SIGS = [
+    ("egonn_ctx_create", C.c_int, [C.POINTER(_P), C.c_int, C.c_int]),
+    ("egonn_ctx_destroy", None, [_P]),
+    ("egonn_last_error", C.c_char_p, []),
+    ("egonn_debug_set_naive_conv", C.c_int, [C.c_int]),
+    ("egonn_voxelize", C.c_int, [_P, _P, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
+    ("egonn_coords_set", C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    ("egonn_level_count", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
+    ("egonn_level_batch_offsets", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
+    ("egonn_level_coords", C.c_int, [_P, C.c_int, _P, _P]),
+    ("egonn_input_index", C.c_int, [_P, _P, _P]),
+    ("egonn_conv", C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P]),
+    ("egonn_conv_transpose", C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P]),
+    ("egonn_global_avg_pool", C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
+    ("egonn_model_create", C.c_int, [C.POINTER(_P)]),
+    ("egonn_model_destroy", None, [_P]),
+    ("egonn_model_set_tensor", C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64)]),
+    ("egonn_model_finalize", C.c_int, [_P, _P]),
+    ("egonn_forward", C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_float), C.c_int, _P, _P, _P, _P, _P]),
+    ("egonn_forward_level_features", C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
+    ("egonn_select_keypoints", C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
+]
+EXPORTED_SYMBOLS = [s[0] for s in _SIGS]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libegonn_hip.so; loud failure if it has not been built (python __graft_entry__.py / make)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"egonn_amd: HIP library not found at {LIB_PATH}. Build it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            f"There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in _SIGS:
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _err(lib) -> str:
+    msg = lib.egonn_last_error()
+    return msg.decode() if msg else "unknown error"
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError(f"libegonn_hip: {_err(load())} (code {rc})")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _dev_f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("egonn_amd: no HIP device visible (torch.cuda.is_available() is False); "
+                           "the descriptor-extraction path runs on MI355X only — there is no CPU fallback.")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class Context:
+    """egonn_ctx: coordinate plan + workspace of one device."""
+
+    def __init__(self, device: Optional[torch.device] = None, coord_bits: int = 16):
+        self.lib = load()
+        self.device = torch.device(device) if device is not None else require_gpu()
+        if self.device.type != "cuda":
+            raise RuntimeError(f"egonn_amd: device {self.device} is not a HIP device; there is no CPU fallback.")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        h = _P()
+        check(self.lib.egonn_ctx_create(C.byref(h), self.device.index, coord_bits))
+        self.h = h
+        self.batch_size = 0
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.egonn_ctx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plan
+    def voxelize(self, points: torch.Tensor, scan_offsets: Sequence[int], mode: int, step: Sequence[float]):
+        assert points.is_cuda and points.dtype == torch.float32 and points.is_contiguous()
+        assert points.dim() == 2 and points.shape[1] == 3
+        B = len(scan_offsets) - 1
+        off = (C.c_int64 * (B + 1))(*[int(o) for o in scan_offsets])
+        st = (C.c_float * 3)(*([float(s) for s in step] + [0.0, 0.0])[:3])
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_voxelize(self.h, points.data_ptr(), off, B, mode, st, _stream()))
+        self.batch_size = B
+
+    def coords_set(self, coords: torch.Tensor, batch_size: int):
+        assert coords.is_cuda and coords.dtype == torch.int32 and coords.is_contiguous()
+        assert coords.dim() == 2 and coords.shape[1] == 4
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_coords_set(self.h, coords.data_ptr(), coords.shape[0], int(batch_size), _stream()))
+        self.batch_size = int(batch_size)
+
+    def level_count(self, level: int) -> int:
+        n = C.c_int64()
+        check(self.lib.egonn_level_count(self.h, level, C.byref(n)))
+        return n.value
+
+    def level_batch_offsets(self, level: int) -> List[int]:
+        off = (C.c_int64 * (self.batch_size + 1))()
+        check(self.lib.egonn_level_batch_offsets(self.h, level, off))
+        return list(off)
+
+    def level_coords(self, level: int) -> torch.Tensor:
+        out = torch.empty((self.level_count(level), 4), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_level_coords(self.h, level, out.data_ptr(), _stream()))
+        return out
+
+    def input_index(self) -> torch.Tensor:
+        out = torch.empty((self.level_count(0),), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_input_index(self.h, out.data_ptr(), _stream()))
+        return out
+
+    # ------------------------------------------------------------------ operators
+    def conv(self, level_in: int, level_out: int, kernel_size: int, x: torch.Tensor, kernel: torch.Tensor,
+             scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, relu: bool = False):
+        x = _dev_f32(x, self.device)
+        kernel = _dev_f32(kernel, self.device)
+        cin, cout = kernel.shape[-2], kernel.shape[-1]
+        assert x.shape == (self.level_count(level_in), cin), (x.shape, self.level_count(level_in), cin)
+        out = torch.empty((self.level_count(level_out), cout), dtype=torch.float32, device=self.device)
+        sc = None if scale is None else _dev_f32(scale, self.device)
+        sh = None if shift is None else _dev_f32(shift, self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_conv(self.h, level_in, level_out, kernel_size, x.data_ptr(), cin, kernel.data_ptr(),
+                                      cout, _ptr(sc), _ptr(sh), int(relu), out.data_ptr(), _stream()))
+        return out
+
+    def conv_transpose(self, level_in: int, x: torch.Tensor, kernel: torch.Tensor):
+        x = _dev_f32(x, self.device)
+        kernel = _dev_f32(kernel, self.device)
+        cin, cout = kernel.shape[-2], kernel.shape[-1]
+        assert x.shape == (self.level_count(level_in), cin)
+        out = torch.empty((self.level_count(level_in - 1), cout), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_conv_transpose(self.h, level_in, x.data_ptr(), cin, kernel.data_ptr(), cout,
+                                                out.data_ptr(), _stream()))
+        return out
+
+    def global_avg_pool(self, level: int, x: torch.Tensor):
+        x = _dev_f32(x, self.device)
+        out = torch.empty((self.batch_size, x.shape[1]), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_global_avg_pool(self.h, level, x.data_ptr(), x.shape[1], out.data_ptr(), _stream()))
+        return out
+
+    def forward_level_features(self, level: int, channels: int) -> torch.Tensor:
+        out = torch.empty((self.level_count(level), channels), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_forward_level_features(self.h, level, out.data_ptr(), channels, _stream()))
+        return out
+
+    def select_keypoints(self, sigma: torch.Tensor, keypoints: torch.Tensor, descriptors: torch.Tensor, n_k: int):
+        B = self.batch_size
+        dev = self.device
+        sel_kp = torch.empty((B, n_k, 3), dtype=torch.float32, device=dev)
+        sel_desc = torch.empty((B, n_k, descriptors.shape[1]), dtype=torch.float32, device=dev)
+        sel_rows = torch.empty((B, n_k), dtype=torch.int32, device=dev)
+        sel_count = torch.empty((B,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(self.lib.egonn_select_keypoints(self.h, sigma.data_ptr(), keypoints.data_ptr(),
+                                                  descriptors.data_ptr(), n_k, sel_kp.data_ptr(), sel_desc.data_ptr(),
+                                                  sel_rows.data_ptr(), sel_count.data_ptr(), _stream()))
+        return sel_kp, sel_desc, sel_rows, sel_count
+
+
+class ModelHandle:
+    """egonn_model: weights registered under the reference's state_dict keys."""
+
+    def __init__(self):
+        self.lib = load()
+        h = _P()
+        check(self.lib.egonn_model_create(C.byref(h)))
+        self.h = h
+        self._keep = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.egonn_model_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_tensor(self, key: str, t: torch.Tensor):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), key
+        shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+        check(self.lib.egonn_model_set_tensor(self.h, key.encode(), t.data_ptr(), t.dim(), shape))
+        self._keep[key] = t
+
+    def finalize(self):
+        check(self.lib.egonn_model_finalize(self.h, _stream()))

@@ -1,0 +1,150 @@
+// Shared host/device definitions for libegonn_hip (gfx950 / MI355X only).
+//
+// Data model:
+//   * every voxel of every scan in a batch is one 64-bit Z-order key
+//         key = (batch << 3*CB) | morton3(x + 2^(CB-1), y + 2^(CB-1), z + 2^(CB-1))
+//     with x in bit 0, y in bit 1, z in bit 2 of every triple and CB = coord_bits (10..16).
+//   * rows of every level are stored sorted by key  =>  rows are batch-contiguous, the 8
+//     children of a stride-2 parent are adjacent and `key >> 3` is the parent's key, and
+//     `key & 7` is MinkowskiEngine's kernel index of a k=2,s=2 convolution (x fastest).
+//   * level l keys are level-0 keys >> 3l; decoded coordinates are multiples of 2^l, equal to
+//     ME's floor(c / 2^l) * 2^l because the bias 2^(CB-1) is a multiple of 2^9.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#define EGONN_MAX_LEVELS 10      // levels 0..9 (7 real strided levels + 2 virtual ones for block masks)
+#define EGONN_NUM_LEVELS 8       // levels that carry features: 0..7
+#define EGONN_MAX_BATCH 4096
+
+namespace egonn {
+
+// ------------------------------------------------------------------ error plumbing
+void set_error(const char* fmt, ...);
+#define EGONN_OK 0
+#define EGONN_ERR_INVALID 1
+#define EGONN_ERR_HIP 2
+#define EGONN_ERR_RANGE 3
+#define EGONN_ERR_STATE 4
+
+#define HIP_CHECK(expr)                                                                   \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      ::egonn::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,               \
+                         hipGetErrorString(_e));                                          \
+      return EGONN_ERR_HIP;                                                               \
+    }                                                                                     \
+  } while (0)
+
+#define EGONN_REQUIRE(cond, code, ...)                                                    \
+  do {                                                                                    \
+    if (!(cond)) {                                                                        \
+      ::egonn::set_error(__VA_ARGS__);                                                    \
+      return (code);                                                                      \
+    }                                                                                     \
+  } while (0)
+
+#define EGONN_TRY(expr)                                                                   \
+  do {                                                                                    \
+    int _rc = (expr);                                                                     \
+    if (_rc != EGONN_OK) return _rc;                                                      \
+  } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------ device arena (grow-only)
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0;
+  size_t off = 0;
+  int ensure(size_t bytes);                 // may hipFree + hipMalloc (only legal when nothing is live)
+  void reset() { off = 0; }
+  template <typename T>
+  T* alloc(size_t n) {
+    size_t o = align_up(off, 256);
+    size_t end = o + n * sizeof(T);
+    if (end > cap) return nullptr;
+    off = end;
+    return reinterpret_cast<T*>(base + o);
+  }
+  void release();
+};
+
+// ------------------------------------------------------------------ Morton helpers (host + device)
+__host__ __device__ static inline uint64_t part1by2(uint32_t v) {   // 16 bits -> every 3rd bit
+  uint64_t x = v & 0xFFFFull;
+  x = (x | (x << 16)) & 0x0000FF0000FFull;
+  x = (x | (x << 8)) & 0x00F00F00F00Full;
+  x = (x | (x << 4)) & 0x0C30C30C30C3ull;
+  x = (x | (x << 2)) & 0x249249249249ull;
+  return x;
+}
+__host__ __device__ static inline uint32_t compact1by2(uint64_t x) {
+  x &= 0x249249249249ull;
+  x = (x | (x >> 2)) & 0x0C30C30C30C3ull;
+  x = (x | (x >> 4)) & 0x00F00F00F00Full;
+  x = (x | (x >> 8)) & 0x0000FF0000FFull;
+  x = (x | (x >> 16)) & 0xFFFFull;
+  return (uint32_t)x;
+}
+__host__ __device__ static inline uint64_t morton3(uint32_t x, uint32_t y, uint32_t z) {
+  return part1by2(x) | (part1by2(y) << 1) | (part1by2(z) << 2);
+}
+
+// ------------------------------------------------------------------ coordinate plan ("coordinate manager")
+struct Level {
+  int64_t n = 0;              // rows at this level (host copy, valid after the size query)
+  uint64_t* keys = nullptr;   // [n]     sorted unique keys (level-l key = level-0 key >> 3l)
+  int32_t* parent = nullptr;  // [n]     row of the parent at level l+1
+  int32_t* cstart = nullptr;  // [n+1]   first child row at level l-1 (l >= 1)
+  uint64_t* mask = nullptr;   // [n]     (l >= 2) 4x4x4 occupancy of the level-(l-2) voxels inside this block
+  int32_t* bstart = nullptr;  // [n]     (l >= 2) first level-(l-2) row inside this block
+  int32_t* boff = nullptr;    // [B+1]   first row of every sample (levels 0..7)
+  int32_t* nbr27 = nullptr;   // [n][27] k=3 neighbour rows at the same level (levels 1..7), -1 = absent
+  int32_t* nbr8 = nullptr;    // [n][8]  k=2,s=2 children rows at level l-1 by kernel slot (levels 1..7)
+  int32_t* nbrT = nullptr;    // [n][8]  transposed conv: parent row (at level l+1) in slot (key&7), else -1
+};
+
+struct Plan {
+  bool valid = false;
+  int batch = 0;              // B
+  int coord_bits = 16;        // CB
+  int64_t n_input = 0;        // rows/points handed in by the caller
+  Level lv[EGONN_MAX_LEVELS];
+  int32_t* perm0 = nullptr;   // [n0] caller row / point index that became sorted row i (first occurrence)
+  std::vector<int32_t> boff_host[EGONN_NUM_LEVELS];   // host copies of boff (size B+1)
+};
+
+struct Ctx {
+  int device = 0;
+  int coord_bits = 16;
+  Arena plan_arena;           // keys, maps (lives until the next plan)
+  Arena work_arena;           // features & scratch of one forward
+  Arena sort_arena;           // radix-sort scratch
+  Plan plan;
+  int32_t* host_counts = nullptr;    // pinned staging for the size query
+  int32_t* dev_counts = nullptr;
+  int32_t* dev_flags = nullptr;      // [0] = out-of-range coordinate seen
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// ------------------------------------------------------------------ sort.hip
+// LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits).  Result lands in (keys_out, vals_out).
+// Stable.  keys_in/vals_in are clobbered.  Scratch comes from ctx->sort_arena.
+int radix_sort_pairs(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
+                     int64_t n, int nbits, hipStream_t stream);
+size_t radix_sort_scratch_bytes(int64_t n);
+
+// ------------------------------------------------------------------ coords.hip
+int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets_host, int B, int mode,
+                     const float* step, hipStream_t stream);
+int plan_from_coords(Ctx* ctx, const int32_t* coords, int64_t n, int B, hipStream_t stream);
+int plan_level_coords(Ctx* ctx, int level, int32_t* out, hipStream_t stream);
+
+}  // namespace egonn

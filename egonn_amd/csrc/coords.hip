@@ -1,0 +1,612 @@
+// Coordinate plan: voxelisation, Z-order keys, unique, the stride-2 pyramid, 4x4x4 occupancy
+// masks and the kernel maps (k=3 neighbour tables, k=2/s=2 child tables, transposed tables).
+//
+// Replaces (reference call sites): ME.utils.sparse_quantize (datasets/quantization.py:42,83),
+// ME.utils.batched_coordinates (eval/evaluate.py:333), ME.SparseTensor's coordinate-map build
+// (models/minkgl.py:269) and ME's coordinate manager (strided maps + kernel maps) used by every
+// MinkowskiConvolution / MinkowskiConvolutionTranspose in models/minkgl.py.
+//
+// One host synchronisation per plan (the size query): after sort + pyramid, the per-level row counts
+// and per-sample offsets are copied to pinned host memory; everything after that is launched with
+// exact grids.
+#include "common.h"
+
+#include <stdarg.h>
+
+namespace egonn {
+
+// ------------------------------------------------------------------ error + arena
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+int Arena::ensure(size_t bytes) {
+  if (bytes <= cap) return EGONN_OK;
+  size_t want = align_up(bytes + bytes / 4, size_t(1) << 20);
+  if (base) {
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipFree(base));
+    base = nullptr;
+    cap = 0;
+  }
+  HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&base), want));
+  cap = want;
+  off = 0;
+  return EGONN_OK;
+}
+void Arena::release() {
+  if (base) (void)hipFree(base);
+  base = nullptr;
+  cap = off = 0;
+}
+
+// ------------------------------------------------------------------ key construction
+struct QuantParams {
+  int mode;        // 0 = cartesian floor(p / q), 1 = polar (theta deg, r, z) / (s0, s1, s2)
+  float s0, s1, s2;
+};
+
+// floor(p / q) in IEEE fp32 — `torch.floor(pc / q)` on CPU is a true fp32 division (pinned in
+// tests/test_oracle.py::test_cartesian_division_is_true_fp32_division).  The __f*_rn intrinsics stop
+// the compiler from contracting or reassociating.
+__device__ static inline void quantize_point(const QuantParams& qp, float x, float y, float z, int32_t& cx,
+                                             int32_t& cy, int32_t& cz) {
+  if (qp.mode == 0) {
+    cx = (int32_t)floorf(qp.s0 == 1.0f ? x : __fdiv_rn(x, qp.s0));
+    cy = (int32_t)floorf(qp.s0 == 1.0f ? y : __fdiv_rn(y, qp.s0));
+    cz = (int32_t)floorf(qp.s0 == 1.0f ? z : __fdiv_rn(z, qp.s0));
+  } else {
+    // reference datasets/quantization.py:35-40, evaluated left to right in fp32
+    const float theta = __fadd_rn(180.0f, __fdiv_rn(__fmul_rn(atan2f(y, x), 180.0f), 3.14159265358979323846f));
+    const float dist = sqrtf(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)));
+    cx = (int32_t)floorf(__fdiv_rn(theta, qp.s0));
+    cy = (int32_t)floorf(__fdiv_rn(dist, qp.s1));
+    cz = (int32_t)floorf(__fdiv_rn(z, qp.s2));
+  }
+}
+
+__device__ static inline bool encode_key(int32_t b, int32_t cx, int32_t cy, int32_t cz, int cb, uint64_t& key) {
+  const int32_t bias = 1 << (cb - 1);
+  const int32_t lim = 1 << cb;
+  const int32_t ux = cx + bias, uy = cy + bias, uz = cz + bias;
+  const bool ok = (ux >= 0) & (ux < lim) & (uy >= 0) & (uy < lim) & (uz >= 0) & (uz < lim) & (b >= 0);
+  key = ((uint64_t)(uint32_t)b << (3 * cb)) | morton3((uint32_t)ux, (uint32_t)uy, (uint32_t)uz);
+  return ok;
+}
+
+__global__ void points_to_keys_kernel(const float* __restrict__ pts, int64_t n, const int64_t* __restrict__ scan_off,
+                                      int B, QuantParams qp, int cb, uint64_t* __restrict__ keys,
+                                      uint32_t* __restrict__ vals, int32_t* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // sample index = last b with scan_off[b] <= i
+  int lo = 0, hi = B;   // invariant: scan_off[lo] <= i < scan_off[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (scan_off[mid] <= i) lo = mid; else hi = mid;
+  }
+  const float x = pts[3 * i + 0], y = pts[3 * i + 1], z = pts[3 * i + 2];
+  int32_t cx, cy, cz;
+  quantize_point(qp, x, y, z, cx, cy, cz);
+  uint64_t key;
+  const bool finite = isfinite(x) & isfinite(y) & isfinite(z);
+  if (!encode_key(lo, cx, cy, cz, cb, key) || !finite) {
+    atomicOr(flags, 1);
+    key = ~0ull >> 1;
+  }
+  keys[i] = key;
+  vals[i] = (uint32_t)i;
+}
+
+__global__ void coords_to_keys_kernel(const int32_t* __restrict__ c4, int64_t n, int cb, int Bmax,
+                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                      int32_t* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4*>(c4)[i];
+  uint64_t key;
+  if (!encode_key(c.x, c.y, c.z, c.w, cb, key) || c.x >= Bmax) {
+    atomicOr(flags, 1);
+    key = ~0ull >> 1;
+  }
+  keys[i] = key;
+  vals[i] = (uint32_t)i;
+}
+
+// ------------------------------------------------------------------ pyramid (all levels in two launches)
+// For sorted keys, element i starts a new group at level l  iff  (key_i >> 3l) != (key_{i-1} >> 3l).
+// h_i = number of levels (0..NL-1) at which i is a group head; heads are nested (head at l => head at l-1).
+static constexpr int PYR_BLOCK = 256;
+static constexpr int PYR_ROUNDS = 8;
+static constexpr int PYR_TILE = PYR_BLOCK * PYR_ROUNDS;
+static constexpr int NL = EGONN_MAX_LEVELS;
+
+__device__ static inline int head_levels(const uint64_t* __restrict__ keys, int64_t i) {
+  if (i == 0) return NL;
+  const uint64_t d = keys[i] ^ keys[i - 1];
+  if (d == 0) return 0;
+  const int t = (63 - __clzll(d)) / 3;
+  return (t >= NL - 1) ? NL : t + 1;
+}
+
+__global__ __launch_bounds__(PYR_BLOCK) void pyramid_count_kernel(const uint64_t* __restrict__ keys, int64_t n,
+                                                                  int32_t* __restrict__ tilecnt) {
+  __shared__ int32_t cnt[PYR_BLOCK / 64][NL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t wbase = (int64_t)blockIdx.x * PYR_TILE + (int64_t)wave * 64 * PYR_ROUNDS;
+  int32_t c[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) c[l] = 0;
+  for (int r = 0; r < PYR_ROUNDS; ++r) {
+    const int64_t i = wbase + r * 64 + lane;
+    const int h = (i < n) ? head_levels(keys, i) : 0;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) c[l] += __popcll(__ballot(h > l));
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) cnt[wave][l] = c[l];
+  }
+  __syncthreads();
+  if (tid < NL) {
+    int32_t s = 0;
+    for (int w = 0; w < PYR_BLOCK / 64; ++w) s += cnt[w][tid];
+    tilecnt[(int64_t)blockIdx.x * NL + tid] = s;
+  }
+}
+
+struct PyramidOut {
+  uint64_t* keys[NL];
+  int32_t* parent[NL];
+  int32_t* cstart[NL];
+  int32_t* boff[EGONN_NUM_LEVELS];
+  int32_t* perm0;
+  int32_t* counts;    // [NL] rows per level, [NL] = batch size seen (max batch index + 1)
+};
+
+__global__ __launch_bounds__(PYR_BLOCK) void pyramid_apply_kernel(const uint64_t* __restrict__ keys,
+                                                                  const uint32_t* __restrict__ vals, int64_t n,
+                                                                  const int32_t* __restrict__ tilecnt, int ntiles,
+                                                                  int cb, int B, PyramidOut out) {
+  __shared__ int32_t red[PYR_BLOCK / 64][NL];
+  __shared__ int32_t tilebase[NL];
+  __shared__ int32_t wavecnt[PYR_BLOCK / 64][NL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x;
+
+  // ---- rows of every level in earlier tiles
+  {
+    int32_t p[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) p[l] = 0;
+    for (int t = tid; t < tile; t += PYR_BLOCK) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l) p[l] += tilecnt[(int64_t)t * NL + l];
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      int32_t v = p[l];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane == 0) red[wave][l] = v;
+    }
+    __syncthreads();
+    if (tid < NL) {
+      int32_t s = 0;
+      for (int w = 0; w < PYR_BLOCK / 64; ++w) s += red[w][tid];
+      tilebase[tid] = s;
+    }
+  }
+
+  // ---- pass 1: head levels of this wave's keys + wave totals
+  const int64_t wbase = (int64_t)tile * PYR_TILE + (int64_t)wave * 64 * PYR_ROUNDS;
+  int hreg[PYR_ROUNDS];
+  int32_t wc[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) wc[l] = 0;
+#pragma unroll
+  for (int r = 0; r < PYR_ROUNDS; ++r) {
+    const int64_t i = wbase + r * 64 + lane;
+    hreg[r] = (i < n) ? head_levels(keys, i) : 0;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) wc[l] += __popcll(__ballot(hreg[r] > l));
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) wavecnt[wave][l] = wc[l];
+  }
+  __syncthreads();
+  int32_t run[NL];   // heads of level l strictly before the current round of this wave (wave-uniform)
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    int32_t s = tilebase[l];
+    for (int w = 0; w < wave; ++w) s += wavecnt[w][l];
+    run[l] = s;
+  }
+
+  // ---- pass 2: rank and write
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int bshift = 3 * cb;
+#pragma unroll
+  for (int r = 0; r < PYR_ROUNDS; ++r) {
+    const int64_t i = wbase + r * 64 + lane;
+    const int h = hreg[r];
+    const uint64_t key = (i < n) ? keys[i] : 0ull;
+    int32_t excl[NL];   // heads of level l among elements < i
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const uint64_t m = __ballot(h > l);
+      excl[l] = run[l] + __popcll(m & lt);
+      run[l] += __popcll(m);
+    }
+    if (i < n && h > 0) {
+      out.perm0[excl[0]] = (int32_t)vals[i];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        if (l < h) {
+          out.keys[l][excl[l]] = key >> (3 * l);
+          if (l >= 1) out.cstart[l][excl[l]] = excl[l - 1];
+          if (l + 1 < NL) {
+            // group index of i at level l+1: a head there -> excl, otherwise the group opened earlier
+            const int32_t g = (l + 1 < h) ? excl[l + 1] : excl[l + 1] - 1;
+            out.parent[l][excl[l]] = g;
+          }
+        }
+      }
+      // per-sample offsets: a change of the batch index makes i a head at every level
+      const int32_t b = (int32_t)(key >> bshift);
+      const int32_t bprev = (i == 0) ? -1 : (int32_t)(keys[i - 1] >> bshift);
+      if (b != bprev) {
+        for (int32_t bb = bprev + 1; bb <= b && bb <= B; ++bb) {
+#pragma unroll
+          for (int l = 0; l < EGONN_NUM_LEVELS; ++l) out.boff[l][bb] = excl[l];
+        }
+      }
+    }
+    // ---- the globally last element closes every table
+    if (i == n - 1) {
+      const int32_t blast = (int32_t)(key >> bshift);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        const int32_t total = excl[l] + (h > l ? 1 : 0);
+        out.counts[l] = total;
+        if (l >= 1) {
+          const int32_t below = excl[l - 1] + (h > l - 1 ? 1 : 0);
+          out.cstart[l][total] = below;
+        }
+        if (l < EGONN_NUM_LEVELS) {
+          for (int32_t bb = blast + 1; bb <= B; ++bb) out.boff[l][bb] = total;
+        }
+      }
+      out.counts[NL] = blast + 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ 4x4x4 occupancy masks
+// Level L row j is a 4x4x4 block of level-(L-2) voxels; its rows at level L-2 are contiguous.
+struct MaskArgs {
+  const int32_t* cstartL[NL];     // cstart of level L
+  const uint64_t* keys[NL];       // keys of level L
+  uint64_t* mask[NL];
+  int32_t* bstart[NL];
+  int32_t n[NL];
+  int32_t prefix[NL + 1];         // prefix over levels 2..NL-1 of n[L]
+};
+
+__global__ void block_mask_kernel(MaskArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.prefix[NL]) return;
+  int L = 2;
+  while (L < NL - 1 && t >= a.prefix[L + 1]) ++L;
+  const int32_t j = (int32_t)(t - a.prefix[L]);
+  const int32_t* cs1 = a.cstartL[L];
+  const int32_t* cs2 = a.cstartL[L - 1];
+  const int32_t s = cs2[cs1[j]];
+  const int32_t e = cs2[cs1[j + 1]];
+  const uint64_t* k = a.keys[L - 2];
+  uint64_t m = 0;
+  for (int32_t r = s; r < e; ++r) m |= 1ull << (k[r] & 63);
+  a.mask[L][j] = m;
+  a.bstart[L][j] = s;
+}
+
+// ------------------------------------------------------------------ k=3 neighbour table
+// One wave per level-(l+2) block.  27 lanes find the adjacent blocks by binary search; every
+// (voxel, offset) pair is then an LDS mask test + popcount.
+__device__ static inline int32_t find_key(const uint64_t* __restrict__ keys, int32_t n, uint64_t q) {
+  int32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (keys[mid] < q) lo = mid + 1; else hi = mid;
+  }
+  return (lo < n && keys[lo] == q) ? lo : -1;
+}
+
+__device__ static inline uint32_t bit_of_local(uint32_t lx, uint32_t ly, uint32_t lz) {   // 2 bits each
+  return (lx & 1) | ((ly & 1) << 1) | ((lz & 1) << 2) | ((lx & 2) << 2) | ((ly & 2) << 3) | ((lz & 2) << 4);
+}
+
+template <int KS>   // 3 or 5
+__device__ static inline void neighbour_blocks(const uint64_t* __restrict__ bkeys, const uint64_t* __restrict__ bmask,
+                                               const int32_t* __restrict__ bstart, int32_t nblocks, int32_t j,
+                                               int cbL, int lane, uint64_t* nbm, int32_t* nbs) {
+  if (lane < 27) {
+    const uint64_t key = bkeys[j];
+    const uint64_t mmask = (1ull << (3 * cbL)) - 1;
+    const uint64_t mort = key & mmask;
+    const uint64_t bat = key >> (3 * cbL);
+    const int32_t bx = (int32_t)compact1by2(mort), by = (int32_t)compact1by2(mort >> 1),
+                  bz = (int32_t)compact1by2(mort >> 2);
+    const int32_t nx = bx + (lane % 3) - 1, ny = by + (lane / 3) % 3 - 1, nz = bz + lane / 9 - 1;
+    const int32_t lim = 1 << cbL;
+    int32_t idx = -1;
+    if (lane == 13) {
+      idx = j;
+    } else if (nx >= 0 && nx < lim && ny >= 0 && ny < lim && nz >= 0 && nz < lim) {
+      idx = find_key(bkeys, nblocks, (bat << (3 * cbL)) | morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    }
+    nbm[lane] = idx >= 0 ? bmask[idx] : 0ull;
+    nbs[lane] = idx >= 0 ? bstart[idx] : 0;
+  }
+}
+
+__device__ static inline int32_t lookup_local(const uint64_t* nbm, const int32_t* nbs, int32_t nx, int32_t ny,
+                                              int32_t nz) {
+  // nx,ny,nz in [-2, 5]: local coordinates relative to the centre block
+  const int32_t sx = (nx < 0) ? 0 : (nx > 3 ? 2 : 1);
+  const int32_t sy = (ny < 0) ? 0 : (ny > 3 ? 2 : 1);
+  const int32_t sz = (nz < 0) ? 0 : (nz > 3 ? 2 : 1);
+  const int32_t slot = sx + 3 * sy + 9 * sz;
+  const uint32_t bit = bit_of_local((uint32_t)nx & 3, (uint32_t)ny & 3, (uint32_t)nz & 3);
+  const uint64_t m = nbm[slot];
+  if (!((m >> bit) & 1)) return -1;
+  return nbs[slot] + __popcll(m & ((1ull << bit) - 1));
+}
+
+__global__ __launch_bounds__(256) void nbr27_kernel(const uint64_t* __restrict__ vkeys,      // level l
+                                                     const uint64_t* __restrict__ bkeys,      // level l+2
+                                                     const uint64_t* __restrict__ bmask,
+                                                     const int32_t* __restrict__ bstart, int32_t nblocks,
+                                                     int32_t nvox, int cbL, int32_t* __restrict__ nbr) {
+  __shared__ uint64_t s_m[4][27];
+  __shared__ int32_t s_s[4][27];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int32_t j = blockIdx.x * 4 + wave;
+  if (j >= nblocks) return;
+  neighbour_blocks<3>(bkeys, bmask, bstart, nblocks, j, cbL, lane, s_m[wave], s_s[wave]);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int32_t s = bstart[j];
+  const int32_t e = (j + 1 < nblocks) ? bstart[j + 1] : nvox;
+  const int32_t items = (e - s) * 27;
+  for (int32_t t = lane; t < items; t += 64) {
+    const int32_t v = t / 27, k = t - v * 27;
+    const uint32_t lk = (uint32_t)(vkeys[s + v] & 63);
+    const int32_t lx = (lk & 1) | ((lk >> 2) & 2), ly = ((lk >> 1) & 1) | ((lk >> 3) & 2),
+                  lz = ((lk >> 2) & 1) | ((lk >> 4) & 2);
+    const int32_t nx = lx + (k % 3) - 1, ny = ly + (k / 3) % 3 - 1, nz = lz + k / 9 - 1;
+    nbr[(int64_t)s * 27 + t] = lookup_local(s_m[wave], s_s[wave], nx, ny, nz);
+  }
+}
+
+// ------------------------------------------------------------------ k=2,s=2 tables
+__global__ void nbr8_kernel(const int32_t* __restrict__ cstart, const uint64_t* __restrict__ ckeys, int32_t n,
+                            int32_t* __restrict__ nbr8) {
+  const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  int32_t r[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  const int32_t s = cstart[p], e = cstart[p + 1];
+  for (int32_t c = s; c < e; ++c) {
+    const int slot = (int)(ckeys[c] & 7);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (q == slot) r[q] = c;
+  }
+  int4* o = reinterpret_cast<int4*>(nbr8 + (int64_t)p * 8);
+  o[0] = make_int4(r[0], r[1], r[2], r[3]);
+  o[1] = make_int4(r[4], r[5], r[6], r[7]);
+}
+
+__global__ void nbrT_kernel(const int32_t* __restrict__ parent, const uint64_t* __restrict__ keys, int32_t n,
+                            int32_t* __restrict__ nbrT) {
+  const int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const int slot = (int)(keys[c] & 7);
+  const int32_t p = parent[c];
+  int32_t r[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) r[q] = (q == slot) ? p : -1;
+  int4* o = reinterpret_cast<int4*>(nbrT + (int64_t)c * 8);
+  o[0] = make_int4(r[0], r[1], r[2], r[3]);
+  o[1] = make_int4(r[4], r[5], r[6], r[7]);
+}
+
+__global__ void decode_coords_kernel(const uint64_t* __restrict__ keys, int32_t n, int level, int cb,
+                                     int32_t* __restrict__ out) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int cbL = cb - level;
+  const uint64_t key = keys[i];
+  const uint64_t mort = key & ((1ull << (3 * cbL)) - 1);
+  const int32_t bias = 1 << (cb - 1);
+  int4 o;
+  o.x = (int32_t)(key >> (3 * cbL));
+  o.y = ((int32_t)compact1by2(mort) << level) - bias;
+  o.z = ((int32_t)compact1by2(mort >> 1) << level) - bias;
+  o.w = ((int32_t)compact1by2(mort >> 2) << level) - bias;
+  reinterpret_cast<int4*>(out)[i] = o;
+}
+
+// ------------------------------------------------------------------ host side
+static int batch_bits(int B) {
+  int b = 0;
+  while ((1 << b) < B) ++b;
+  return b < 1 ? 1 : b;
+}
+
+static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* vals_raw, uint64_t* keys_sorted,
+                                        uint32_t* vals_sorted, int64_t n, int B, hipStream_t stream) {
+  Plan& P = ctx->plan;
+  const int cb = ctx->coord_bits;
+  Arena& A = ctx->plan_arena;
+  EGONN_TRY(radix_sort_pairs(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, 3 * cb + batch_bits(B), stream));
+
+  const int ntiles = (int)cdiv(n, PYR_TILE);
+  int32_t* tilecnt = A.alloc<int32_t>((size_t)ntiles * NL);
+  PyramidOut po;
+  for (int l = 0; l < NL; ++l) {
+    // rows at level l <= n ; a level-l row needs >= 1 row below, so upper levels could be bounded tighter,
+    // but HBM is plentiful: worst case everywhere, the arrays are tiny next to the features.
+    P.lv[l] = Level();
+    P.lv[l].keys = po.keys[l] = A.alloc<uint64_t>(n);
+    P.lv[l].parent = po.parent[l] = A.alloc<int32_t>(n);
+    P.lv[l].cstart = po.cstart[l] = A.alloc<int32_t>(n + 1);
+    EGONN_REQUIRE(po.keys[l] && po.parent[l] && po.cstart[l], EGONN_ERR_STATE, "plan arena too small");
+  }
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) {
+    P.lv[l].boff = po.boff[l] = A.alloc<int32_t>(B + 1);
+    EGONN_REQUIRE(po.boff[l], EGONN_ERR_STATE, "plan arena too small");
+  }
+  P.perm0 = po.perm0 = A.alloc<int32_t>(n);
+  po.counts = ctx->dev_counts;
+  EGONN_REQUIRE(tilecnt && po.perm0, EGONN_ERR_STATE, "plan arena too small");
+
+  hipLaunchKernelGGL(pyramid_count_kernel, dim3(ntiles), dim3(PYR_BLOCK), 0, stream, keys_sorted, n, tilecnt);
+  hipLaunchKernelGGL(pyramid_apply_kernel, dim3(ntiles), dim3(PYR_BLOCK), 0, stream, keys_sorted, vals_sorted, n,
+                     tilecnt, ntiles, cb, B, po);
+  HIP_CHECK(hipGetLastError());
+
+  // ---- the size query (single host sync of the plan): counts, range flag, per-sample offsets
+  HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ctx->dev_counts, sizeof(int32_t) * (NL + 1), hipMemcpyDeviceToHost,
+                           stream));
+  HIP_CHECK(hipMemcpyAsync(ctx->host_counts + 16, ctx->dev_flags, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l)
+    HIP_CHECK(hipMemcpyAsync(ctx->host_counts + 32 + (size_t)l * (EGONN_MAX_BATCH + 1), P.lv[l].boff,
+                             sizeof(int32_t) * (B + 1), hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  EGONN_REQUIRE(ctx->host_counts[16] == 0, EGONN_ERR_RANGE,
+                "coordinate outside the +-2^%d voxel range of coord_bits=%d (or non-finite point / batch index "
+                "out of range)", cb - 1, cb);
+  EGONN_REQUIRE(ctx->host_counts[NL] <= B, EGONN_ERR_RANGE, "batch index %d >= batch size %d",
+                ctx->host_counts[NL] - 1, B);
+  for (int l = 0; l < NL; ++l) P.lv[l].n = ctx->host_counts[l];
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) {
+    const int32_t* src = ctx->host_counts + 32 + (size_t)l * (EGONN_MAX_BATCH + 1);
+    P.boff_host[l].assign(src, src + B + 1);
+  }
+  P.batch = B;
+  P.coord_bits = cb;
+  P.n_input = n;
+
+  // ---- masks for levels 2..9 (blocks of levels 0..7)
+  MaskArgs ma;
+  int32_t pre = 0;
+  for (int L = 0; L < NL; ++L) {
+    ma.cstartL[L] = P.lv[L].cstart;
+    ma.keys[L] = P.lv[L].keys;
+    ma.n[L] = (int32_t)P.lv[L].n;
+    ma.mask[L] = nullptr;
+    ma.bstart[L] = nullptr;
+    ma.prefix[L] = 0;
+  }
+  for (int L = 2; L < NL; ++L) {
+    P.lv[L].mask = ma.mask[L] = A.alloc<uint64_t>(P.lv[L].n);
+    P.lv[L].bstart = ma.bstart[L] = A.alloc<int32_t>(P.lv[L].n);
+    EGONN_REQUIRE(ma.mask[L] && ma.bstart[L], EGONN_ERR_STATE, "plan arena too small");
+    ma.prefix[L] = pre;
+    pre += (int32_t)P.lv[L].n;
+  }
+  ma.prefix[NL] = pre;
+  if (pre > 0) hipLaunchKernelGGL(block_mask_kernel, dim3((unsigned)cdiv(pre, 256)), dim3(256), 0, stream, ma);
+
+  // ---- kernel maps
+  for (int l = 1; l < EGONN_NUM_LEVELS; ++l) {
+    Level& V = P.lv[l];
+    const int32_t nv = (int32_t)V.n;
+    V.nbr27 = A.alloc<int32_t>((size_t)nv * 27);
+    V.nbr8 = A.alloc<int32_t>((size_t)nv * 8);
+    V.nbrT = A.alloc<int32_t>((size_t)nv * 8);
+    EGONN_REQUIRE(V.nbr27 && V.nbr8 && V.nbrT, EGONN_ERR_STATE, "plan arena too small");
+    if (nv == 0) continue;
+    const Level& Bk = P.lv[l + 2];
+    hipLaunchKernelGGL(nbr27_kernel, dim3((unsigned)cdiv(Bk.n, 4)), dim3(256), 0, stream, V.keys, Bk.keys, Bk.mask,
+                       Bk.bstart, (int32_t)Bk.n, nv, cb - (l + 2), V.nbr27);
+    hipLaunchKernelGGL(nbr8_kernel, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, stream, V.cstart, P.lv[l - 1].keys,
+                       nv, V.nbr8);
+    hipLaunchKernelGGL(nbrT_kernel, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, stream, V.parent, V.keys, nv,
+                       V.nbrT);
+  }
+  HIP_CHECK(hipGetLastError());
+  P.valid = true;
+  return EGONN_OK;
+}
+
+static size_t plan_arena_bytes(int64_t n, int B) {
+  // raw+sorted keys/vals, 10 levels x (keys, parent, cstart, mask, bstart), perm, maps of levels 1..7 (<= n rows each)
+  size_t per_row = 2 * (8 + 4) + NL * (8 + 4 + 4 + 8 + 4) + 4 + 7 * (27 + 8 + 8) * 4;
+  return (size_t)(n + 8) * per_row + (size_t)(B + 1) * 4 * EGONN_NUM_LEVELS + (size_t)cdiv(n, PYR_TILE) * NL * 4 +
+         (1 << 20);
+}
+
+int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets_host, int B, int mode,
+                     const float* step, hipStream_t stream) {
+  ctx->plan.valid = false;
+  EGONN_REQUIRE(B >= 1 && B <= EGONN_MAX_BATCH, EGONN_ERR_INVALID, "batch size %d outside [1,%d]", B, EGONN_MAX_BATCH);
+  const int64_t n = scan_offsets_host[B];
+  EGONN_REQUIRE(scan_offsets_host[0] == 0 && n >= 1, EGONN_ERR_INVALID, "empty input (n=%lld points)", (long long)n);
+  for (int b = 0; b < B; ++b)
+    EGONN_REQUIRE(scan_offsets_host[b] <= scan_offsets_host[b + 1], EGONN_ERR_INVALID, "scan offsets not monotone");
+  EGONN_REQUIRE(mode == 0 || mode == 1, EGONN_ERR_INVALID, "unknown quantiser mode %d", mode);
+  EGONN_TRY(ctx->plan_arena.ensure(plan_arena_bytes(n, B)));
+  Arena& A = ctx->plan_arena;
+  A.reset();
+  uint64_t* k0 = A.alloc<uint64_t>(n);
+  uint64_t* k1 = A.alloc<uint64_t>(n);
+  uint32_t* v0 = A.alloc<uint32_t>(n);
+  uint32_t* v1 = A.alloc<uint32_t>(n);
+  int64_t* doff = A.alloc<int64_t>(B + 1);
+  EGONN_REQUIRE(k0 && k1 && v0 && v1 && doff, EGONN_ERR_STATE, "plan arena too small");
+  HIP_CHECK(hipMemcpyAsync(doff, scan_offsets_host, sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice, stream));
+  HIP_CHECK(hipMemsetAsync(ctx->dev_flags, 0, sizeof(int32_t), stream));
+  QuantParams qp{mode, step[0], mode ? step[1] : step[0], mode ? step[2] : step[0]};
+  hipLaunchKernelGGL(points_to_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, points, n, doff, B, qp,
+                     ctx->coord_bits, k0, v0, ctx->dev_flags);
+  return build_plan_from_sorted_input(ctx, k0, v0, k1, v1, n, B, stream);
+}
+
+int plan_from_coords(Ctx* ctx, const int32_t* coords, int64_t n, int B, hipStream_t stream) {
+  ctx->plan.valid = false;
+  EGONN_REQUIRE(n >= 1, EGONN_ERR_INVALID, "empty coordinate list");
+  EGONN_REQUIRE(B >= 1 && B <= EGONN_MAX_BATCH, EGONN_ERR_INVALID, "batch size %d outside [1,%d]", B, EGONN_MAX_BATCH);
+  EGONN_TRY(ctx->plan_arena.ensure(plan_arena_bytes(n, B)));
+  Arena& A = ctx->plan_arena;
+  A.reset();
+  uint64_t* k0 = A.alloc<uint64_t>(n);
+  uint64_t* k1 = A.alloc<uint64_t>(n);
+  uint32_t* v0 = A.alloc<uint32_t>(n);
+  uint32_t* v1 = A.alloc<uint32_t>(n);
+  EGONN_REQUIRE(k0 && k1 && v0 && v1, EGONN_ERR_STATE, "plan arena too small");
+  HIP_CHECK(hipMemsetAsync(ctx->dev_flags, 0, sizeof(int32_t), stream));
+  hipLaunchKernelGGL(coords_to_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, coords, n,
+                     ctx->coord_bits, B, k0, v0, ctx->dev_flags);
+  return build_plan_from_sorted_input(ctx, k0, v0, k1, v1, n, B, stream);
+}
+
+int plan_level_coords(Ctx* ctx, int level, int32_t* out, hipStream_t stream) {
+  EGONN_REQUIRE(ctx->plan.valid, EGONN_ERR_STATE, "no coordinate plan (call egonn_voxelize / egonn_coords_set first)");
+  EGONN_REQUIRE(level >= 0 && level < EGONN_MAX_LEVELS, EGONN_ERR_INVALID, "level %d out of range", level);
+  const Level& L = ctx->plan.lv[level];
+  if (L.n == 0) return EGONN_OK;
+  hipLaunchKernelGGL(decode_coords_kernel, dim3((unsigned)cdiv(L.n, 256)), dim3(256), 0, stream, L.keys, (int32_t)L.n,
+                     level, ctx->plan.coord_bits, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+}  // namespace egonn

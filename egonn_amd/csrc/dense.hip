@@ -1,0 +1,377 @@
+// Row-wise (dense) kernels of the EgoNN path: 1x1 convolutions / nn.Linear on exact-f32 MFMA, folded
+// BatchNorm, ECA gate, GeM pooling, L2 normalisation, keypoint positions and top-k keypoint selection.
+//
+// Reference call sites: MinkowskiConvolution(k=1) models/minkgl.py:43,124 ; MinkowskiLinear
+// models/minkgl.py:167-217 ; MinkowskiBatchNorm (nn.BatchNorm1d eval) ; ECALayer layers/eca_block.py:11-36 ;
+// GeM layers/pooling.py:82-86 ; MinkowskiFunctional.normalize models/minkgl.py:223 ;
+// Quantizer.keypoint_position datasets/quantization.py:60-72,93-103 ; torch.topk eval/evaluate.py:359.
+#include "common.h"
+#include "kernels.h"
+
+namespace egonn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ static inline float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_TANH: return tanhf(v);
+    case ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));     // torch softplus(beta=1, threshold=20)
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+
+// ------------------------------------------------------------------ dense GEMM + epilogue
+// One wave = 16 rows x all output columns (16 at a time), v_mfma_f32_16x16x4_f32.  The contraction index
+// inside a 16-wide k-block is permuted (lane group g owns ci = 16t + 4g .. 4g+3) so that A comes in as
+// one float4 per lane per k-block; B uses the same permutation.
+template <int W_OUT_IN>
+__global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ in, int64_t n, int cin,
+                                                    const float* __restrict__ W, int cout,
+                                                    const float* __restrict__ bias, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, int act,
+                                                    const float* __restrict__ residual, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int64_t row_base = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  if (row_base >= n) return;
+  const int64_t row = row_base + l15;
+  const bool vrow = row < n;
+  const float* arow = in + row * cin + 4 * g4;
+  const int ksteps = cin >> 4;
+  for (int n0 = 0; n0 < cout; n0 += 16) {
+    const int col = n0 + l15;
+    const bool vcol = col < cout;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < ksteps; ++t) {
+      float4 a4 = make_float4(0, 0, 0, 0);
+      if (vrow) a4 = *reinterpret_cast<const float4*>(arow + 16 * t);
+      float4 b4 = make_float4(0, 0, 0, 0);
+      if (vcol) {
+        if (W_OUT_IN) {
+          b4 = *reinterpret_cast<const float4*>(W + (int64_t)col * cin + 16 * t + 4 * g4);
+        } else {
+          const float* wp = W + (int64_t)(16 * t + 4 * g4) * cout + col;
+          b4.x = wp[0];
+          b4.y = wp[cout];
+          b4.z = wp[2 * (int64_t)cout];
+          b4.w = wp[3 * (int64_t)cout];
+        }
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+    if (vcol) {
+      const float bi = bias ? bias[col] : 0.f;
+      const float sc = scale ? scale[col] : 1.f, sh = scale ? shift[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t orow = row_base + 4 * g4 + r;
+        if (orow < n) {
+          float v = acc[r] + bi;
+          if (scale) v = v * sc + sh;
+          v = apply_act(v, act);
+          if (residual) v += residual[orow * cout + col];
+          out[orow * cout + col] = v;
+        }
+      }
+    }
+  }
+}
+
+int dense_forward(const float* in, int64_t n, int cin, const float* W, int w_out_in, int cout, const float* bias,
+                  const float* scale, const float* shift, int act, const float* residual, float* out,
+                  hipStream_t stream) {
+  if (n == 0) return EGONN_OK;
+  EGONN_REQUIRE(cin % 16 == 0 && cin >= 16, EGONN_ERR_INVALID, "dense: cin=%d must be a multiple of 16", cin);
+  const dim3 grid((unsigned)cdiv(n, 64));
+  if (w_out_in)
+    hipLaunchKernelGGL(dense_kernel<1>, grid, dim3(256), 0, stream, in, n, cin, W, cout, bias, scale, shift, act,
+                       residual, out);
+  else
+    hipLaunchKernelGGL(dense_kernel<0>, grid, dim3(256), 0, stream, in, n, cin, W, cout, bias, scale, shift, act,
+                       residual, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ BatchNorm folding (eval mode)
+__global__ void bn_fold_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                               const float* __restrict__ rm, const float* __restrict__ rv, float eps, int c,
+                               float* __restrict__ scale, float* __restrict__ shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const float s = w[i] / sqrtf(rv[i] + eps);
+  scale[i] = s;
+  shift[i] = b[i] - rm[i] * s;
+}
+int bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps, int c, float* scale,
+            float* shift, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)cdiv(c, 128)), dim3(128), 0, stream, w, b, rm, rv, eps, c, scale,
+                     shift);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ row gather (features -> sorted row order)
+__global__ void gather_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ perm, int64_t n, int c,
+                                   float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * c) return;
+  const int64_t r = t / c;
+  const int ch = (int)(t - r * c);
+  out[t] = in[(int64_t)perm[r] * c + ch];
+}
+int gather_rows(const float* in, const int32_t* perm, int64_t n, int c, float* out, hipStream_t stream) {
+  if (n == 0) return EGONN_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(n * c, 256)), dim3(256), 0, stream, in, perm, n, c, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ per-sample column sums (deterministic)
+// grid (SEG_CHUNKS, B): block (ch, b) sums rows [s + ch*len/CH, s + (ch+1)*len/CH) of sample b.
+__global__ __launch_bounds__(256) void segment_partial_kernel(const float* __restrict__ in,
+                                                               const int32_t* __restrict__ boff, int c, int pow_mode,
+                                                               const float* __restrict__ pexp,
+                                                               float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int32_t s = boff[b], e = boff[b + 1];
+  const int64_t len = e - s;
+  const int32_t r0 = s + (int32_t)(len * ch / SEG_CHUNKS), r1 = s + (int32_t)(len * (ch + 1) / SEG_CHUNKS);
+  const int tid = threadIdx.x;
+  const float p = pow_mode ? pexp[0] : 1.f;
+  // c <= 256: thread -> (row lane, channel); for c < 256 several rows advance in parallel
+  const int rl = tid / c, cidx = tid - rl * c, nrl = 256 / c;
+  float acc = 0.f;
+  if (rl < nrl) {
+    for (int32_t r = r0 + rl; r < r1; r += nrl) {
+      float v = in[(int64_t)r * c + cidx];
+      if (pow_mode) v = powf(fmaxf(v, 1e-6f), p);
+      acc += v;
+    }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  if (tid < c) {
+    float sum = 0.f;
+    for (int k = 0; k < nrl; ++k) sum += red[k * c + tid];
+    partial[((int64_t)b * SEG_CHUNKS + ch) * c + tid] = sum;
+  }
+}
+int segment_partial_sums(const float* in, const int32_t* boff, int B, int c, int pow_mode, const float* p,
+                         float* partial, hipStream_t stream) {
+  EGONN_REQUIRE(c >= 1 && c <= 256 && 256 % c == 0, EGONN_ERR_INVALID, "segment sums: %d channels unsupported", c);
+  hipLaunchKernelGGL(segment_partial_kernel, dim3(SEG_CHUNKS, B), dim3(256), 0, stream, in, boff, c, pow_mode, p,
+                     partial);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ ECA: gate = sigmoid(conv1d_k(mean)) ; out = relu(x*gate + res)
+__global__ void eca_gate_kernel(const float* __restrict__ partial, const int32_t* __restrict__ boff, int c,
+                                const float* __restrict__ wconv, int ksize, float* __restrict__ gate) {
+  extern __shared__ float mean[];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int32_t cntr = boff[b + 1] - boff[b];
+  if (t < c) {
+    float s = 0.f;
+    for (int ch = 0; ch < SEG_CHUNKS; ++ch) s += partial[((int64_t)b * SEG_CHUNKS + ch) * c + t];
+    mean[t] = cntr > 0 ? s / (float)cntr : 0.f;
+  }
+  __syncthreads();
+  if (t < c) {
+    const int pad = (ksize - 1) / 2;
+    float y = 0.f;
+    for (int j = 0; j < ksize; ++j) {
+      const int q = t + j - pad;
+      if (q >= 0 && q < c) y += wconv[j] * mean[q];
+    }
+    gate[(int64_t)b * c + t] = 1.f / (1.f + expf(-y));
+  }
+}
+
+__device__ static inline int sample_of_row(const int32_t* __restrict__ boff, int B, int32_t r) {
+  int lo = 0, hi = B;   // boff[lo] <= r < boff[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (boff[mid] <= r) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void eca_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                 const float* __restrict__ gate, const int32_t* __restrict__ boff, int B, int64_t n,
+                                 int c4, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * c4) return;
+  const int32_t r = (int32_t)(t / c4);
+  const int q = (int)(t - (int64_t)r * c4);
+  const int b = sample_of_row(boff, B, r);
+  const float4 xv = reinterpret_cast<const float4*>(x)[t];
+  const float4 rv = reinterpret_cast<const float4*>(res)[t];
+  const float4 g = reinterpret_cast<const float4*>(gate)[(int64_t)b * c4 + q];
+  float4 o;
+  o.x = fmaxf(xv.x * g.x + rv.x, 0.f);
+  o.y = fmaxf(xv.y * g.y + rv.y, 0.f);
+  o.z = fmaxf(xv.z * g.z + rv.z, 0.f);
+  o.w = fmaxf(xv.w * g.w + rv.w, 0.f);
+  reinterpret_cast<float4*>(out)[t] = o;
+}
+
+int eca_apply(const float* x, const float* res, const float* partial, const int32_t* boff, int B, int64_t n, int c,
+              const float* wconv, int ksize, float* out, hipStream_t stream) {
+  if (n == 0) return EGONN_OK;
+  // gate lives right behind the partial sums: partial[B*SEG_CHUNKS*c] | gate[B*c]
+  float* gate = const_cast<float*>(partial) + (int64_t)B * SEG_CHUNKS * c;
+  hipLaunchKernelGGL(eca_gate_kernel, dim3(B), dim3(256), c * sizeof(float), stream, partial, boff, c, wconv, ksize,
+                     gate);
+  const int c4 = c / 4;
+  hipLaunchKernelGGL(eca_apply_kernel, dim3((unsigned)cdiv(n * c4, 256)), dim3(256), 0, stream, x, res, gate, boff, B,
+                     n, c4, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ GeM finish
+__global__ void gem_finish_kernel(const float* __restrict__ partial, const int32_t* __restrict__ boff, int c,
+                                  const float* __restrict__ pexp, float* __restrict__ out) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t >= c) return;
+  const int32_t cntr = boff[b + 1] - boff[b];
+  float s = 0.f;
+  for (int ch = 0; ch < SEG_CHUNKS; ++ch) s += partial[((int64_t)b * SEG_CHUNKS + ch) * c + t];
+  const float m = cntr > 0 ? s / (float)cntr : 0.f;
+  out[(int64_t)b * c + t] = powf(m, 1.f / pexp[0]);
+}
+int gem_finish(const float* partial, const int32_t* boff, int B, int c, const float* p, float* out,
+               hipStream_t stream) {
+  hipLaunchKernelGGL(gem_finish_kernel, dim3(B), dim3(256), 0, stream, partial, boff, c, p, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ row L2 normalisation (F.normalize eps=1e-12)
+__global__ void l2norm_kernel(float* __restrict__ x, int64_t n, int c) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  float* p = x + row * c;
+  float ss = 0.f;
+  for (int i = lane; i < c; i += 64) ss += p[i] * p[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+  for (int i = lane; i < c; i += 64) p[i] *= inv;
+}
+int l2_normalize_rows(float* x, int64_t n, int c, hipStream_t stream) {
+  if (n == 0) return EGONN_OK;
+  hipLaunchKernelGGL(l2norm_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream, x, n, c);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ keypoint positions
+__global__ void keypoint_kernel(const uint64_t* __restrict__ keys, int64_t n, int level, int cb,
+                                const float* __restrict__ offs, int mode, float s0, float s1, float s2, int ignore,
+                                float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int cbL = cb - level;
+  const uint64_t mort = keys[i] & ((1ull << (3 * cbL)) - 1);
+  const int32_t bias = 1 << (cb - 1);
+  const float cx = (float)(((int32_t)compact1by2(mort) << level) - bias);
+  const float cy = (float)(((int32_t)compact1by2(mort >> 1) << level) - bias);
+  const float cz = (float)(((int32_t)compact1by2(mort >> 2) << level) - bias);
+  const float stride = (float)(1 << level);
+  const float ox = ignore ? 0.f : offs[3 * i + 0], oy = ignore ? 0.f : offs[3 * i + 1],
+              oz = ignore ? 0.f : offs[3 * i + 2];
+  // (C + 0.5) * q + offset * (stride * q) / 2, evaluated like the reference (no contraction)
+  const float px = __fadd_rn(__fmul_rn(__fadd_rn(cx, 0.5f), s0), __fdiv_rn(__fmul_rn(ox, __fmul_rn(stride, s0)), 2.f));
+  const float py = __fadd_rn(__fmul_rn(__fadd_rn(cy, 0.5f), s1), __fdiv_rn(__fmul_rn(oy, __fmul_rn(stride, s1)), 2.f));
+  const float pz = __fadd_rn(__fmul_rn(__fadd_rn(cz, 0.5f), s2), __fdiv_rn(__fmul_rn(oz, __fmul_rn(stride, s2)), 2.f));
+  if (mode == 0) {
+    out[3 * i + 0] = px; out[3 * i + 1] = py; out[3 * i + 2] = pz;
+  } else {
+    // polar -> cartesian (reference quantization.py:46-53): theta = pi * (deg - 180) / 180
+    const float theta = __fdiv_rn(__fmul_rn(3.14159265358979323846f, __fadd_rn(px, -180.f)), 180.f);
+    out[3 * i + 0] = cosf(theta) * py;
+    out[3 * i + 1] = sinf(theta) * py;
+    out[3 * i + 2] = pz;
+  }
+}
+int keypoint_positions(const uint64_t* keys, int64_t n, int level, int cb, const float* offsets, int mode,
+                       const float* step, int ignore_offsets, float* out, hipStream_t stream) {
+  if (n == 0) return EGONN_OK;
+  const float s0 = step[0], s1 = mode ? step[1] : step[0], s2 = mode ? step[2] : step[0];
+  hipLaunchKernelGGL(keypoint_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, keys, n, level, cb, offsets,
+                     mode, s0, s1, s2, ignore_offsets, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ top-k (smallest sigma, ascending, ties by row)
+__global__ void topk_keys_kernel(const float* __restrict__ sigma, const int32_t* __restrict__ boff, int B, int64_t n,
+                                 uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t u = __float_as_uint(sigma[i]);
+  const uint32_t s = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotone float -> uint
+  const int b = sample_of_row(boff, B, (int32_t)i);
+  keys[i] = ((uint64_t)(uint32_t)b << 32) | s;
+  vals[i] = (uint32_t)i;
+}
+__global__ void topk_pick_kernel(const uint32_t* __restrict__ sorted_rows, const int32_t* __restrict__ boff, int B,
+                                 int k, int32_t* __restrict__ sel_rows, int32_t* __restrict__ sel_count) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * k) return;
+  const int b = t / k, i = t - b * k;
+  const int32_t s = boff[b], cntr = min(boff[b + 1] - s, k);
+  sel_rows[t] = (i < cntr) ? (int32_t)sorted_rows[s + i] : -1;
+  if (i == 0) sel_count[b] = cntr;
+}
+int topk_select(Ctx* ctx, const float* sigma, const int32_t* boff_dev, const int32_t* /*boff_host*/, int B, int64_t n,
+                int k, int32_t* sel_rows, int32_t* sel_count, hipStream_t stream) {
+  EGONN_REQUIRE(k >= 1, EGONN_ERR_INVALID, "topk: k=%d", k);
+  Arena& A = ctx->work_arena;
+  uint64_t* k0 = A.alloc<uint64_t>(n + 1);
+  uint64_t* k1 = A.alloc<uint64_t>(n + 1);
+  uint32_t* v0 = A.alloc<uint32_t>(n + 1);
+  uint32_t* v1 = A.alloc<uint32_t>(n + 1);
+  EGONN_REQUIRE(k0 && k1 && v0 && v1, EGONN_ERR_STATE, "work arena too small (topk)");
+  if (n > 0) {
+    hipLaunchKernelGGL(topk_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, sigma, boff_dev, B, n, k0,
+                       v0);
+    int bb = 1;
+    while ((1 << bb) < B) ++bb;
+    EGONN_TRY(radix_sort_pairs(ctx, k0, v0, k1, v1, n, 32 + bb, stream));
+  }
+  hipLaunchKernelGGL(topk_pick_kernel, dim3((unsigned)cdiv((int64_t)B * k, 256)), dim3(256), 0, stream, v1, boff_dev, B,
+                     k, sel_rows, sel_count);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+__global__ void gather_topk_kernel(const int32_t* __restrict__ sel_rows, int total, const float* __restrict__ kp,
+                                   const float* __restrict__ desc, int dc, float* __restrict__ out_kp,
+                                   float* __restrict__ out_desc) {
+  const int slot = blockIdx.x;
+  if (slot >= total) return;
+  const int32_t r = sel_rows[slot];
+  for (int i = threadIdx.x; i < dc; i += blockDim.x)
+    out_desc[(int64_t)slot * dc + i] = (r >= 0) ? desc[(int64_t)r * dc + i] : 0.f;
+  if (threadIdx.x < 3) out_kp[(int64_t)slot * 3 + threadIdx.x] = (r >= 0) ? kp[(int64_t)r * 3 + threadIdx.x] : 0.f;
+}
+int gather_topk(const int32_t* sel_rows, const int32_t* /*sel_count*/, int B, int k, const float* kp,
+                const float* desc, int dc, float* out_kp, float* out_desc, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_topk_kernel, dim3(B * k), dim3(64), 0, stream, sel_rows, B * k, kp, desc, dc, out_kp,
+                     out_desc);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+}  // namespace egonn

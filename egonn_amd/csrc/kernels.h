@@ -1,0 +1,47 @@
+// Internal kernel-launcher declarations shared between the .hip translation units.
+#pragma once
+#include "common.h"
+
+namespace egonn {
+
+const char* last_error();
+
+// conv.hip -------------------------------------------------------------------------------------
+// out[o] = act( (sum_k in[nbr[o][k]] @ W[k]) * scale + shift ), nbr: [n_out][K] rows or -1, W: [K][cin][cout]
+int sconv_forward(const float* in, const int32_t* nbr, const float* W, const float* scale, const float* shift,
+                  int relu, float* out, int32_t n_out, int K, int cin, int cout, hipStream_t stream);
+void sconv_set_naive(bool on);
+int conv0_k5_forward(const Plan& P, const float* feat, const float* W, int cout, const float* scale,
+                     const float* shift, int relu, float* out, hipStream_t stream);
+
+// dense.hip ------------------------------------------------------------------------------------
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SOFTPLUS = 3, ACT_SIGMOID = 4 };
+// out[r][:] = act( (in[r] @ Wmat + bias) * scale + shift ) (+ residual[r])
+//   w_out_in = 0: Wmat = W[cin][cout] (ME 1x1 kernel layout) ; 1: Wmat = W[cout][cin]^T (nn.Linear layout)
+int dense_forward(const float* in, int64_t n, int cin, const float* W, int w_out_in, int cout, const float* bias,
+                  const float* scale, const float* shift, int act, const float* residual, float* out,
+                  hipStream_t stream);
+int bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps, int c, float* scale,
+            float* shift, hipStream_t stream);
+int gather_rows(const float* in, const int32_t* perm, int64_t n, int c, float* out, hipStream_t stream);
+// per-sample column sums, deterministic two-stage: partial[b][chunk][c]
+static constexpr int SEG_CHUNKS = 32;
+int segment_partial_sums(const float* in, const int32_t* boff, int B, int c, int pow_mode, const float* p,
+                         float* partial, hipStream_t stream);
+// out[r] = relu(x[r] * sigmoid(conv1d_k(mean_b))[c] + res[r])  (ECA gate + residual + ReLU)
+int eca_apply(const float* x, const float* res, const float* partial, const int32_t* boff, int B, int64_t n, int c,
+              const float* wconv, int ksize, float* out, hipStream_t stream);
+// GeM: out[b][c] = (mean_b clamp(x,eps)^p)^(1/p) from the pow-mode partial sums
+int gem_finish(const float* partial, const int32_t* boff, int B, int c, const float* p, float* out,
+               hipStream_t stream);
+int l2_normalize_rows(float* x, int64_t n, int c, hipStream_t stream);
+// keypoint positions (reference datasets/quantization.py:60-72, 93-103)
+int keypoint_positions(const uint64_t* keys, int64_t n, int level, int cb, const float* offsets, int mode,
+                       const float* step, int ignore_offsets, float* out, hipStream_t stream);
+// top-k smallest sigma per sample, ascending, ties by row (= Z-order) — eval/evaluate.py:352-361
+int topk_select(Ctx* ctx, const float* sigma, const int32_t* boff_dev, const int32_t* boff_host, int B, int64_t n,
+                int k, int32_t* sel_rows /*[B][k]*/, int32_t* sel_count /*[B]*/, hipStream_t stream);
+int gather_topk(const int32_t* sel_rows, const int32_t* sel_count, int B, int k, const float* kp, const float* desc,
+                int dc, float* out_kp, float* out_desc, hipStream_t stream);
+
+}  // namespace egonn

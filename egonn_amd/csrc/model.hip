@@ -1,0 +1,547 @@
+// C ABI (include/egonn_hip.h) + the EgoNN graph executor.
+//
+// The graph restates model_factory('egonn') (reference models/model_factory.py:31-76) and
+// MinkGL.forward in eval mode (models/minkgl.py:267-315): MinkTrunk (:136-153), ECABasicBlock
+// (layers/eca_block.py:56-73), MinkHead (:46-60), DescriptorDecoder / KeypointRegressor / SigmaRegressor
+// (:175-225), GeM (layers/pooling.py:82-86).  Weights are addressed by the reference's state_dict keys.
+#include <map>
+#include <string>
+
+#include "../../include/egonn_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+using namespace egonn;
+
+#define API extern "C" __attribute__((visibility("default")))
+
+struct egonn_ctx : public Ctx {
+  // scratch kept between egonn_forward and its readers
+  float* level_feat[EGONN_NUM_LEVELS] = {};
+  int level_ch[EGONN_NUM_LEVELS] = {};
+  int64_t* scan_off_dev = nullptr;   // device copy of the scan offsets (voxelize plans)
+  bool from_points = false;
+};
+
+namespace {
+
+struct TensorRef {
+  const float* p = nullptr;
+  std::vector<int64_t> shape;
+};
+
+struct BnRef {
+  const float *w = nullptr, *b = nullptr, *rm = nullptr, *rv = nullptr;
+  float *scale = nullptr, *shift = nullptr;
+  int c = 0;
+};
+
+struct BlockRef {
+  const float *conv1 = nullptr, *conv2 = nullptr, *down = nullptr, *eca = nullptr;
+  BnRef n1, n2, dn;
+  int cin = 0, cout = 0, eca_k = 0;
+};
+
+struct MlpRef {
+  const float *w0 = nullptr, *b0 = nullptr, *w1 = nullptr, *b1 = nullptr;
+  int cin = 0, mid = 0, cout = 0;
+};
+
+const int PLANES[7] = {32, 64, 64, 128, 128, 128, 128};   // models/model_factory.py:40
+const int GLOBAL_CH = 128, GLOBAL_DIM = 256, LOCAL_CH = 64, LOCAL_DIM = 128;
+
+}  // namespace
+
+struct egonn_model {
+  std::map<std::string, TensorRef> t;
+  bool ready = false;
+  float* folded = nullptr;      // scale/shift storage
+  size_t folded_cap = 0;
+  // resolved views
+  const float* conv0 = nullptr;
+  BnRef bn[8];
+  const float* convs[8] = {};
+  BlockRef blk[8];
+  const float *g1x1[8] = {}, *gt[8] = {}, *l1x1[8] = {}, *lt[8] = {};
+  const float* gem_p = nullptr;
+  MlpRef gdec, ldec, kp, sg;
+};
+
+// ------------------------------------------------------------------------------------------ lifecycle
+API const char* egonn_last_error(void) { return last_error(); }
+
+API int egonn_debug_set_naive_conv(int on) {
+  sconv_set_naive(on != 0);
+  return EGONN_OK;
+}
+
+API int egonn_ctx_create(egonn_ctx** out, int device, int coord_bits) {
+  EGONN_REQUIRE(out != nullptr, EGONN_ERR_INVALID, "ctx_create: null out pointer");
+  EGONN_REQUIRE(coord_bits >= 10 && coord_bits <= 16, EGONN_ERR_INVALID, "coord_bits=%d outside [10,16]", coord_bits);
+  int ndev = 0;
+  HIP_CHECK(hipGetDeviceCount(&ndev));
+  EGONN_REQUIRE(device >= 0 && device < ndev, EGONN_ERR_INVALID, "device %d not present (%d HIP devices)", device, ndev);
+  HIP_CHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  EGONN_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, EGONN_ERR_INVALID,
+                "libegonn_hip is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+  egonn_ctx* c = new egonn_ctx();
+  c->device = device;
+  c->coord_bits = coord_bits;
+  const size_t hc = sizeof(int32_t) * (32 + (size_t)EGONN_NUM_LEVELS * (EGONN_MAX_BATCH + 1));
+  if (hipHostMalloc(reinterpret_cast<void**>(&c->host_counts), hc) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->dev_counts), sizeof(int32_t) * 32) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->dev_flags), sizeof(int32_t) * 4) != hipSuccess) {
+    set_error("ctx_create: allocation failed");
+    delete c;
+    return EGONN_ERR_HIP;
+  }
+  *out = c;
+  return EGONN_OK;
+}
+
+API void egonn_ctx_destroy(egonn_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  c->plan_arena.release();
+  c->work_arena.release();
+  c->sort_arena.release();
+  if (c->host_counts) (void)hipHostFree(c->host_counts);
+  if (c->dev_counts) (void)hipFree(c->dev_counts);
+  if (c->dev_flags) (void)hipFree(c->dev_flags);
+  delete c;
+}
+
+// ------------------------------------------------------------------------------------------ plan
+API int egonn_voxelize(egonn_ctx* c, const float* points, const int64_t* scan_offsets, int B, int mode,
+                       const float* step, void* stream) {
+  EGONN_REQUIRE(c && points && scan_offsets && step, EGONN_ERR_INVALID, "voxelize: null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
+  EGONN_TRY(plan_from_points(c, points, scan_offsets, B, mode, step, (hipStream_t)stream));
+  // keep a device copy of the offsets for egonn_input_index
+  c->scan_off_dev = c->plan_arena.alloc<int64_t>(B + 1);
+  EGONN_REQUIRE(c->scan_off_dev, EGONN_ERR_STATE, "plan arena too small");
+  HIP_CHECK(hipMemcpyAsync(c->scan_off_dev, scan_offsets, sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice,
+                           (hipStream_t)stream));
+  c->from_points = true;
+  return EGONN_OK;
+}
+
+API int egonn_coords_set(egonn_ctx* c, const int32_t* coords, int64_t n, int B, void* stream) {
+  EGONN_REQUIRE(c && coords, EGONN_ERR_INVALID, "coords_set: null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
+  EGONN_TRY(plan_from_coords(c, coords, n, B, (hipStream_t)stream));
+  c->from_points = false;
+  return EGONN_OK;
+}
+
+#define REQUIRE_PLAN(c)                                                                               \
+  EGONN_REQUIRE((c) && (c)->plan.valid, EGONN_ERR_STATE, "no coordinate plan (call egonn_voxelize / " \
+                                                         "egonn_coords_set first)")
+
+API int egonn_level_count(egonn_ctx* c, int level, int64_t* n) {
+  REQUIRE_PLAN(c);
+  EGONN_REQUIRE(level >= 0 && level < EGONN_MAX_LEVELS && n, EGONN_ERR_INVALID, "level %d out of range", level);
+  *n = c->plan.lv[level].n;
+  return EGONN_OK;
+}
+
+API int egonn_level_batch_offsets(egonn_ctx* c, int level, int64_t* off) {
+  REQUIRE_PLAN(c);
+  EGONN_REQUIRE(level >= 0 && level < EGONN_NUM_LEVELS && off, EGONN_ERR_INVALID, "level %d out of range", level);
+  for (int b = 0; b <= c->plan.batch; ++b) off[b] = c->plan.boff_host[level][b];
+  return EGONN_OK;
+}
+
+API int egonn_level_coords(egonn_ctx* c, int level, int32_t* out, void* stream) {
+  REQUIRE_PLAN(c);
+  HIP_CHECK(hipSetDevice(c->device));
+  return plan_level_coords(c, level, out, (hipStream_t)stream);
+}
+
+__global__ void input_index_kernel(const int32_t* __restrict__ perm0, const uint64_t* __restrict__ keys, int64_t n,
+                                   int bshift, const int64_t* __restrict__ scan_off, int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t v = perm0[i];
+  if (scan_off) v -= scan_off[(int)(keys[i] >> bshift)];
+  out[i] = v;
+}
+
+API int egonn_input_index(egonn_ctx* c, int64_t* out, void* stream) {
+  REQUIRE_PLAN(c);
+  HIP_CHECK(hipSetDevice(c->device));
+  const Level& L = c->plan.lv[0];
+  if (L.n == 0) return EGONN_OK;
+  hipLaunchKernelGGL(input_index_kernel, dim3((unsigned)cdiv(L.n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     c->plan.perm0, L.keys, L.n, 3 * c->plan.coord_bits, c->from_points ? c->scan_off_dev : nullptr,
+                     out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ operators
+API int egonn_conv(egonn_ctx* c, int level_in, int level_out, int ks, const float* in, int cin, const float* kernel,
+                   int cout, const float* scale, const float* shift, int relu, float* out, void* stream) {
+  REQUIRE_PLAN(c);
+  HIP_CHECK(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  EGONN_REQUIRE(level_in >= 0 && level_in < EGONN_NUM_LEVELS && level_out >= level_in && level_out < EGONN_NUM_LEVELS,
+                EGONN_ERR_INVALID, "conv: levels (%d,%d) out of range", level_in, level_out);
+  const Plan& P = c->plan;
+  if (ks == 1) {
+    EGONN_REQUIRE(level_in == level_out, EGONN_ERR_INVALID, "1x1 conv cannot change the level");
+    return dense_forward(in, P.lv[level_in].n, cin, kernel, 0, cout, nullptr, scale, shift, relu ? ACT_RELU : ACT_NONE,
+                         nullptr, out, st);
+  }
+  if (ks == 5) {
+    EGONN_REQUIRE(level_in == 0 && level_out == 0 && cin == 1, EGONN_ERR_INVALID,
+                  "k=5 convolution is implemented for the stride-1 input layer with Cin=1 only");
+    return conv0_k5_forward(P, in, kernel, cout, scale, shift, relu, out, st);
+  }
+  if (ks == 3) {
+    EGONN_REQUIRE(level_in == level_out && level_in >= 1, EGONN_ERR_INVALID,
+                  "k=3 convolution is implemented for levels 1..7 (same in/out level)");
+    return sconv_forward(in, P.lv[level_in].nbr27, kernel, scale, shift, relu, out, (int32_t)P.lv[level_in].n, 27, cin,
+                         cout, st);
+  }
+  if (ks == 2) {
+    EGONN_REQUIRE(level_out == level_in + 1, EGONN_ERR_INVALID, "k=2,s=2 convolution maps level l to l+1");
+    return sconv_forward(in, P.lv[level_out].nbr8, kernel, scale, shift, relu, out, (int32_t)P.lv[level_out].n, 8, cin,
+                         cout, st);
+  }
+  set_error("conv: kernel_size %d not supported (1, 2, 3, 5)", ks);
+  return EGONN_ERR_INVALID;
+}
+
+API int egonn_conv_transpose(egonn_ctx* c, int level_in, const float* in, int cin, const float* kernel, int cout,
+                             float* out, void* stream) {
+  REQUIRE_PLAN(c);
+  HIP_CHECK(hipSetDevice(c->device));
+  EGONN_REQUIRE(level_in >= 2 && level_in < EGONN_NUM_LEVELS, EGONN_ERR_INVALID,
+                "transposed conv: input level %d out of range [2,7]", level_in);
+  const Level& L = c->plan.lv[level_in - 1];
+  return sconv_forward(in, L.nbrT, kernel, nullptr, nullptr, 0, out, (int32_t)L.n, 8, cin, cout, (hipStream_t)stream);
+}
+
+__global__ void avg_finish_kernel(const float* __restrict__ partial, const int32_t* __restrict__ boff, int c,
+                                  float* __restrict__ out) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t >= c) return;
+  const int32_t n = boff[b + 1] - boff[b];
+  float s = 0.f;
+  for (int ch = 0; ch < SEG_CHUNKS; ++ch) s += partial[((int64_t)b * SEG_CHUNKS + ch) * c + t];
+  out[(int64_t)b * c + t] = n > 0 ? s / (float)n : 0.f;
+}
+
+API int egonn_global_avg_pool(egonn_ctx* c, int level, const float* in, int ch, float* out, void* stream) {
+  REQUIRE_PLAN(c);
+  HIP_CHECK(hipSetDevice(c->device));
+  EGONN_REQUIRE(level >= 0 && level < EGONN_NUM_LEVELS, EGONN_ERR_INVALID, "level %d out of range", level);
+  const int B = c->plan.batch;
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
+  EGONN_TRY(c->work_arena.ensure((size_t)B * SEG_CHUNKS * ch * 4 + 4096));
+  c->work_arena.reset();
+  float* partial = c->work_arena.alloc<float>((size_t)B * SEG_CHUNKS * ch);
+  EGONN_TRY(segment_partial_sums(in, c->plan.lv[level].boff, B, ch, 0, nullptr, partial, (hipStream_t)stream));
+  hipLaunchKernelGGL(avg_finish_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, c->plan.lv[level].boff, ch,
+                     out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ model
+API int egonn_model_create(egonn_model** m) {
+  EGONN_REQUIRE(m, EGONN_ERR_INVALID, "model_create: null out pointer");
+  *m = new egonn_model();
+  return EGONN_OK;
+}
+
+API void egonn_model_destroy(egonn_model* m) {
+  if (!m) return;
+  if (m->folded) (void)hipFree(m->folded);
+  delete m;
+}
+
+API int egonn_model_set_tensor(egonn_model* m, const char* key, const float* data, int ndim, const int64_t* shape) {
+  EGONN_REQUIRE(m && key && data && ndim >= 0 && ndim <= 4, EGONN_ERR_INVALID, "model_set_tensor: bad argument");
+  TensorRef r;
+  r.p = data;
+  r.shape.assign(shape, shape + ndim);
+  m->t[key] = r;
+  m->ready = false;
+  return EGONN_OK;
+}
+
+namespace {
+
+int get_tensor(egonn_model* m, const std::string& key, std::initializer_list<int64_t> want, const float** out) {
+  auto it = m->t.find(key);
+  EGONN_REQUIRE(it != m->t.end(), EGONN_ERR_STATE, "model: missing state_dict tensor '%s'", key.c_str());
+  const std::vector<int64_t>& s = it->second.shape;
+  bool ok = s.size() == want.size();
+  size_t i = 0;
+  for (int64_t w : want) {
+    if (ok && s[i] != w) ok = false;
+    ++i;
+  }
+  if (!ok) {
+    std::string got = "(", exp = "(";
+    for (int64_t v : s) got += std::to_string(v) + ",";
+    for (int64_t v : want) exp += std::to_string(v) + ",";
+    set_error("model: tensor '%s' has shape %s), expected %s)", key.c_str(), got.c_str(), exp.c_str());
+    return EGONN_ERR_INVALID;
+  }
+  *out = it->second.p;
+  return EGONN_OK;
+}
+
+int get_bn(egonn_model* m, const std::string& prefix, int c, BnRef* bn, float** cursor) {
+  bn->c = c;
+  EGONN_TRY(get_tensor(m, prefix + ".bn.weight", {c}, &bn->w));
+  EGONN_TRY(get_tensor(m, prefix + ".bn.bias", {c}, &bn->b));
+  EGONN_TRY(get_tensor(m, prefix + ".bn.running_mean", {c}, &bn->rm));
+  EGONN_TRY(get_tensor(m, prefix + ".bn.running_var", {c}, &bn->rv));
+  bn->scale = *cursor;
+  bn->shift = *cursor + c;
+  *cursor += 2 * c;
+  return EGONN_OK;
+}
+
+int get_mlp(egonn_model* m, const std::string& prefix, int cin, int mid, int cout, MlpRef* r) {
+  r->cin = cin; r->mid = mid; r->cout = cout;
+  EGONN_TRY(get_tensor(m, prefix + ".net.0.linear.weight", {mid, cin}, &r->w0));
+  EGONN_TRY(get_tensor(m, prefix + ".net.0.linear.bias", {mid}, &r->b0));
+  EGONN_TRY(get_tensor(m, prefix + ".net.2.linear.weight", {cout, mid}, &r->w1));
+  EGONN_TRY(get_tensor(m, prefix + ".net.2.linear.bias", {cout}, &r->b1));
+  return EGONN_OK;
+}
+
+int fold(const BnRef& bn, hipStream_t st) { return bn_fold(bn.w, bn.b, bn.rm, bn.rv, 1e-5f, bn.c, bn.scale, bn.shift, st); }
+
+}  // namespace
+
+API int egonn_model_finalize(egonn_model* m, void* stream) {
+  EGONN_REQUIRE(m, EGONN_ERR_INVALID, "model_finalize: null model");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t need = 2 * 128 * 32;   // generous: 24 BN layers x <=128 ch x (scale, shift)
+  if (m->folded_cap < need) {
+    if (m->folded) HIP_CHECK(hipFree(m->folded));
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->folded), need * sizeof(float)));
+    m->folded_cap = need;
+  }
+  float* cur = m->folded;
+  EGONN_TRY(get_tensor(m, "trunk.convs.0.kernel", {125, 1, 32}, &m->conv0));
+  EGONN_TRY(get_bn(m, "trunk.bn.0", 32, &m->bn[0], &cur));
+  int inpl = PLANES[0];
+  for (int i = 1; i <= 7; ++i) {
+    const std::string si = std::to_string(i);
+    const int cout = PLANES[i - 1];
+    EGONN_TRY(get_tensor(m, "trunk.convs." + si + ".kernel", {8, inpl, inpl}, &m->convs[i]));
+    EGONN_TRY(get_bn(m, "trunk.bn." + si, inpl, &m->bn[i], &cur));
+    BlockRef& b = m->blk[i];
+    b.cin = inpl;
+    b.cout = cout;
+    const std::string pre = "trunk.blocks." + si + ".0";
+    EGONN_TRY(get_tensor(m, pre + ".conv1.kernel", {27, inpl, cout}, &b.conv1));
+    EGONN_TRY(get_bn(m, pre + ".norm1", cout, &b.n1, &cur));
+    EGONN_TRY(get_tensor(m, pre + ".conv2.kernel", {27, cout, cout}, &b.conv2));
+    EGONN_TRY(get_bn(m, pre + ".norm2", cout, &b.n2, &cur));
+    if (inpl != cout) {
+      EGONN_TRY(get_tensor(m, pre + ".downsample.0.kernel", {inpl, cout}, &b.down));
+      EGONN_TRY(get_bn(m, pre + ".downsample.1", cout, &b.dn, &cur));
+    } else {
+      b.down = nullptr;
+    }
+    // ECALayer kernel size (layers/eca_block.py:14-15): t = int(|log2(C)+1| / 2), odd
+    int tt = 0;
+    {
+      int lg = 0;
+      while ((1 << lg) < cout) ++lg;
+      tt = (lg + 1) / 2;
+    }
+    b.eca_k = (tt % 2) ? tt : tt + 1;
+    EGONN_TRY(get_tensor(m, pre + ".eca.conv.weight", {1, 1, b.eca_k}, &b.eca));
+    inpl = cout;
+  }
+  for (int l : {5, 6, 7})
+    EGONN_TRY(get_tensor(m, "global_head.conv1x1." + std::to_string(l) + ".kernel", {PLANES[l - 1], GLOBAL_CH}, &m->g1x1[l]));
+  for (int l : {6, 7})
+    EGONN_TRY(get_tensor(m, "global_head.tconv." + std::to_string(l) + ".kernel", {8, GLOBAL_CH, GLOBAL_CH}, &m->gt[l]));
+  for (int l : {3, 4})
+    EGONN_TRY(get_tensor(m, "local_head.conv1x1." + std::to_string(l) + ".kernel", {PLANES[l - 1], LOCAL_CH}, &m->l1x1[l]));
+  EGONN_TRY(get_tensor(m, "local_head.tconv.4.kernel", {8, LOCAL_CH, LOCAL_CH}, &m->lt[4]));
+  EGONN_TRY(get_tensor(m, "global_pooling.pooling.p", {1}, &m->gem_p));
+  EGONN_TRY(get_mlp(m, "global_descriptor_decoder", GLOBAL_CH, GLOBAL_DIM + (GLOBAL_CH - GLOBAL_DIM) / 2, GLOBAL_DIM, &m->gdec));
+  EGONN_TRY(get_mlp(m, "local_descriptor_decoder", LOCAL_CH, LOCAL_DIM + (LOCAL_CH - LOCAL_DIM) / 2, LOCAL_DIM, &m->ldec));
+  EGONN_TRY(get_mlp(m, "local_keypoint_regressor", LOCAL_CH, LOCAL_CH / 2, 3, &m->kp));
+  EGONN_TRY(get_mlp(m, "local_sigma_regressor", LOCAL_CH, LOCAL_CH / 2, 1, &m->sg));
+
+  EGONN_TRY(fold(m->bn[0], st));
+  for (int i = 1; i <= 7; ++i) {
+    EGONN_TRY(fold(m->bn[i], st));
+    EGONN_TRY(fold(m->blk[i].n1, st));
+    EGONN_TRY(fold(m->blk[i].n2, st));
+    if (m->blk[i].down) EGONN_TRY(fold(m->blk[i].dn, st));
+  }
+  m->ready = true;
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+namespace {
+
+int run_mlp(const MlpRef& r, const float* x, int64_t n, int act_out, float* hidden, float* out, hipStream_t st) {
+  EGONN_TRY(dense_forward(x, n, r.cin, r.w0, 1, r.mid, r.b0, nullptr, nullptr, ACT_RELU, nullptr, hidden, st));
+  return dense_forward(hidden, n, r.mid, r.w1, 1, r.cout, r.b1, nullptr, nullptr, act_out, nullptr, out, st);
+}
+
+}  // namespace
+
+API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int quant_mode, const float* step, int flags,
+                      float* out_global, float* out_desc, float* out_kp, float* out_sigma, void* stream) {
+  REQUIRE_PLAN(c);
+  EGONN_REQUIRE(m && m->ready, EGONN_ERR_STATE, "model not finalized (call egonn_model_finalize)");
+  EGONN_REQUIRE(features && step, EGONN_ERR_INVALID, "forward: null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  const Plan& P = c->plan;
+  const int B = P.batch;
+  const bool do_global = !(flags & EGONN_FLAG_DISABLE_GLOBAL);
+  const bool do_local = !(flags & EGONN_FLAG_DISABLE_LOCAL);
+  EGONN_REQUIRE(!do_global || out_global, EGONN_ERR_INVALID, "forward: out_global is null");
+  EGONN_REQUIRE(!do_local || (out_desc && out_kp && out_sigma), EGONN_ERR_INVALID, "forward: local outputs are null");
+
+  // ---- workspace: every intermediate gets its own buffer (HBM is plentiful; no aliasing hazards)
+  size_t need = (size_t)P.lv[0].n * (1 + 32) * 4;
+  for (int i = 1; i <= 7; ++i) need += (size_t)P.lv[i].n * 128 * 4 * 6;
+  need += (size_t)P.lv[5].n * (192 + 256 + 128 * 2) * 4 + (size_t)P.lv[3].n * (96 + 32 + 32 + 3 + 64 * 2) * 4;
+  need += (size_t)B * SEG_CHUNKS * 256 * 4 * 10 + (size_t)P.lv[3].n * 32 + (4u << 20);
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
+  EGONN_TRY(c->work_arena.ensure(need));
+  Arena& A = c->work_arena;
+  A.reset();
+#define WALLOC(var, count)                                                         \
+  float* var = A.alloc<float>((size_t)(count));                                    \
+  EGONN_REQUIRE(var != nullptr, EGONN_ERR_STATE, "work arena too small (" #var ")")
+
+  // ---- trunk (models/minkgl.py:136-153)
+  const int64_t n0 = P.lv[0].n;
+  const float* f0 = features;          // voxelize plans: features are already in level-0 row order
+  if (!c->from_points) {
+    WALLOC(fg, n0);
+    EGONN_TRY(gather_rows(features, P.perm0, n0, 1, fg, st));
+    f0 = fg;
+  }
+  WALLOC(x0, n0 * 32);
+  EGONN_TRY(conv0_k5_forward(P, f0, m->conv0, 32, m->bn[0].scale, m->bn[0].shift, 1, x0, st));
+  const float* x[8] = {x0};
+  c->level_feat[0] = x0;
+  c->level_ch[0] = 32;
+  for (int i = 1; i <= 7; ++i) {
+    const BlockRef& b = m->blk[i];
+    const Level& L = P.lv[i];
+    const int64_t n = L.n;
+    WALLOC(y, n * b.cin);
+    EGONN_TRY(sconv_forward(x[i - 1], L.nbr8, m->convs[i], m->bn[i].scale, m->bn[i].shift, 1, y, (int32_t)n, 8, b.cin,
+                            b.cin, st));
+    // ECABasicBlock (layers/eca_block.py:56-73)
+    WALLOC(t1, n * b.cout);
+    EGONN_TRY(sconv_forward(y, L.nbr27, b.conv1, b.n1.scale, b.n1.shift, 1, t1, (int32_t)n, 27, b.cin, b.cout, st));
+    WALLOC(t2, n * b.cout);
+    EGONN_TRY(sconv_forward(t1, L.nbr27, b.conv2, b.n2.scale, b.n2.shift, 0, t2, (int32_t)n, 27, b.cout, b.cout, st));
+    WALLOC(partial, (size_t)B * SEG_CHUNKS * b.cout + (size_t)B * b.cout);
+    EGONN_TRY(segment_partial_sums(t2, L.boff, B, b.cout, 0, nullptr, partial, st));
+    const float* res = y;
+    if (b.down) {
+      WALLOC(rd, n * b.cout);
+      EGONN_TRY(dense_forward(y, n, b.cin, b.down, 0, b.cout, nullptr, b.dn.scale, b.dn.shift, ACT_NONE, nullptr, rd, st));
+      res = rd;
+    }
+    WALLOC(xo, n * b.cout);
+    EGONN_TRY(eca_apply(t2, res, partial, L.boff, B, n, b.cout, b.eca, b.eca_k, xo, st));
+    x[i] = xo;
+    c->level_feat[i] = xo;
+    c->level_ch[i] = b.cout;
+  }
+
+  // ---- global head + decoder + GeM (models/minkgl.py:46-60, 207-225; layers/pooling.py:82-86)
+  if (do_global) {
+    WALLOC(g7, P.lv[7].n * GLOBAL_CH);
+    EGONN_TRY(dense_forward(x[7], P.lv[7].n, 128, m->g1x1[7], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, g7, st));
+    WALLOC(u6, P.lv[6].n * GLOBAL_CH);
+    EGONN_TRY(sconv_forward(g7, P.lv[6].nbrT, m->gt[7], nullptr, nullptr, 0, u6, (int32_t)P.lv[6].n, 8, GLOBAL_CH, GLOBAL_CH, st));
+    WALLOC(g6, P.lv[6].n * GLOBAL_CH);
+    EGONN_TRY(dense_forward(x[6], P.lv[6].n, 128, m->g1x1[6], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u6, g6, st));
+    WALLOC(u5, P.lv[5].n * GLOBAL_CH);
+    EGONN_TRY(sconv_forward(g6, P.lv[5].nbrT, m->gt[6], nullptr, nullptr, 0, u5, (int32_t)P.lv[5].n, 8, GLOBAL_CH, GLOBAL_CH, st));
+    WALLOC(g5, P.lv[5].n * GLOBAL_CH);
+    EGONN_TRY(dense_forward(x[5], P.lv[5].n, 128, m->g1x1[5], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u5, g5, st));
+    WALLOC(gh, P.lv[5].n * m->gdec.mid);
+    WALLOC(gd, P.lv[5].n * GLOBAL_DIM);
+    EGONN_TRY(run_mlp(m->gdec, g5, P.lv[5].n, ACT_NONE, gh, gd, st));
+    WALLOC(gp, (size_t)B * SEG_CHUNKS * GLOBAL_DIM);
+    EGONN_TRY(segment_partial_sums(gd, P.lv[5].boff, B, GLOBAL_DIM, 1, m->gem_p, gp, st));
+    EGONN_TRY(gem_finish(gp, P.lv[5].boff, B, GLOBAL_DIM, m->gem_p, out_global, st));
+  }
+
+  // ---- local head, descriptor / keypoint / sigma regressors (models/minkgl.py:287-308)
+  if (do_local) {
+    const int64_t n3 = P.lv[3].n, n4 = P.lv[4].n;
+    WALLOC(l4, n4 * LOCAL_CH);
+    EGONN_TRY(dense_forward(x[4], n4, 128, m->l1x1[4], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, l4, st));
+    WALLOC(u3, n3 * LOCAL_CH);
+    EGONN_TRY(sconv_forward(l4, P.lv[3].nbrT, m->lt[4], nullptr, nullptr, 0, u3, (int32_t)n3, 8, LOCAL_CH, LOCAL_CH, st));
+    WALLOC(l3, n3 * LOCAL_CH);
+    EGONN_TRY(dense_forward(x[3], n3, 64, m->l1x1[3], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u3, l3, st));
+    WALLOC(dh, n3 * m->ldec.mid);
+    EGONN_TRY(run_mlp(m->ldec, l3, n3, ACT_NONE, dh, out_desc, st));
+    EGONN_TRY(l2_normalize_rows(out_desc, n3, LOCAL_DIM, st));
+    WALLOC(kh, n3 * m->kp.mid);
+    WALLOC(ko, n3 * 3);
+    EGONN_TRY(run_mlp(m->kp, l3, n3, ACT_TANH, kh, ko, st));
+    EGONN_TRY(keypoint_positions(P.lv[3].keys, n3, 3, P.coord_bits, ko, quant_mode, step,
+                                 (flags & EGONN_FLAG_IGNORE_KP_REGRESSOR) ? 1 : 0, out_kp, st));
+    WALLOC(sh, n3 * m->sg.mid);
+    EGONN_TRY(run_mlp(m->sg, l3, n3, ACT_SOFTPLUS, sh, out_sigma, st));
+  }
+#undef WALLOC
+  return EGONN_OK;
+}
+
+API int egonn_forward_level_features(egonn_ctx* c, int level, float* out, int channels, void* stream) {
+  REQUIRE_PLAN(c);
+  EGONN_REQUIRE(level >= 0 && level < EGONN_NUM_LEVELS && c->level_feat[level], EGONN_ERR_STATE,
+                "no features for level %d (run egonn_forward first)", level);
+  EGONN_REQUIRE(channels == c->level_ch[level], EGONN_ERR_INVALID, "level %d has %d channels, caller expects %d", level,
+                c->level_ch[level], channels);
+  HIP_CHECK(hipMemcpyAsync(out, c->level_feat[level], sizeof(float) * c->plan.lv[level].n * channels,
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return EGONN_OK;
+}
+
+API int egonn_select_keypoints(egonn_ctx* c, const float* sigma, const float* keypoints, const float* descriptors,
+                               int n_k, float* sel_kp, float* sel_desc, int32_t* sel_rows, int32_t* sel_count,
+                               void* stream) {
+  REQUIRE_PLAN(c);
+  EGONN_REQUIRE(sigma && keypoints && descriptors && sel_kp && sel_desc && sel_rows && sel_count, EGONN_ERR_INVALID,
+                "select_keypoints: null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  const Plan& P = c->plan;
+  const int64_t n3 = P.lv[3].n;
+  // scratch for the sort lives behind whatever the last forward left in the work arena
+  const size_t need = c->work_arena.off + (size_t)(n3 + 64) * 24 + 4096;
+  EGONN_REQUIRE(need <= c->work_arena.cap || c->work_arena.off == 0, EGONN_ERR_STATE,
+                "work arena too small for keypoint selection");
+  if (c->work_arena.off == 0) EGONN_TRY(c->work_arena.ensure(need));
+  const size_t mark = c->work_arena.off;
+  int rc = topk_select(c, sigma, P.lv[3].boff, nullptr, P.batch, n3, n_k, sel_rows, sel_count, st);
+  if (rc == EGONN_OK) rc = gather_topk(sel_rows, sel_count, P.batch, n_k, keypoints, descriptors, LOCAL_DIM, sel_kp, sel_desc, st);
+  c->work_arena.off = mark;
+  return rc;
+}

@@ -1,0 +1,183 @@
+// Stable LSD radix sort of (u64 key, u32 value) pairs, 8 bits per pass, hand-written for wave64.
+//
+// Per pass two launches:
+//   hist    : per-tile digit histogram (LDS atomics) -> tilehist[tile][256]; integer global atomics
+//             additionally accumulate per-supertile (32 tiles) and grand totals, so that the scatter
+//             kernel can derive its global base offsets without a separate scan launch.
+//   scatter : every wave ranks its keys with a ballot-based match-any (8 ballots per 64 keys),
+//             wave-private LDS counters give the stable in-tile rank, then keys/values are written
+//             to  digit_base + tiles_before + rank.
+// Order inside a tile is (wave, round, lane) and waves own contiguous sub-ranges, so the sort is stable.
+//
+// HBM traffic per pass: 12 B read (hist: 8) + 12 B written per pair; the sort is launch/latency bound at
+// the sizes of this path (<= a few M keys), not bandwidth bound.
+#include "common.h"
+
+namespace egonn {
+
+static constexpr int SORT_BLOCK = 256;
+static constexpr int SORT_WAVES = SORT_BLOCK / 64;
+static constexpr int SORT_ROUNDS = 16;                       // keys per thread
+static constexpr int SORT_TILE = SORT_BLOCK * SORT_ROUNDS;   // 4096 keys per workgroup
+static constexpr int SORT_SUPER = 32;                        // tiles per supertile
+
+__global__ __launch_bounds__(SORT_BLOCK) void sort_hist_kernel(const uint64_t* __restrict__ keys, int64_t n,
+                                                               int shift, int32_t* __restrict__ tilehist,
+                                                               int32_t* __restrict__ superhist,
+                                                               int32_t* __restrict__ total) {
+  __shared__ int32_t hist[256];
+  const int tid = threadIdx.x;
+  hist[tid] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+#pragma unroll 4
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    int64_t i = base + (int64_t)r * SORT_BLOCK + tid;
+    if (i < n) atomicAdd(&hist[(keys[i] >> shift) & 0xFF], 1);
+  }
+  __syncthreads();
+  const int32_t c = hist[tid];
+  tilehist[(int64_t)blockIdx.x * 256 + tid] = c;
+  if (c) {
+    atomicAdd(&superhist[(blockIdx.x / SORT_SUPER) * 256 + tid], c);
+    atomicAdd(&total[tid], c);
+  }
+}
+
+__global__ __launch_bounds__(SORT_BLOCK) void sort_scatter_kernel(
+    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, int64_t n, int shift, const int32_t* __restrict__ tilehist,
+    const int32_t* __restrict__ superhist, const int32_t* __restrict__ total) {
+  __shared__ int32_t whist[SORT_WAVES][256];   // running per-wave digit counts
+  __shared__ int32_t dbase[256];               // global base of every digit for this tile
+  __shared__ int32_t wsum[SORT_WAVES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int tile = blockIdx.x;
+
+  // ---- global base for digit d = tid: (#keys with smaller digit) + (#keys with digit d in earlier tiles)
+  {
+    int32_t before = 0;
+    const int super = tile / SORT_SUPER;
+    for (int s = 0; s < super; ++s) before += superhist[s * 256 + tid];
+    for (int t = super * SORT_SUPER; t < tile; ++t) before += tilehist[(int64_t)t * 256 + tid];
+    // exclusive scan of total[] over the 256 digits (wave scan + 4 wave sums)
+    const int32_t tot = total[tid];
+    int32_t incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int32_t v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) whist[w][tid] = 0;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    dbase[tid] = woff + incl - tot + before;
+  }
+  __syncthreads();
+
+  // ---- stable ranking: wave `wave` owns keys [base + wave*64*ROUNDS, +64*ROUNDS)
+  const int64_t wbase = (int64_t)tile * SORT_TILE + (int64_t)wave * (64 * SORT_ROUNDS);
+  uint64_t k[SORT_ROUNDS];
+  uint32_t v[SORT_ROUNDS];
+  int32_t rank[SORT_ROUNDS];
+  volatile int32_t* my = whist[wave];
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int64_t i = wbase + r * 64 + lane;
+    const bool valid = i < n;
+    k[r] = valid ? keys_in[i] : ~0ull;
+    v[r] = valid ? vals_in[i] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int64_t i = wbase + r * 64 + lane;
+    const bool valid = i < n;
+    const uint32_t d = (uint32_t)(k[r] >> shift) & 0xFF;
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1;
+      const uint64_t bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    const int32_t prior = my[d];
+    __builtin_amdgcn_wave_barrier();
+    rank[r] = prior + __popcll(m & lt);
+    if (valid && (m & lt) == 0) my[d] = prior + __popcll(m);   // group leader publishes the new count
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // ---- per-digit offset of this wave = dbase + counts of earlier waves  (thread = digit)
+  {
+    int32_t acc = dbase[tid];
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) {
+      const int32_t c = whist[w][tid];
+      whist[w][tid] = acc;
+      acc += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int64_t i = wbase + r * 64 + lane;
+    if (i < n) {
+      const uint32_t d = (uint32_t)(k[r] >> shift) & 0xFF;
+      const int64_t dst = (int64_t)whist[wave][d] + rank[r];
+      keys_out[dst] = k[r];
+      vals_out[dst] = v[r];
+    }
+  }
+}
+
+size_t radix_sort_scratch_bytes(int64_t n) {
+  const int64_t tiles = cdiv(n > 0 ? n : 1, SORT_TILE);
+  const int64_t supers = cdiv(tiles, SORT_SUPER);
+  // tilehist (reused per pass) + 8 passes x (superhist + total)
+  return (size_t)(tiles * 256 + 8 * (supers + 1) * 256) * sizeof(int32_t) + 1024;
+}
+
+int radix_sort_pairs(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
+                     int64_t n, int nbits, hipStream_t stream) {
+  EGONN_REQUIRE(n >= 0 && n < (int64_t(1) << 31), EGONN_ERR_INVALID, "radix_sort: n=%lld out of range", (long long)n);
+  EGONN_REQUIRE(nbits >= 1 && nbits <= 64, EGONN_ERR_INVALID, "radix_sort: nbits=%d", nbits);
+  const int passes = (nbits + 7) / 8;
+  if (n == 0) return EGONN_OK;
+  const int64_t tiles = cdiv(n, SORT_TILE);
+  const int64_t supers = cdiv(tiles, SORT_SUPER);
+  EGONN_TRY(ctx->sort_arena.ensure(radix_sort_scratch_bytes(n)));
+  ctx->sort_arena.reset();
+  int32_t* tilehist = ctx->sort_arena.alloc<int32_t>(tiles * 256);
+  int32_t* slabs = ctx->sort_arena.alloc<int32_t>(8 * (supers + 1) * 256);
+  EGONN_REQUIRE(tilehist && slabs, EGONN_ERR_STATE, "radix_sort: scratch arena too small");
+  HIP_CHECK(hipMemsetAsync(slabs, 0, sizeof(int32_t) * passes * (supers + 1) * 256, stream));
+
+  // ping-pong so that the LAST pass writes (keys_out, vals_out)
+  uint64_t* kb[2] = {keys_in, keys_out};
+  uint32_t* vb[2] = {vals_in, vals_out};
+  int src = (passes % 2 == 1) ? 0 : 1;
+  if (src == 1) {   // even number of passes: start from the "out" buffers
+    HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream));
+  }
+  for (int p = 0; p < passes; ++p) {
+    int32_t* superhist = slabs + (int64_t)p * (supers + 1) * 256;
+    int32_t* total = superhist + supers * 256;
+    const int shift = 8 * p;
+    hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)tiles), dim3(SORT_BLOCK), 0, stream, kb[src], n, shift,
+                       tilehist, superhist, total);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)tiles), dim3(SORT_BLOCK), 0, stream, kb[src], vb[src],
+                       kb[src ^ 1], vb[src ^ 1], n, shift, tilehist, superhist, total);
+    src ^= 1;
+  }
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+}  // namespace egonn

@@ -1,0 +1,114 @@
+/* libegonn_hip — C ABI of the MI355X-native EgoNN descriptor-extraction path.
+ *
+ * Drop-in boundary: the reference (jac99/Egonn) has no native code; its
+ * hot path crosses into the third-party MinkowskiEngine 0.5.4 Python bindings.  Each entry point below
+ * cites the reference call site (file:line under /root/reference) whose MinkowskiEngine call it
+ * replaces.  All pointers are raw device pointers (unless marked HOST), all sizes are explicit, there
+ * are no torch types in any signature.  Every call enqueues its work on `stream` (a hipStream_t passed
+ * as void*); the only host synchronisations are the size queries marked [SYNC].
+ *
+ * Conventions
+ *   - return value: 0 = ok, non-zero = error; egonn_last_error() returns a thread-local message.
+ *   - coordinates: int32 [batch, x, y, z] rows, exactly ME's `batched_coordinates` layout.
+ *   - rows of every level are stored in Z-order of (batch, x, y, z): batch-contiguous, deterministic.
+ *     (ME's own row order is hash-iteration order and unspecified; consumers may only rely on the
+ *     coordinate <-> row association, which egonn_level_coords exposes.)
+ *   - levels: level l has tensor stride 2^l (coordinates are multiples of 2^l), l = 0..7.
+ *   - fp32 everywhere; sparse-conv kernels are (K, Cin, Cout) / (Cin, Cout), Linear weights (out, in):
+ *     the reference's own state_dict layouts.
+ */
+#ifndef EGONN_HIP_H
+#define EGONN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct egonn_ctx egonn_ctx;       /* one per (device, stream user); owns the coordinate plan + workspace */
+typedef struct egonn_model egonn_model;   /* EgoNN weights registered by state_dict key */
+
+enum { EGONN_QUANT_CARTESIAN = 0, EGONN_QUANT_POLAR = 1 };
+enum { EGONN_FLAG_DISABLE_GLOBAL = 1, EGONN_FLAG_DISABLE_LOCAL = 2, EGONN_FLAG_IGNORE_KP_REGRESSOR = 4 };
+
+/* ------------------------------------------------------------------ lifecycle / errors */
+/* coord_bits in [10,16]: voxel coordinates must lie in [-2^(coord_bits-1), 2^(coord_bits-1)). */
+int egonn_ctx_create(egonn_ctx** ctx, int device, int coord_bits);
+void egonn_ctx_destroy(egonn_ctx* ctx);
+const char* egonn_last_error(void);
+/* debug: 1 = route sparse convolutions through the naive (non-MFMA) HIP kernel (cross-check only). */
+int egonn_debug_set_naive_conv(int on);
+
+/* ------------------------------------------------------------------ coordinate plan
+ * replaces ME.utils.sparse_quantize      datasets/quantization.py:42,83   (Cartesian/Polar quantizer __call__)
+ *          ME.utils.batched_coordinates  eval/evaluate.py:333, datasets/dataset_utils.py:77
+ *          ME.SparseTensor(...)          models/minkgl.py:269             (coordinate-map build)
+ *          ME coordinate manager         strided maps + kernel maps of every conv in models/minkgl.py:100-134,39-43
+ */
+/* Voxelise B scans.  points: (n,3) f32 device, scan b = rows [scan_offsets[b], scan_offsets[b+1]) (HOST, B+1
+ * entries).  step: HOST, 1 value (Cartesian) or 3 (polar: degrees, metres, metres).  Builds the plan for the
+ * voxelised batch.  [SYNC] */
+int egonn_voxelize(egonn_ctx* ctx, const float* points, const int64_t* scan_offsets, int batch_size, int quant_mode,
+                   const float* step, void* stream);
+/* Build the plan from explicit coordinates (N,4) int32 [b,x,y,z] in any row order; duplicate rows collapse onto
+ * their first occurrence (ME SparseTensor default).  [SYNC] */
+int egonn_coords_set(egonn_ctx* ctx, const int32_t* coords, int64_t n, int batch_size, void* stream);
+
+/* Queries on the current plan (HOST results, no sync: filled by the size query of the call above). */
+int egonn_level_count(egonn_ctx* ctx, int level, int64_t* n_rows);
+int egonn_level_batch_offsets(egonn_ctx* ctx, int level, int64_t* offsets /* HOST, B+1 */);
+/* (N_l,4) int32 coordinates of level `level` in row order. */
+int egonn_level_coords(egonn_ctx* ctx, int level, int32_t* out, void* stream);
+/* For level-0 row i: index of the caller's point / coordinate row it came from (first occurrence).
+ * For egonn_voxelize the index is relative to the scan's own first point, as the reference quantizer returns. */
+int egonn_input_index(egonn_ctx* ctx, int64_t* out /* (N0,) device */, void* stream);
+
+/* ------------------------------------------------------------------ operators on the current plan
+ * (per-operator entry points; egonn_forward below chains them on device)                                  */
+/* MinkowskiConvolution: kernel_size 5 (level_out==level_in==0, Cin=1), 3 (same level), 2 (stride 2,
+ * level_out = level_in+1), 1 (dense).  models/minkgl.py:100,105,43,124; ME BasicBlock conv1/conv2.
+ * scale/shift (nullable): folded eval-mode MinkowskiBatchNorm; relu: fused MinkowskiReLU. */
+int egonn_conv(egonn_ctx* ctx, int level_in, int level_out, int kernel_size, const float* in, int cin,
+               const float* kernel, int cout, const float* scale, const float* shift, int relu, float* out,
+               void* stream);
+/* MinkowskiConvolutionTranspose(k=2,s=2) onto the cached finer map: models/minkgl.py:39,53. level_out = level_in-1 */
+int egonn_conv_transpose(egonn_ctx* ctx, int level_in, const float* in, int cin, const float* kernel, int cout,
+                         float* out, void* stream);
+/* MinkowskiGlobalAvgPooling: layers/eca_block.py:16, layers/pooling.py:80.  out (B,C) */
+int egonn_global_avg_pool(egonn_ctx* ctx, int level, const float* in, int channels, float* out, void* stream);
+
+/* ------------------------------------------------------------------ model
+ * replaces model_factory(...) / MinkGL.forward: models/model_factory.py:31-76, models/minkgl.py:267-315       */
+int egonn_model_create(egonn_model** model);
+void egonn_model_destroy(egonn_model* model);
+/* Register a tensor by its reference state_dict key.  The pointer is borrowed and must
+ * stay valid until it is re-registered or the model is destroyed. */
+int egonn_model_set_tensor(egonn_model* model, const char* key, const float* data, int ndim, const int64_t* shape);
+/* Validate keys/shapes, fold eval-mode BatchNorm into scale/shift.  Call again whenever weights change. */
+int egonn_model_finalize(egonn_model* model, void* stream);
+
+/* Forward on the current plan.  features: for an egonn_coords_set plan (n_input, 1) f32 in the CALLER's row
+ * order (batch['features'], eval/evaluate.py:334); for an egonn_voxelize plan (N0, 1) in level-0 row order
+ * (the voxels did not exist before the call, so there is no caller order).  Outputs (caller-allocated, sizes from egonn_level_count):
+ *   out_global (B,256) ; out_descriptors (N3,128) unit-L2 ; out_keypoints (N3,3) metres ; out_sigma (N3,1)
+ * rows in level-3 row order (per-sample splits = egonn_level_batch_offsets(3)).  Any output may be NULL when
+ * the corresponding head is disabled through `flags`.  quant_mode/step as in egonn_voxelize (needed for
+ * Quantizer.keypoint_position, datasets/quantization.py:60-72,93-103).  No host sync. */
+int egonn_forward(egonn_ctx* ctx, egonn_model* model, const float* features, int quant_mode, const float* step,
+                  int flags, float* out_global, float* out_descriptors, float* out_keypoints, float* out_sigma,
+                  void* stream);
+/* Feature map of a trunk level produced by the last egonn_forward (debug / parity tests): (N_l, C_l). */
+int egonn_forward_level_features(egonn_ctx* ctx, int level, float* out, int channels, void* stream);
+
+/* Keypoint selection — MinkLocGLEvaluator.get_keypoints_idxes, eval/evaluate.py:352-361: per sample the n_k
+ * keypoints with the lowest sigma in increasing order (ties: Z-order of the super-voxel).  Padded outputs:
+ *   sel_keypoints (B,n_k,3), sel_descriptors (B,n_k,128), sel_rows (B,n_k) level-3 row or -1, sel_count (B,). */
+int egonn_select_keypoints(egonn_ctx* ctx, const float* sigma, const float* keypoints, const float* descriptors,
+                           int n_k, float* sel_keypoints, float* sel_descriptors, int32_t* sel_rows,
+                           int32_t* sel_count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGONN_HIP_H */

@@ -1,0 +1,412 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+  * the golden vectors produced by the reference's own graph code (tests/golden/*.npz),
+  * the CPU oracle (oracle/me_ops.py, oracle/egonn_ref.py) on seeded inputs,
+  * size-independent properties at BASELINE.json's full size (50k-pt clouds, batch 16).
+
+Bars: integer voxel coordinates / indices / keypoint selection bit-exact; fp32 descriptors within 1e-4
+cosine (BASELINE.json north_star); other fp32 tensors within the rtol/atol written in each test.
+Row order differs between implementations, so everything joins on the (b,x,y,z) coordinate."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import __graft_entry__ as g
+    g.build()
+    import egonn_amd
+    return egonn_amd
+
+
+def _model(gpu, case=None, seed=None, coordinates="cartesian", step=0.1):
+    if case is not None:
+        coordinates = str(case["coordinates"])
+        st = case["quantization_step"]
+        step = float(st[0]) if coordinates == "cartesian" else [float(s) for s in st]
+        seed = int(case["weight_seed"])
+    mp = gpu.ModelParams(model="egonn", coordinates=coordinates, quantization_step=step)
+    m = gpu.model_factory(mp)
+    w = H.seeded_weights(seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    return m.to("cuda").eval(), w
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------ voxeliser (a1, a2)
+@pytest.mark.parametrize("name", H.CASES)
+def test_quantizer_matches_reference(gpu, name):
+    case = H.load_case(name)
+    m, _ = _model(gpu, case)
+    for b in range(int(case["n_scans"])):
+        pts = torch.from_numpy(case[f"points_{b}"])
+        coords, idx = m.quantizer(pts)                       # CPU in -> CPU out, like the reference
+        coords, idx = _np(coords), _np(idx)
+        assert coords.dtype == np.int32 and idx.dtype == np.int64
+        g_c, g_i = case[f"quant_coords_{b}"], case[f"quant_index_{b}"]
+        c4 = np.concatenate([np.zeros((len(coords), 1), np.int32), coords], axis=1)
+        g4 = np.concatenate([np.zeros((len(g_c), 1), np.int32), g_c], axis=1)
+        if str(case["coordinates"]) == "cartesian":          # integer work: bit-exact
+            perm = H.join_perm(c4, g4)
+            assert np.array_equal(coords[perm], g_c)
+            assert np.array_equal(idx[perm], g_i)            # first point of every voxel
+        else:                                                # transcendental: bin-edge points may move
+            a, g = set(map(tuple, coords.tolist())), set(map(tuple, g_c.tolist()))
+            assert len(a ^ g) <= max(2, len(g) // 1000)
+        # Z-order output is sorted by construction and duplicate-free
+        assert len(np.unique(H.rowkey(c4))) == len(c4)
+
+
+def test_quantizer_edge_cases(gpu):
+    from oracle import me_ops as ops
+    q = gpu.CartesianQuantizer(0.1)
+    # single point, duplicates, negative coordinates (true floor), exact bin edges
+    pts = np.array([[0.05, 0.0, 0.0], [-0.05, 0.0, 0.0], [0.06, 0.01, 0.0], [0.31, 0.0, -0.11],
+                    [-0.1, -0.2, -0.3], [0.3, 0.2, 0.1], [-0.1, -0.2, -0.3]], np.float32)
+    c, i = q(torch.from_numpy(pts))
+    oc, oi = ops.sparse_quantize(pts, 0.1)
+    perm = H.join_perm(np.c_[np.zeros(len(c), np.int32), _np(c)], np.c_[np.zeros(len(oc), np.int32), oc])
+    assert np.array_equal(_np(c)[perm], oc) and np.array_equal(_np(i)[perm], oi)
+    c1, i1 = q(torch.from_numpy(pts[:1]))
+    assert _np(c1).tolist() == [[0, 0, 0]] and _np(i1).tolist() == [0]
+    # out-of-range coordinates must fail loudly, not wrap
+    with pytest.raises(RuntimeError, match="range"):
+        q(torch.tensor([[1.0e6, 0.0, 0.0]]))
+    with pytest.raises(RuntimeError, match="range"):
+        q(torch.tensor([[float("nan"), 0.0, 0.0]]))
+
+
+def test_quantizer_random_cloud_vs_oracle(gpu):
+    from oracle import me_ops as ops
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-60, 60, size=(200000, 3)).astype(np.float32)
+    pts[:, 2] = rng.uniform(-3, 8, size=len(pts))
+    for qs in (0.1, 0.3, 1.0):
+        c, i = gpu.CartesianQuantizer(qs)(torch.from_numpy(pts).cuda())
+        oc, oi = ops.sparse_quantize(pts, qs)
+        perm = H.join_perm(np.c_[np.zeros(len(c), np.int32), _np(c)], np.c_[np.zeros(len(oc), np.int32), oc])
+        assert np.array_equal(_np(c)[perm], oc) and np.array_equal(_np(i)[perm], oi)
+
+
+# ------------------------------------------------------------------------------------ coordinate pyramid (a3)
+@pytest.mark.parametrize("name", H.CASES)
+def test_pyramid_matches_reference(gpu, name):
+    from oracle import me_ops as ops
+    case = H.load_case(name)
+    ctx = gpu._lib.Context()
+    c4 = case["coords"]
+    rng = np.random.default_rng(0)
+    shuffled = c4[rng.permutation(len(c4))]                   # "must not assume sorted input"
+    ctx.coords_set(torch.from_numpy(shuffled).cuda(), int(case["n_scans"]))
+    assert np.array_equal(H.sort_rows(_np(ctx.level_coords(0))), H.sort_rows(c4))
+    for lvl in range(1, 8):
+        got = _np(ctx.level_coords(lvl))
+        assert len(np.unique(H.rowkey(got))) == len(got)
+        if lvl >= 3:
+            assert np.array_equal(H.sort_rows(got), case[f"level{lvl}_coords"])
+        else:
+            assert np.array_equal(H.sort_rows(got), H.sort_rows(ops.stride_coords(c4, 1 << lvl)))
+    # input_index: row i of level 0 came from caller row index[i]
+    idx = _np(ctx.input_index())
+    assert np.array_equal(shuffled[idx], _np(ctx.level_coords(0)))
+    # per-sample offsets
+    off = ctx.level_batch_offsets(3)
+    b = _np(ctx.level_coords(3))[:, 0]
+    assert off[0] == 0 and off[-1] == len(b)
+    for s in range(int(case["n_scans"])):
+        assert (b[off[s]:off[s + 1]] == s).all()
+
+
+def test_coords_duplicates_and_errors(gpu):
+    ctx = gpu._lib.Context()
+    c = torch.tensor([[0, 1, 2, 3], [0, -5, 0, 7], [0, 1, 2, 3], [1, 0, 0, 0]], dtype=torch.int32).cuda()
+    ctx.coords_set(c, 2)
+    assert ctx.level_count(0) == 3                             # duplicate collapsed onto its first occurrence
+    idx = _np(ctx.input_index())
+    assert sorted(idx.tolist()) == [0, 1, 3]
+    with pytest.raises(RuntimeError, match="batch"):
+        ctx.coords_set(c, 1)                                   # batch index 1 >= batch size 1
+    big = torch.tensor([[0, 40000, 0, 0]], dtype=torch.int32).cuda()
+    with pytest.raises(RuntimeError, match="range"):
+        ctx.coords_set(big, 1)
+    small = gpu._lib.Context(coord_bits=10)                    # +-512 voxels
+    with pytest.raises(RuntimeError, match="range"):
+        small.coords_set(torch.tensor([[0, 600, 0, 0]], dtype=torch.int32).cuda(), 1)
+    small.coords_set(torch.tensor([[0, 511, -512, 0]], dtype=torch.int32).cuda(), 1)
+    assert _np(small.level_coords(0)).tolist() == [[0, 511, -512, 0]]
+    assert _np(small.level_coords(7)).tolist() == [[0, 384, -512, 0]]
+
+
+# ------------------------------------------------------------------------------------ sparse-conv primitives (a4-a6)
+def _oracle_levels(c4):
+    from oracle import egonn_ref as ref
+    return ref.SparseLevels(c4)
+
+
+@pytest.mark.parametrize("naive", [False, True])
+def test_conv_primitives_vs_oracle(gpu, naive):
+    from oracle import me_ops as ops
+    case = H.load_case("egonn_cart01_b2")
+    c4 = case["coords"]
+    lv = _oracle_levels(c4)
+    ctx = gpu._lib.Context()
+    ctx.coords_set(torch.from_numpy(c4).cuda(), 2)
+    rng = np.random.default_rng(1)
+    gpu._lib.load().egonn_debug_set_naive_conv(int(naive))
+    try:
+        def feats(level, c):
+            """random features defined per coordinate; returns (oracle-order, hip-order) arrays"""
+            f = rng.standard_normal((lv.n(level), c)).astype(np.float32)
+            perm = H.join_perm(lv.coords[level], _np(ctx.level_coords(level)))
+            return f, f[perm]
+
+        def check(level, got, want, tol=2e-5):
+            perm = H.join_perm(_np(ctx.level_coords(level)), lv.coords[level])
+            got = _np(got)[perm]
+            scale = np.abs(want).max() + 1e-6
+            assert np.abs(got - want).max() / scale < tol, (level, np.abs(got - want).max() / scale)
+
+        # k=3 at several levels / channel plans (all kernel instantiations of the EgoNN trunk)
+        for level, cin, cout in [(1, 32, 32), (2, 32, 64), (2, 64, 64), (4, 64, 128), (4, 128, 128), (6, 128, 128)]:
+            fo, fh = feats(level, cin)
+            w = (rng.standard_normal((27, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+            sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+            sh = rng.standard_normal(cout).astype(np.float32) * 0.1
+            want = ops.conv_forward(fo, w, lv.kmap(level, level, 3), lv.n(level))
+            got = ctx.conv(level, level, 3, torch.from_numpy(fh), torch.from_numpy(w))
+            check(level, got, want)
+            got = ctx.conv(level, level, 3, torch.from_numpy(fh), torch.from_numpy(w), torch.from_numpy(sc),
+                           torch.from_numpy(sh), relu=True)
+            check(level, got, np.maximum(want * sc + sh, 0))
+        # k=2, s=2
+        for level, c in [(0, 32), (1, 32), (2, 64), (4, 128)]:
+            fo, fh = feats(level, c)
+            w = (rng.standard_normal((8, c, c)) / np.sqrt(2 * c)).astype(np.float32)
+            want = ops.conv_forward(fo, w, lv.kmap(level, level + 1, 2), lv.n(level + 1))
+            got = ctx.conv(level, level + 1, 2, torch.from_numpy(fh), torch.from_numpy(w))
+            check(level + 1, got, want)
+        # transposed k=2, s=2 onto the cached finer map
+        for level, c in [(4, 64), (7, 128), (6, 128)]:
+            fo, fh = feats(level, c)
+            w = (rng.standard_normal((8, c, c)) / np.sqrt(c)).astype(np.float32)
+            want = ops.conv_transpose_forward(fo, w, lv.kmap(level - 1, level, 2), lv.n(level - 1))
+            got = ctx.conv_transpose(level, torch.from_numpy(fh), torch.from_numpy(w))
+            check(level - 1, got, want)
+        # k=5, Cin=1 (non-constant features to exercise the general path)
+        fo, fh = feats(0, 1)
+        w = (rng.standard_normal((125, 1, 32)) / np.sqrt(20)).astype(np.float32)
+        want = ops.conv_forward(fo, w, lv.kmap(0, 0, 5), lv.n(0))
+        got = ctx.conv(0, 0, 5, torch.from_numpy(fh), torch.from_numpy(w))
+        check(0, got, want)
+        # 1x1
+        fo, fh = feats(3, 64)
+        w = (rng.standard_normal((64, 128)) / 8).astype(np.float32)
+        check(3, ctx.conv(3, 3, 1, torch.from_numpy(fh), torch.from_numpy(w)), fo @ w)
+        # global average pooling
+        fo, fh = feats(2, 64)
+        got = _np(ctx.global_avg_pool(2, torch.from_numpy(fh)))
+        np.testing.assert_allclose(got, ops.global_avg_pool(fo, lv.coords[2], 2), rtol=1e-4, atol=1e-5)
+    finally:
+        gpu._lib.load().egonn_debug_set_naive_conv(0)
+
+
+def test_conv_known_answer_line(gpu):
+    """hand-derivable case: three voxels on a line (same as tests/test_oracle.py)."""
+    ctx = gpu._lib.Context()
+    # put the line at level 1 (coordinates multiples of 2) by giving every level-1 voxel one child
+    c = torch.tensor([[0, 0, 0, 0], [0, 2, 0, 0], [0, 4, 0, 0]], dtype=torch.int32).cuda()
+    ctx.coords_set(c, 1)
+    assert _np(ctx.level_coords(1)).tolist() == [[0, 0, 0, 0], [0, 2, 0, 0], [0, 4, 0, 0]]
+    f = torch.zeros((3, 32))
+    f[:, 0] = torch.tensor([1.0, 10.0, 100.0])
+    k = torch.zeros((27, 32, 32))
+    k[:, 0, 0] = torch.arange(27, dtype=torch.float32)
+    out = _np(ctx.conv(1, 1, 3, f, k))[:, 0]
+    assert np.allclose(out, [1 * 13 + 10 * 14, 1 * 12 + 10 * 13 + 100 * 14, 10 * 12 + 100 * 13])
+
+
+# ------------------------------------------------------------------------------------ full forward (a4-a10)
+@pytest.mark.parametrize("name", H.CASES)
+def test_forward_matches_reference_graph(gpu, name):
+    case = H.load_case(name)
+    m, _ = _model(gpu, case)
+    c4 = case["coords"]
+    rng = np.random.default_rng(2)
+    order = rng.permutation(len(c4))                           # arbitrary caller row order
+    batch = {"coords": torch.from_numpy(c4[order]), "features": torch.ones((len(c4), 1))}
+    with torch.no_grad():
+        y = m(batch)
+    ctx = m.context()
+    for lvl, ch in ((3, 64), (7, 128)):
+        got = _np(ctx.forward_level_features(lvl, ch))
+        perm = H.join_perm(_np(ctx.level_coords(lvl)), case[f"level{lvl}_coords"])
+        np.testing.assert_allclose(got[perm], case[f"level{lvl}_feats"], rtol=2e-3, atol=2e-4)
+    g = _np(y["global"])
+    assert g.shape == case["global"].shape
+    assert H.cosine_err(g, case["global"]).max() < 1e-4        # north_star bar
+    np.testing.assert_allclose(g, case["global"], rtol=1e-3, atol=1e-4)
+    kc = m.keypoint_coords()
+    assert len(y["descriptors"]) == len(y["keypoints"]) == len(y["sigma"]) == int(case["n_scans"])
+    for b in range(int(case["n_scans"])):
+        perm = H.join_perm(_np(kc[b]), case[f"kp_coords_{b}"])
+        assert H.cosine_err(_np(y["descriptors"][b])[perm], case[f"descriptors_{b}"]).max() < 1e-4
+        np.testing.assert_allclose(_np(y["keypoints"][b])[perm], case[f"keypoints_{b}"], rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(_np(y["sigma"][b])[perm], case[f"sigma_{b}"], rtol=1e-3, atol=1e-4)
+        assert y["sigma"][b].shape[1] == 1 and y["keypoints"][b].shape[1] == 3
+    # head switches (reference models/minkgl.py:267-268)
+    with torch.no_grad():
+        yg = m(batch, disable_local_head=True)
+        yl = m(batch, disable_global_head=True)
+    assert set(yg.keys()) == {"global"} and set(yl.keys()) == {"descriptors", "keypoints", "sigma"}
+    assert torch.equal(yg["global"], y["global"])              # deterministic
+
+
+@pytest.mark.parametrize("name", ["egonn_cart01_b1", "egonn_cart01_b2", "egonn_cart03_b1"])
+def test_compute_embedding_matches_reference_selection(gpu, name):
+    """eval/evaluate.py:327-361: quantise -> forward -> 128 lowest-sigma keypoints, ascending."""
+    case = H.load_case(name)
+    m, _ = _model(gpu, case)
+    ex = gpu.DescriptorExtractor(m, n_k=128)
+    scans = [torch.from_numpy(case[f"points_{b}"]) for b in range(int(case["n_scans"]))]
+    out = ex.extract(scans)
+    assert H.cosine_err(_np(out["global"]), case["global"]).max() < 1e-4
+    kc = m.keypoint_coords()
+    off = m.context().level_batch_offsets(3)
+    for b in range(len(scans)):
+        n = int(out["count"][b])
+        want_c = case[f"topk_coords_{b}"]
+        assert n == len(want_c)
+        rows = _np(out["rows"][b, :n]).astype(np.int64) - off[b]
+        got_c = _np(kc[b])[rows]
+        # the ordered list of selected super-voxels; fp32 noise may swap near-equal sigmas, so compare
+        # exactly where the reference sigmas are separated by more than the forward tolerance
+        ws = case[f"topk_sigma_{b}"]
+        gap_ok = np.r_[True, np.diff(ws) > 2e-4] & np.r_[np.diff(ws) > 2e-4, True]
+        assert (np.all(got_c == want_c, axis=1) | ~gap_ok).all()
+        assert np.all(got_c == want_c, axis=1).mean() > 0.9
+        # selected descriptors / keypoints equal the full outputs at those rows
+        sel = {tuple(c): i for i, c in enumerate(case[f"kp_coords_{b}"].tolist())}
+        ridx = np.array([sel[tuple(c)] for c in got_c.tolist()])
+        assert H.cosine_err(_np(out["descriptors"][b, :n]), case[f"descriptors_{b}"][ridx]).max() < 1e-4
+        np.testing.assert_allclose(_np(out["keypoints"][b, :n]), case[f"keypoints_{b}"][ridx], rtol=1e-4, atol=2e-3)
+    # reference-shaped single-scan API
+    g, kp, desc = ex.compute_embedding(scans[0])
+    assert g.shape == (1, 256) and kp.shape[1] == 3 and desc.shape[1] == 128 and not kp.is_cuda
+
+
+def test_select_keypoints_exact_vs_oracle(gpu):
+    """integer result: on identical sigma values the selection is bit-exact, ties broken by Z-order."""
+    from oracle import egonn_ref as ref
+    case = H.load_case("egonn_cart01_b2")
+    ctx = gpu._lib.Context()
+    ctx.coords_set(torch.from_numpy(case["coords"]).cuda(), 2)
+    c3 = _np(ctx.level_coords(3))
+    off = ctx.level_batch_offsets(3)
+    rng = np.random.default_rng(3)
+    sigma = rng.uniform(0.1, 2.0, size=(len(c3), 1)).astype(np.float32)
+    sigma[rng.integers(0, len(c3), 300)] = 0.5                 # force ties
+    kp = rng.standard_normal((len(c3), 3)).astype(np.float32)
+    desc = rng.standard_normal((len(c3), 128)).astype(np.float32)
+    for n_k in (128, 16, 4096):
+        skp, sdesc, rows, cnt = ctx.select_keypoints(torch.from_numpy(sigma).cuda(), torch.from_numpy(kp).cuda(),
+                                                     torch.from_numpy(desc).cuda(), n_k)
+        for b in range(2):
+            s, e = off[b], off[b + 1]
+            want = ref.select_keypoints(sigma[s:e], c3[s:e], n_k) + s
+            n = int(cnt[b])
+            assert n == len(want)
+            assert np.array_equal(_np(rows[b, :n]), want)
+            assert np.array_equal(_np(skp[b, :n]), kp[want]) and np.array_equal(_np(sdesc[b, :n]), desc[want])
+            assert (_np(rows[b, n:]) == -1).all()
+
+
+# ------------------------------------------------------------------------------------ edge cases
+def test_tiny_and_ragged_batches(gpu):
+    from oracle import egonn_ref as ref
+    m, w = _model(gpu, seed=21)
+    oracle = ref.EgoNNOracle(w, ref.CartesianQuantizer(0.1))
+    rng = np.random.default_rng(4)
+    # one voxel; two distant voxels; a ragged batch with very different sample sizes
+    cases = [np.array([[0, 3, -4, 5]], np.int32),
+             np.array([[0, 0, 0, 0], [0, 900, -900, 40]], np.int32)]
+    from egonn_amd.synth import lidar_scan
+    big = ref.CartesianQuantizer(0.1)(lidar_scan(8, 3000))[0]
+    small = ref.CartesianQuantizer(0.1)(lidar_scan(9, 40))[0]
+    from oracle import me_ops as ops
+    cases.append(ops.batched_coordinates([small, big, small[:1]]))
+    for c4 in cases:
+        f = np.ones((len(c4), 1), np.float32)
+        with torch.no_grad():
+            y = m({"coords": torch.from_numpy(c4), "features": torch.from_numpy(f)})
+        yo = oracle.forward(c4, f)
+        assert H.cosine_err(_np(y["global"]), yo["global"]).max() < 1e-4
+        kc = m.keypoint_coords()
+        for b in range(len(yo["descriptors"])):
+            perm = H.join_perm(_np(kc[b]), yo["keypoint_coords"][b])
+            assert H.cosine_err(_np(y["descriptors"][b])[perm], yo["descriptors"][b]).max() < 1e-4
+            np.testing.assert_allclose(_np(y["sigma"][b])[perm], yo["sigma"][b], rtol=1e-3, atol=1e-4)
+            np.testing.assert_allclose(_np(y["keypoints"][b])[perm], yo["keypoints"][b], rtol=1e-4, atol=2e-3)
+
+
+def test_empty_scan_inside_batch(gpu):
+    m, _ = _model(gpu, seed=22)
+    ex = gpu.DescriptorExtractor(m, n_k=64)
+    from egonn_amd.synth import lidar_scan
+    a, b = torch.from_numpy(lidar_scan(1, 2000)), torch.from_numpy(lidar_scan(2, 2500))
+    out = ex.extract([a, torch.zeros((0, 3)), b])
+    solo_a, solo_b = ex.extract([a]), ex.extract([b])
+    assert int(out["count"][1]) == 0
+    assert H.cosine_err(_np(out["global"][[0]]), _np(solo_a["global"])).max() < 1e-5
+    assert H.cosine_err(_np(out["global"][[2]]), _np(solo_b["global"])).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------ full size (BASELINE configs[1])
+def test_full_size_properties_batch16(gpu):
+    """50k-pt clouds @ 0.1 m, batch 16 (BASELINE.json configs[1]): properties that need no oracle.
+       (1) determinism, (2) batch invariance: every sample's outputs equal the single-sample run
+       (eval BN, per-sample ECA/GeM), (3) voxel keys strictly increasing and parents consistent,
+       (4) a sampled oracle check on one of the 16 scans."""
+    from egonn_amd.synth import lidar_scan
+    from oracle import egonn_ref as ref
+    m, w = _model(gpu, seed=31)
+    ex = gpu.DescriptorExtractor(m, n_k=128)
+    scans = [torch.from_numpy(lidar_scan(100 + i, 50_000)).cuda() for i in range(16)]
+    out1 = ex.extract(scans)
+    ctx = m.context()
+    counts = [ctx.level_count(l) for l in range(8)]
+    assert all(counts[l] > counts[l + 1] > 0 for l in range(7))
+    c0 = _np(ctx.level_coords(0))
+    k0 = H.rowkey(c0)
+    assert len(np.unique(k0)) == len(k0) and (np.diff(c0[:, 0]) >= 0).all()     # unique, batch-contiguous
+    c3 = _np(ctx.level_coords(3))
+    assert (c3[:, 1:] % 8 == 0).all()
+    par = np.unique(H.rowkey(np.c_[c0[:, :1], (c0[:, 1:] >> 3) << 3]))
+    assert np.array_equal(par, np.sort(H.rowkey(c3)))                             # level 3 = floor-parents of level 0
+    g1, d1, k1 = out1["global"].clone(), out1["descriptors"].clone(), out1["keypoints"].clone()
+    out2 = ex.extract(scans)
+    assert torch.equal(g1, out2["global"]) and torch.equal(d1, out2["descriptors"]) and torch.equal(k1, out2["keypoints"])
+    for b in (0, 7, 15):
+        solo = ex.extract([scans[b]])
+        assert H.cosine_err(_np(solo["global"]), _np(g1[[b]])).max() < 1e-5
+        n = int(solo["count"][0])
+        assert n == int(out1["count"][b]) == 128
+        assert H.cosine_err(_np(solo["descriptors"][0]), _np(d1[b])).max() < 1e-4
+        np.testing.assert_allclose(_np(solo["keypoints"][0]), _np(k1[b]), atol=2e-3)
+    # sampled oracle check of one full-size scan (the oracle needs a few seconds for it)
+    oracle = ref.EgoNNOracle(w, ref.CartesianQuantizer(0.1))
+    pc = _np(scans[3])
+    g_ref, kp_ref, desc_ref, kc_ref = ref.compute_embedding(oracle, pc, 128)
+    assert H.cosine_err(_np(g1[[3]]), g_ref).max() < 1e-4
+    rows = _np(out1["rows"][3]).astype(np.int64)
+    got_c = c3[rows]
+    same = np.all(got_c[:, 1:] == kc_ref[:, 1:], axis=1)
+    assert same.mean() > 0.9                                    # near-tie swaps only
+    assert H.cosine_err(_np(d1[3])[same], desc_ref[same]).max() < 1e-4

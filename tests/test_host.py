@@ -1,0 +1,84 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, the module
+tree reproduces the reference state_dict, the INI surface parses, and the product path refuses to run
+without a HIP device (no CPU fallback)."""
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from tests import helpers as H
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    return True
+
+
+def test_library_exports_every_declared_symbol(built):
+    from egonn_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(REPO, "include", "egonn_hip.h")).read()
+    declared = set(re.findall(r"\b(egonn_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_state_dict_matches_reference_keys_shapes_and_order(built):
+    from egonn_amd import ModelParams, model_factory
+    m = model_factory(ModelParams(model="egonn", coordinates="cartesian", quantization_step=0.1))
+    sd = m.state_dict()
+    ref = H.state_dict_shapes()
+    assert set(sd.keys()) == set(ref.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == ref[k], k
+    assert sum(p.nelement() for p in m.parameters()) == 4707298
+    assert sum(p.nelement() for p in m.trunk.parameters()) == 4253821
+    # load_state_dict(strict) round trip with seeded weights
+    w = H.seeded_weights(3)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+
+
+def test_model_params_ini(tmp_path, built):
+    from egonn_amd import ModelParams, CartesianQuantizer, PolarQuantizer
+    p = tmp_path / "egonn.txt"
+    p.write_text("[MODEL]\nmodel = egonn\ncoordinates = polar\nquantization_step = 1., 0.3, 0.2\n")
+    mp = ModelParams(str(p))
+    assert mp.model == "egonn" and isinstance(mp.quantizer, PolarQuantizer)
+    assert mp.quantization_step == [1.0, 0.3, 0.2] and mp.quantizer.theta_range == 360
+    p.write_text("[MODEL]\nmodel = egonn\ncoordinates = cartesian\nquantization_step = 0.1\n")
+    mp = ModelParams(str(p))
+    assert isinstance(mp.quantizer, CartesianQuantizer) and mp.quantization_step == 0.1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback(built):
+    from egonn_amd import ModelParams, model_factory
+    m = model_factory(ModelParams(model="egonn", coordinates="cartesian", quantization_step=0.1)).eval()
+    batch = {"coords": torch.zeros((1, 4), dtype=torch.int32), "features": torch.ones((1, 1))}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(batch)
+    with pytest.raises(RuntimeError, match="no CPU fallback|no HIP device"):
+        m.quantizer(torch.zeros((4, 3)))
+
+
+def test_training_mode_is_refused_loudly(built):
+    from egonn_amd import ModelParams, model_factory
+    m = model_factory(ModelParams(model="egonn", coordinates="cartesian", quantization_step=0.1)).train()
+    with pytest.raises(NotImplementedError):
+        m({"coords": torch.zeros((1, 4), dtype=torch.int32), "features": torch.ones((1, 1))})
+
+
+def test_synthetic_generator_is_deterministic():
+    from egonn_amd.synth import lidar_scan
+    a, b = lidar_scan(4, 5000), lidar_scan(4, 5000)
+    assert a.shape == (5000, 3) and a.dtype.name == "float32" and (a == b).all()
+    case = H.load_case("egonn_cart01_b1")
+    assert (lidar_scan(3, 12000) == case["points_0"]).all()      # fixtures are reproducible from the seed
