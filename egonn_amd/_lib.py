@@ -40,6 +40,9 @@ _SIGS = [
     ("egonn_forward", C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_float), C.c_int, _P, _P, _P, _P, _P]),
     ("egonn_forward_level_features", C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     ("egonn_select_keypoints", C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
+    ("egonn_profile_enable", C.c_int, [_P, C.c_int, C.c_char_p]),
+    ("egonn_profile_fetch", C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGS]
 
@@ -209,6 +212,25 @@ class Context:
                                                   descriptors.data_ptr(), n_k, sel_kp.data_ptr(), sel_desc.data_ptr(),
                                                   sel_rows.data_ptr(), sel_count.data_ptr(), _stream()))
         return sel_kp, sel_desc, sel_rows, sel_count
+
+
+    # ------------------------------------------------------------------ launch timing
+    def profile_enable(self, mode: int, filt: str = ""):
+        check(self.lib.egonn_profile_enable(self.h, mode, filt.encode()))
+
+    def profile_fetch(self, cap: int = 4096):
+        n = C.c_int()
+        names = C.create_string_buffer(cap * 64)
+        ms = (C.c_float * cap)()
+        by = (C.c_double * cap)()
+        fl = (C.c_double * cap)()
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_profile_fetch(self.h, cap, C.byref(n), names, ms, by, fl, _stream()))
+        out = []
+        for i in range(n.value):
+            nm = names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode()
+            out.append((nm, float(ms[i]), float(by[i]), float(fl[i])))
+        return out
 
 
 class ModelHandle:

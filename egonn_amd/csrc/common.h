@@ -121,7 +121,25 @@ struct Plan {
   std::vector<int32_t> boff_host[EGONN_NUM_LEVELS];   // host copies of boff (size B+1)
 };
 
+// ------------------------------------------------------------------ per-launch HIP-event timing (bench.py roofline leg)
+enum ProfKind { PK_CONV0 = 0, PK_K3 = 1, PK_K2S2 = 2, PK_TCONV = 3, PK_OTHER = 4 };
+struct ProfRec {
+  char name[64];
+  int kind, level, K, cin, cout;     // enough to evaluate the algorithmic-bytes formula of SURVEY.md §8(d)
+  int64_t n_in, n_out;
+  hipEvent_t e0, e1;
+};
+struct Profiler {
+  int mode = 0;                       // 0 off, 1 all tagged launches, 2 only launches whose name contains `filter`
+  char filter[64] = "";
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get();
+};
+
 struct Ctx {
+  Profiler prof;
+  unsigned long long* dev_pairs = nullptr;   // [16] kernel-map pair counters: [0] conv0 k5, [l] k3 map of level l
   int device = 0;
   int coord_bits = 16;
   Arena plan_arena;           // keys, maps (lives until the next plan)
@@ -132,6 +150,16 @@ struct Ctx {
   int32_t* dev_counts = nullptr;
   int32_t* dev_flags = nullptr;      // [0] = out-of-range coordinate seen
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// RAII launch timer: records events on `stream` around the enclosed launches when profiling is enabled.
+struct ProfScope {
+  Ctx* ctx;
+  hipStream_t st;
+  int idx = -1;
+  ProfScope(Ctx* c, hipStream_t s, const char* name, int kind, int level, int K, int cin, int cout, int64_t n_in,
+            int64_t n_out);
+  ~ProfScope();
 };
 
 // ------------------------------------------------------------------ sort.hip

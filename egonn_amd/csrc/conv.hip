@@ -329,7 +329,8 @@ __global__ __launch_bounds__(256) void conv0_k5_kernel(const float* __restrict__
                                                         int32_t nvox, int cbL, const float* __restrict__ W,   // [125][32]
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int relu,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out,
+                                                        unsigned long long* __restrict__ pair_counter) {
   __shared__ float sW[125 * COUT0];
   __shared__ uint64_t s_m[4][27];
   __shared__ int32_t s_s[4][27];
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(256) void conv0_k5_kernel(const float* __restrict__
   const int k0 = lane, k1 = lane + 64;
   const int dx0 = k0 % 5 - 2, dy0 = (k0 / 5) % 5 - 2, dz0 = k0 / 25 - 2;
   const int dx1 = k1 % 5 - 2, dy1 = (k1 / 5) % 5 - 2, dz1 = k1 / 25 - 2;
+  int32_t npairs = 0;
   for (int32_t v = s; v < e; ++v) {
     const uint32_t lk = (uint32_t)(vkeys[v] & 63);
     const int32_t lx = (lk & 1) | ((lk >> 2) & 2), ly = ((lk >> 1) & 1) | ((lk >> 3) & 2),
@@ -390,6 +392,7 @@ __global__ __launch_bounds__(256) void conv0_k5_kernel(const float* __restrict__
       }
     }
     uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
+    npairs += __popcll(m0) + __popcll(m1);
     float acc = 0.f;
     // two hits per iteration: lanes 0-31 take the first, lanes 32-63 the second
 #pragma unroll 1
@@ -421,16 +424,18 @@ __global__ __launch_bounds__(256) void conv0_k5_kernel(const float* __restrict__
       out[(int64_t)v * COUT0 + c] = r;
     }
   }
+  if (lane == 0 && npairs) atomicAdd(pair_counter, (unsigned long long)npairs);
 }
 
-int conv0_k5_forward(const Plan& P, const float* feat, const float* W, int cout, const float* scale,
+int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, const float* scale,
                      const float* shift, int relu, float* out, hipStream_t stream) {
+  const Plan& P = ctx->plan;
   EGONN_REQUIRE(cout == COUT0, EGONN_ERR_INVALID, "conv0: %d output channels not supported (expected %d)", cout, COUT0);
   const Level& V = P.lv[0];
   const Level& B = P.lv[2];
   if (V.n == 0) return EGONN_OK;
   hipLaunchKernelGGL(conv0_k5_kernel, dim3((unsigned)cdiv(B.n, 4)), dim3(256), 0, stream, feat, V.keys, B.keys, B.mask,
-                     B.bstart, (int32_t)B.n, (int32_t)V.n, P.coord_bits - 2, W, scale, shift, relu, out);
+                     B.bstart, (int32_t)B.n, (int32_t)V.n, P.coord_bits - 2, W, scale, shift, relu, out, ctx->dev_pairs);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }

@@ -45,6 +45,34 @@ void Arena::release() {
   cap = off = 0;
 }
 
+hipEvent_t Profiler::get() {
+  if (!pool.empty()) {
+    hipEvent_t e = pool.back();
+    pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+ProfScope::ProfScope(Ctx* c, hipStream_t s, const char* name, int kind, int level, int K, int cin, int cout,
+                     int64_t n_in, int64_t n_out)
+    : ctx(c), st(s) {
+  if (!c || c->prof.mode == 0) return;
+  if (c->prof.mode == 2 && !strstr(name, c->prof.filter)) return;
+  ProfRec r;
+  snprintf(r.name, sizeof(r.name), "%s", name);
+  r.kind = kind; r.level = level; r.K = K; r.cin = cin; r.cout = cout; r.n_in = n_in; r.n_out = n_out;
+  r.e0 = c->prof.get();
+  r.e1 = c->prof.get();
+  (void)hipEventRecord(r.e0, s);
+  idx = (int)c->prof.recs.size();
+  c->prof.recs.push_back(r);
+}
+ProfScope::~ProfScope() {
+  if (idx >= 0) (void)hipEventRecord(ctx->prof.recs[idx].e1, st);
+}
+
 // ------------------------------------------------------------------ key construction
 struct QuantParams {
   int mode;        // 0 = cartesian floor(p / q), 1 = polar (theta deg, r, z) / (s0, s1, s2)
@@ -373,7 +401,8 @@ __global__ __launch_bounds__(256) void nbr27_kernel(const uint64_t* __restrict__
                                                      const uint64_t* __restrict__ bkeys,      // level l+2
                                                      const uint64_t* __restrict__ bmask,
                                                      const int32_t* __restrict__ bstart, int32_t nblocks,
-                                                     int32_t nvox, int cbL, int32_t* __restrict__ nbr) {
+                                                     int32_t nvox, int cbL, int32_t* __restrict__ nbr,
+                                                     unsigned long long* __restrict__ pair_counter) {
   __shared__ uint64_t s_m[4][27];
   __shared__ int32_t s_s[4][27];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -385,14 +414,20 @@ __global__ __launch_bounds__(256) void nbr27_kernel(const uint64_t* __restrict__
   const int32_t s = bstart[j];
   const int32_t e = (j + 1 < nblocks) ? bstart[j + 1] : nvox;
   const int32_t items = (e - s) * 27;
+  int32_t found = 0;
   for (int32_t t = lane; t < items; t += 64) {
     const int32_t v = t / 27, k = t - v * 27;
     const uint32_t lk = (uint32_t)(vkeys[s + v] & 63);
     const int32_t lx = (lk & 1) | ((lk >> 2) & 2), ly = ((lk >> 1) & 1) | ((lk >> 3) & 2),
                   lz = ((lk >> 2) & 1) | ((lk >> 4) & 2);
     const int32_t nx = lx + (k % 3) - 1, ny = ly + (k / 3) % 3 - 1, nz = lz + k / 9 - 1;
-    nbr[(int64_t)s * 27 + t] = lookup_local(s_m[wave], s_s[wave], nx, ny, nz);
+    const int32_t r = lookup_local(s_m[wave], s_s[wave], nx, ny, nz);
+    nbr[(int64_t)s * 27 + t] = r;
+    found += (r >= 0);
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) found += __shfl_xor(found, o, 64);
+  if (lane == 0 && found) atomicAdd(pair_counter, (unsigned long long)found);
 }
 
 // ------------------------------------------------------------------ k=2,s=2 tables
@@ -455,6 +490,7 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
   Plan& P = ctx->plan;
   const int cb = ctx->coord_bits;
   Arena& A = ctx->plan_arena;
+  HIP_CHECK(hipMemsetAsync(ctx->dev_pairs, 0, sizeof(unsigned long long) * 16, stream));
   EGONN_TRY(radix_sort_pairs(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, 3 * cb + batch_bits(B), stream));
 
   const int ntiles = (int)cdiv(n, PYR_TILE);
@@ -536,7 +572,7 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
     if (nv == 0) continue;
     const Level& Bk = P.lv[l + 2];
     hipLaunchKernelGGL(nbr27_kernel, dim3((unsigned)cdiv(Bk.n, 4)), dim3(256), 0, stream, V.keys, Bk.keys, Bk.mask,
-                       Bk.bstart, (int32_t)Bk.n, nv, cb - (l + 2), V.nbr27);
+                       Bk.bstart, (int32_t)Bk.n, nv, cb - (l + 2), V.nbr27, ctx->dev_pairs + l);
     hipLaunchKernelGGL(nbr8_kernel, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, stream, V.cstart, P.lv[l - 1].keys,
                        nv, V.nbr8);
     hipLaunchKernelGGL(nbrT_kernel, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, stream, V.parent, V.keys, nv,

@@ -11,7 +11,7 @@ const char* last_error();
 int sconv_forward(const float* in, const int32_t* nbr, const float* W, const float* scale, const float* shift,
                   int relu, float* out, int32_t n_out, int K, int cin, int cout, hipStream_t stream);
 void sconv_set_naive(bool on);
-int conv0_k5_forward(const Plan& P, const float* feat, const float* W, int cout, const float* scale,
+int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, const float* scale,
                      const float* shift, int relu, float* out, hipStream_t stream);
 
 // dense.hip ------------------------------------------------------------------------------------

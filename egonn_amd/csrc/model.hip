@@ -92,7 +92,8 @@ API int egonn_ctx_create(egonn_ctx** out, int device, int coord_bits) {
   const size_t hc = sizeof(int32_t) * (32 + (size_t)EGONN_NUM_LEVELS * (EGONN_MAX_BATCH + 1));
   if (hipHostMalloc(reinterpret_cast<void**>(&c->host_counts), hc) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&c->dev_counts), sizeof(int32_t) * 32) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&c->dev_flags), sizeof(int32_t) * 4) != hipSuccess) {
+      hipMalloc(reinterpret_cast<void**>(&c->dev_flags), sizeof(int32_t) * 4) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->dev_pairs), sizeof(unsigned long long) * 16) != hipSuccess) {
     set_error("ctx_create: allocation failed");
     delete c;
     return EGONN_ERR_HIP;
@@ -111,6 +112,9 @@ API void egonn_ctx_destroy(egonn_ctx* c) {
   if (c->host_counts) (void)hipHostFree(c->host_counts);
   if (c->dev_counts) (void)hipFree(c->dev_counts);
   if (c->dev_flags) (void)hipFree(c->dev_flags);
+  if (c->dev_pairs) (void)hipFree(c->dev_pairs);
+  for (auto& r : c->prof.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto e : c->prof.pool) (void)hipEventDestroy(e);
   delete c;
 }
 
@@ -201,7 +205,7 @@ API int egonn_conv(egonn_ctx* c, int level_in, int level_out, int ks, const floa
   if (ks == 5) {
     EGONN_REQUIRE(level_in == 0 && level_out == 0 && cin == 1, EGONN_ERR_INVALID,
                   "k=5 convolution is implemented for the stride-1 input layer with Cin=1 only");
-    return conv0_k5_forward(P, in, kernel, cout, scale, shift, relu, out, st);
+    return conv0_k5_forward(c, in, kernel, cout, scale, shift, relu, out, st);
   }
   if (ks == 3) {
     EGONN_REQUIRE(level_in == level_out && level_in >= 1, EGONN_ERR_INVALID,
@@ -438,7 +442,10 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     f0 = fg;
   }
   WALLOC(x0, n0 * 32);
-  EGONN_TRY(conv0_k5_forward(P, f0, m->conv0, 32, m->bn[0].scale, m->bn[0].shift, 1, x0, st));
+  {
+    ProfScope ps(c, st, "conv0_k5_kernel/L0", PK_CONV0, 0, 125, 1, 32, n0, n0);
+    EGONN_TRY(conv0_k5_forward(c, f0, m->conv0, 32, m->bn[0].scale, m->bn[0].shift, 1, x0, st));
+  }
   const float* x[8] = {x0};
   c->level_feat[0] = x0;
   c->level_ch[0] = 32;
@@ -447,13 +454,26 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     const Level& L = P.lv[i];
     const int64_t n = L.n;
     WALLOC(y, n * b.cin);
-    EGONN_TRY(sconv_forward(x[i - 1], L.nbr8, m->convs[i], m->bn[i].scale, m->bn[i].shift, 1, y, (int32_t)n, 8, b.cin,
-                            b.cin, st));
+    char tag[64];
+    {
+      snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k2s2", b.cin, b.cin, i);
+      ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, P.lv[i - 1].n, n);
+      EGONN_TRY(sconv_forward(x[i - 1], L.nbr8, m->convs[i], m->bn[i].scale, m->bn[i].shift, 1, y, (int32_t)n, 8,
+                              b.cin, b.cin, st));
+    }
     // ECABasicBlock (layers/eca_block.py:56-73)
     WALLOC(t1, n * b.cout);
-    EGONN_TRY(sconv_forward(y, L.nbr27, b.conv1, b.n1.scale, b.n1.shift, 1, t1, (int32_t)n, 27, b.cin, b.cout, st));
+    {
+      snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k3.conv1", b.cin, b.cout, i);
+      ProfScope ps(c, st, tag, PK_K3, i, 27, b.cin, b.cout, n, n);
+      EGONN_TRY(sconv_forward(y, L.nbr27, b.conv1, b.n1.scale, b.n1.shift, 1, t1, (int32_t)n, 27, b.cin, b.cout, st));
+    }
     WALLOC(t2, n * b.cout);
-    EGONN_TRY(sconv_forward(t1, L.nbr27, b.conv2, b.n2.scale, b.n2.shift, 0, t2, (int32_t)n, 27, b.cout, b.cout, st));
+    {
+      snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k3.conv2", b.cout, b.cout, i);
+      ProfScope ps(c, st, tag, PK_K3, i, 27, b.cout, b.cout, n, n);
+      EGONN_TRY(sconv_forward(t1, L.nbr27, b.conv2, b.n2.scale, b.n2.shift, 0, t2, (int32_t)n, 27, b.cout, b.cout, st));
+    }
     WALLOC(partial, (size_t)B * SEG_CHUNKS * b.cout + (size_t)B * b.cout);
     EGONN_TRY(segment_partial_sums(t2, L.boff, B, b.cout, 0, nullptr, partial, st));
     const float* res = y;
@@ -544,4 +564,51 @@ API int egonn_select_keypoints(egonn_ctx* c, const float* sigma, const float* ke
   if (rc == EGONN_OK) rc = gather_topk(sel_rows, sel_count, P.batch, n_k, keypoints, descriptors, LOCAL_DIM, sel_kp, sel_desc, st);
   c->work_arena.off = mark;
   return rc;
+}
+
+
+// ------------------------------------------------------------------------------------------ launch timing (bench.py)
+API int egonn_profile_enable(egonn_ctx* c, int mode, const char* filter) {
+  EGONN_REQUIRE(c && mode >= 0 && mode <= 2, EGONN_ERR_INVALID, "profile_enable: bad argument");
+  c->prof.mode = mode;
+  snprintf(c->prof.filter, sizeof(c->prof.filter), "%s", filter ? filter : "");
+  return EGONN_OK;
+}
+
+// Drains the timing records collected since the last fetch.  [SYNC]  Returns up to `cap` records:
+// names (cap x 64 chars), milliseconds, algorithmic bytes (P*Cin*4 + N_out*Cout*4 + K*Cin*Cout*4 + 8*P) and flops
+// (2*P*Cin*Cout) of every launch; *n = number of records written.
+API int egonn_profile_fetch(egonn_ctx* c, int cap, int* n, char* names, float* ms, double* bytes, double* flops,
+                            void* stream) {
+  EGONN_REQUIRE(c && n && names && ms && bytes && flops, EGONN_ERR_INVALID, "profile_fetch: null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  unsigned long long pairs[16];
+  HIP_CHECK(hipMemcpy(pairs, c->dev_pairs, sizeof(pairs), hipMemcpyDeviceToHost));
+  int w = 0;
+  for (auto& r : c->prof.recs) {
+    float t = 0.f;
+    HIP_CHECK(hipEventSynchronize(r.e1));
+    HIP_CHECK(hipEventElapsedTime(&t, r.e0, r.e1));
+    if (w < cap) {
+      double Pn = 0;
+      switch (r.kind) {
+        case PK_CONV0: Pn = (double)pairs[0]; break;
+        case PK_K3: Pn = (double)pairs[r.level]; break;
+        case PK_K2S2: Pn = (double)r.n_in; break;
+        case PK_TCONV: Pn = (double)r.n_out; break;
+        default: Pn = (double)r.n_in; break;
+      }
+      snprintf(names + (size_t)w * 64, 64, "%s", r.name);
+      ms[w] = t;
+      bytes[w] = Pn * r.cin * 4.0 + (double)r.n_out * r.cout * 4.0 + (double)r.K * r.cin * r.cout * 4.0 + 8.0 * Pn;
+      flops[w] = 2.0 * Pn * r.cin * r.cout;
+      ++w;
+    }
+    c->prof.pool.push_back(r.e0);
+    c->prof.pool.push_back(r.e1);
+  }
+  c->prof.recs.clear();
+  *n = w;
+  return EGONN_OK;
 }

@@ -108,6 +108,15 @@ int egonn_select_keypoints(egonn_ctx* ctx, const float* sigma, const float* keyp
                            int n_k, float* sel_keypoints, float* sel_descriptors, int32_t* sel_rows,
                            int32_t* sel_count, void* stream);
 
+/* ------------------------------------------------------------------ launch timing (bench.py roofline leg)
+ * mode 0: off; 1: time every tagged sparse-conv launch; 2: only launches whose tag contains `filter`.
+ * Timing = HIP events recorded on the caller's stream around the launch. */
+int egonn_profile_enable(egonn_ctx* ctx, int mode, const char* filter);
+/* Drain the records collected since the last fetch.  [SYNC]  names: cap x 64 chars.  bytes = the algorithmic
+ * bytes of SURVEY.md §8(d) (P*Cin*4 + N_out*Cout*4 + K*Cin*Cout*4 + 8*P), flops = 2*P*Cin*Cout. */
+int egonn_profile_fetch(egonn_ctx* ctx, int cap, int* n, char* names, float* ms, double* bytes, double* flops,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif
