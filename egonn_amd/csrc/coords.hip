@@ -360,30 +360,6 @@ __device__ static inline uint32_t bit_of_local(uint32_t lx, uint32_t ly, uint32_
   return (lx & 1) | ((ly & 1) << 1) | ((lz & 1) << 2) | ((lx & 2) << 2) | ((ly & 2) << 3) | ((lz & 2) << 4);
 }
 
-template <int KS>   // 3 or 5
-__device__ static inline void neighbour_blocks(const uint64_t* __restrict__ bkeys, const uint64_t* __restrict__ bmask,
-                                               const int32_t* __restrict__ bstart, int32_t nblocks, int32_t j,
-                                               int cbL, int lane, uint64_t* nbm, int32_t* nbs) {
-  if (lane < 27) {
-    const uint64_t key = bkeys[j];
-    const uint64_t mmask = (1ull << (3 * cbL)) - 1;
-    const uint64_t mort = key & mmask;
-    const uint64_t bat = key >> (3 * cbL);
-    const int32_t bx = (int32_t)compact1by2(mort), by = (int32_t)compact1by2(mort >> 1),
-                  bz = (int32_t)compact1by2(mort >> 2);
-    const int32_t nx = bx + (lane % 3) - 1, ny = by + (lane / 3) % 3 - 1, nz = bz + lane / 9 - 1;
-    const int32_t lim = 1 << cbL;
-    int32_t idx = -1;
-    if (lane == 13) {
-      idx = j;
-    } else if (nx >= 0 && nx < lim && ny >= 0 && ny < lim && nz >= 0 && nz < lim) {
-      idx = find_key(bkeys, nblocks, (bat << (3 * cbL)) | morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
-    }
-    nbm[lane] = idx >= 0 ? bmask[idx] : 0ull;
-    nbs[lane] = idx >= 0 ? bstart[idx] : 0;
-  }
-}
-
 __device__ static inline int32_t lookup_local(const uint64_t* nbm, const int32_t* nbs, int32_t nx, int32_t ny,
                                               int32_t nz) {
   // nx,ny,nz in [-2, 5]: local coordinates relative to the centre block
@@ -397,18 +373,45 @@ __device__ static inline int32_t lookup_local(const uint64_t* nbm, const int32_t
   return nbs[slot] + __popcll(m & ((1ull << bit) - 1));
 }
 
+// Row adjacency by direct search: adj[i][s] = row of the same-level voxel at offset s (27 slots, x fastest), -1 =
+// absent.  Used for the two top (virtual) levels only, where N is tiny; every level below derives its table
+// from the table two levels up (nbr27_kernel), so no level with many rows ever binary-searches.
+__global__ void adj27_search_kernel(const uint64_t* __restrict__ keys, int32_t n, int cbL, int32_t* __restrict__ adj) {
+  const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 27) return;
+  const int32_t i = t / 27, sl = t - i * 27;
+  const uint64_t key = keys[i];
+  const uint64_t mort = key & ((1ull << (3 * cbL)) - 1);
+  const uint64_t bat = key >> (3 * cbL);
+  const int32_t nx = (int32_t)compact1by2(mort) + (sl % 3) - 1, ny = (int32_t)compact1by2(mort >> 1) + (sl / 3) % 3 - 1,
+                nz = (int32_t)compact1by2(mort >> 2) + sl / 9 - 1;
+  const int32_t lim = 1 << cbL;
+  int32_t r = -1;
+  if (sl == 13) r = i;
+  else if (nx >= 0 && nx < lim && ny >= 0 && ny < lim && nz >= 0 && nz < lim)
+    r = find_key(keys, n, (bat << (3 * cbL)) | morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+  adj[t] = r;
+}
+
+// k=3 neighbour table of level l from the adjacency of its 4x4x4 blocks (= the k=3 table of level l+2).
+// One wave per block: 27 lanes fetch (mask, first row) of the adjacent blocks into LDS, then every
+// (voxel, offset) pair is an LDS mask test + popcount.
 __global__ __launch_bounds__(256) void nbr27_kernel(const uint64_t* __restrict__ vkeys,      // level l
-                                                     const uint64_t* __restrict__ bkeys,      // level l+2
+                                                     const int32_t* __restrict__ badj,        // [nblocks][27] level l+2
                                                      const uint64_t* __restrict__ bmask,
                                                      const int32_t* __restrict__ bstart, int32_t nblocks,
-                                                     int32_t nvox, int cbL, int32_t* __restrict__ nbr,
+                                                     int32_t nvox, int32_t* __restrict__ nbr,
                                                      unsigned long long* __restrict__ pair_counter) {
   __shared__ uint64_t s_m[4][27];
   __shared__ int32_t s_s[4][27];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int32_t j = blockIdx.x * 4 + wave;
   if (j >= nblocks) return;
-  neighbour_blocks<3>(bkeys, bmask, bstart, nblocks, j, cbL, lane, s_m[wave], s_s[wave]);
+  if (lane < 27) {
+    const int32_t idx = badj[(int64_t)j * 27 + lane];
+    s_m[wave][lane] = idx >= 0 ? bmask[idx] : 0ull;
+    s_s[wave][lane] = idx >= 0 ? bstart[idx] : 0;
+  }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   const int32_t s = bstart[j];
@@ -505,10 +508,9 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
     P.lv[l].cstart = po.cstart[l] = A.alloc<int32_t>(n + 1);
     EGONN_REQUIRE(po.keys[l] && po.parent[l] && po.cstart[l], EGONN_ERR_STATE, "plan arena too small");
   }
-  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) {
-    P.lv[l].boff = po.boff[l] = A.alloc<int32_t>(B + 1);
-    EGONN_REQUIRE(po.boff[l], EGONN_ERR_STATE, "plan arena too small");
-  }
+  int32_t* boff_all = A.alloc<int32_t>((size_t)EGONN_NUM_LEVELS * (B + 1));   // contiguous: one D2H copy
+  EGONN_REQUIRE(boff_all, EGONN_ERR_STATE, "plan arena too small");
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) P.lv[l].boff = po.boff[l] = boff_all + (size_t)l * (B + 1);
   P.perm0 = po.perm0 = A.alloc<int32_t>(n);
   po.counts = ctx->dev_counts;
   EGONN_REQUIRE(tilecnt && po.perm0, EGONN_ERR_STATE, "plan arena too small");
@@ -519,12 +521,9 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
   HIP_CHECK(hipGetLastError());
 
   // ---- the size query (single host sync of the plan): counts, range flag, per-sample offsets
-  HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ctx->dev_counts, sizeof(int32_t) * (NL + 1), hipMemcpyDeviceToHost,
-                           stream));
-  HIP_CHECK(hipMemcpyAsync(ctx->host_counts + 16, ctx->dev_flags, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  for (int l = 0; l < EGONN_NUM_LEVELS; ++l)
-    HIP_CHECK(hipMemcpyAsync(ctx->host_counts + 32 + (size_t)l * (EGONN_MAX_BATCH + 1), P.lv[l].boff,
-                             sizeof(int32_t) * (B + 1), hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ctx->dev_counts, sizeof(int32_t) * 17, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipMemcpyAsync(ctx->host_counts + 32, boff_all, sizeof(int32_t) * EGONN_NUM_LEVELS * (B + 1),
+                           hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
   EGONN_REQUIRE(ctx->host_counts[16] == 0, EGONN_ERR_RANGE,
                 "coordinate outside the +-2^%d voxel range of coord_bits=%d (or non-finite point / batch index "
@@ -533,7 +532,7 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
                 ctx->host_counts[NL] - 1, B);
   for (int l = 0; l < NL; ++l) P.lv[l].n = ctx->host_counts[l];
   for (int l = 0; l < EGONN_NUM_LEVELS; ++l) {
-    const int32_t* src = ctx->host_counts + 32 + (size_t)l * (EGONN_MAX_BATCH + 1);
+    const int32_t* src = ctx->host_counts + 32 + (size_t)l * (B + 1);
     P.boff_host[l].assign(src, src + B + 1);
   }
   P.batch = B;
@@ -561,18 +560,30 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
   ma.prefix[NL] = pre;
   if (pre > 0) hipLaunchKernelGGL(block_mask_kernel, dim3((unsigned)cdiv(pre, 256)), dim3(256), 0, stream, ma);
 
-  // ---- kernel maps
-  for (int l = 1; l < EGONN_NUM_LEVELS; ++l) {
+  // ---- kernel maps, top-down: the two virtual levels by search (tiny), every other level from the k=3
+  //      table of the level two above (which is the adjacency of its 4x4x4 blocks)
+  for (int l = NL - 1; l >= 1; --l) {
     Level& V = P.lv[l];
     const int32_t nv = (int32_t)V.n;
     V.nbr27 = A.alloc<int32_t>((size_t)nv * 27);
+    EGONN_REQUIRE(V.nbr27, EGONN_ERR_STATE, "plan arena too small");
+    if (nv == 0) continue;
+    if (l + 2 >= NL) {
+      hipLaunchKernelGGL(adj27_search_kernel, dim3((unsigned)cdiv((int64_t)nv * 27, 256)), dim3(256), 0, stream, V.keys,
+                         nv, cb - l, V.nbr27);
+    } else {
+      const Level& Bk = P.lv[l + 2];
+      hipLaunchKernelGGL(nbr27_kernel, dim3((unsigned)cdiv(Bk.n, 4)), dim3(256), 0, stream, V.keys, Bk.nbr27, Bk.mask,
+                         Bk.bstart, (int32_t)Bk.n, nv, V.nbr27, ctx->dev_pairs + l);
+    }
+  }
+  for (int l = 1; l < EGONN_NUM_LEVELS; ++l) {
+    Level& V = P.lv[l];
+    const int32_t nv = (int32_t)V.n;
     V.nbr8 = A.alloc<int32_t>((size_t)nv * 8);
     V.nbrT = A.alloc<int32_t>((size_t)nv * 8);
-    EGONN_REQUIRE(V.nbr27 && V.nbr8 && V.nbrT, EGONN_ERR_STATE, "plan arena too small");
+    EGONN_REQUIRE(V.nbr8 && V.nbrT, EGONN_ERR_STATE, "plan arena too small");
     if (nv == 0) continue;
-    const Level& Bk = P.lv[l + 2];
-    hipLaunchKernelGGL(nbr27_kernel, dim3((unsigned)cdiv(Bk.n, 4)), dim3(256), 0, stream, V.keys, Bk.keys, Bk.mask,
-                       Bk.bstart, (int32_t)Bk.n, nv, cb - (l + 2), V.nbr27, ctx->dev_pairs + l);
     hipLaunchKernelGGL(nbr8_kernel, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, stream, V.cstart, P.lv[l - 1].keys,
                        nv, V.nbr8);
     hipLaunchKernelGGL(nbrT_kernel, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, stream, V.parent, V.keys, nv,
@@ -585,7 +596,7 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
 
 static size_t plan_arena_bytes(int64_t n, int B) {
   // raw+sorted keys/vals, 10 levels x (keys, parent, cstart, mask, bstart), perm, maps of levels 1..7 (<= n rows each)
-  size_t per_row = 2 * (8 + 4) + NL * (8 + 4 + 4 + 8 + 4) + 4 + 7 * (27 + 8 + 8) * 4;
+  size_t per_row = 2 * (8 + 4) + NL * (8 + 4 + 4 + 8 + 4) + 4 + 9 * 27 * 4 + 7 * (8 + 8) * 4;
   return (size_t)(n + 8) * per_row + (size_t)(B + 1) * 4 * EGONN_NUM_LEVELS + (size_t)cdiv(n, PYR_TILE) * NL * 4 +
          (1 << 20);
 }

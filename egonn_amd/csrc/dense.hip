@@ -23,59 +23,80 @@ __device__ static inline float apply_act(float v, int act) {
 }
 
 // ------------------------------------------------------------------ dense GEMM + epilogue
-// One wave = 16 rows x all output columns (16 at a time), v_mfma_f32_16x16x4_f32.  The contraction index
-// inside a 16-wide k-block is permuted (lane group g owns ci = 16t + 4g .. 4g+3) so that A comes in as
-// one float4 per lane per k-block; B uses the same permutation.
-template <int W_OUT_IN>
-__global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ in, int64_t n, int cin,
+// Workgroup = 64 rows x 64 output columns (grid.y walks the column groups), wave = 16 rows x 64 columns as two
+// passes of two 16-wide v_mfma_f32_16x16x4_f32 column tiles.  The wave's A fragment (16 rows x CIN) is loaded
+// once into registers; all B loads of a pass are issued before its MFMA chains (CIN is a template parameter so
+// the loops unroll and the loads batch).  The contraction index inside a 16-wide k-block is permuted (lane
+// group g owns ci = 16t + 4g .. 4g+3) so that A and (out,in)-layout B come in as one float4 per lane.
+template <int W_OUT_IN, int CIN>
+__global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ in, int64_t n,
                                                     const float* __restrict__ W, int cout,
                                                     const float* __restrict__ bias, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, int act,
                                                     const float* __restrict__ residual, float* __restrict__ out) {
+  constexpr int KS = CIN / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g4 = lane >> 4;
   const int64_t row_base = ((int64_t)blockIdx.x * 4 + wave) * 16;
   if (row_base >= n) return;
   const int64_t row = row_base + l15;
-  const bool vrow = row < n;
-  const float* arow = in + row * cin + 4 * g4;
-  const int ksteps = cin >> 4;
-  for (int n0 = 0; n0 < cout; n0 += 16) {
-    const int col = n0 + l15;
-    const bool vcol = col < cout;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < ksteps; ++t) {
-      float4 a4 = make_float4(0, 0, 0, 0);
-      if (vrow) a4 = *reinterpret_cast<const float4*>(arow + 16 * t);
-      float4 b4 = make_float4(0, 0, 0, 0);
-      if (vcol) {
-        if (W_OUT_IN) {
-          b4 = *reinterpret_cast<const float4*>(W + (int64_t)col * cin + 16 * t + 4 * g4);
-        } else {
-          const float* wp = W + (int64_t)(16 * t + 4 * g4) * cout + col;
-          b4.x = wp[0];
-          b4.y = wp[cout];
-          b4.z = wp[2 * (int64_t)cout];
-          b4.w = wp[3 * (int64_t)cout];
-        }
-      }
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
-    }
-    if (vcol) {
-      const float bi = bias ? bias[col] : 0.f;
-      const float sc = scale ? scale[col] : 1.f, sh = scale ? shift[col] : 0.f;
+  float4 a[KS];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t orow = row_base + 4 * g4 + r;
-        if (orow < n) {
-          float v = acc[r] + bi;
-          if (scale) v = v * sc + sh;
-          v = apply_act(v, act);
-          if (residual) v += residual[orow * cout + col];
-          out[orow * cout + col] = v;
+  for (int t = 0; t < KS; ++t)
+    a[t] = (row < n) ? *reinterpret_cast<const float4*>(in + row * CIN + 16 * t + 4 * g4) : make_float4(0, 0, 0, 0);
+  const int ncol0 = blockIdx.y * 64;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int n0 = ncol0 + pass * 32;
+    if (n0 >= cout) break;
+    float4 b[2][KS];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = n0 + nt * 16 + l15;
+#pragma unroll
+      for (int t = 0; t < KS; ++t) {
+        float4 v = make_float4(0, 0, 0, 0);
+        if (col < cout) {
+          if (W_OUT_IN) {
+            v = *reinterpret_cast<const float4*>(W + (int64_t)col * CIN + 16 * t + 4 * g4);
+          } else {
+            const float* wp = W + (int64_t)(16 * t + 4 * g4) * cout + col;
+            v.x = wp[0];
+            v.y = wp[cout];
+            v.z = wp[2 * (int64_t)cout];
+            v.w = wp[3 * (int64_t)cout];
+          }
+        }
+        b[nt][t] = v;
+      }
+    }
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b[nt][t].x, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, b[nt][t].y, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, b[nt][t].z, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b[nt][t].w, acc[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = n0 + nt * 16 + l15;
+      if (col < cout) {
+        const float bi = bias ? bias[col] : 0.f;
+        const float sc = scale ? scale[col] : 1.f, sh = scale ? shift[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t orow = row_base + 4 * g4 + r;
+          if (orow < n) {
+            float v = acc[nt][r] + bi;
+            if (scale) v = v * sc + sh;
+            v = apply_act(v, act);
+            if (residual) v += residual[orow * cout + col];
+            out[orow * cout + col] = v;
+          }
         }
       }
     }
@@ -86,16 +107,27 @@ int dense_forward(const float* in, int64_t n, int cin, const float* W, int w_out
                   const float* scale, const float* shift, int act, const float* residual, float* out,
                   hipStream_t stream) {
   if (n == 0) return EGONN_OK;
-  EGONN_REQUIRE(cin % 16 == 0 && cin >= 16, EGONN_ERR_INVALID, "dense: cin=%d must be a multiple of 16", cin);
-  const dim3 grid((unsigned)cdiv(n, 64));
-  if (w_out_in)
-    hipLaunchKernelGGL(dense_kernel<1>, grid, dim3(256), 0, stream, in, n, cin, W, cout, bias, scale, shift, act,
-                       residual, out);
-  else
-    hipLaunchKernelGGL(dense_kernel<0>, grid, dim3(256), 0, stream, in, n, cin, W, cout, bias, scale, shift, act,
-                       residual, out);
-  HIP_CHECK(hipGetLastError());
-  return EGONN_OK;
+  const dim3 grid((unsigned)cdiv(n, 64), (unsigned)cdiv(cout, 64));
+#define EGONN_DENSE_CASE(CI)                                                                                       \
+  if (cin == CI) {                                                                                                 \
+    if (w_out_in)                                                                                                  \
+      hipLaunchKernelGGL((dense_kernel<1, CI>), grid, dim3(256), 0, stream, in, n, W, cout, bias, scale, shift, act, \
+                         residual, out);                                                                           \
+    else                                                                                                           \
+      hipLaunchKernelGGL((dense_kernel<0, CI>), grid, dim3(256), 0, stream, in, n, W, cout, bias, scale, shift, act, \
+                         residual, out);                                                                           \
+    HIP_CHECK(hipGetLastError());                                                                                  \
+    return EGONN_OK;                                                                                               \
+  }
+  EGONN_DENSE_CASE(32)
+  EGONN_DENSE_CASE(64)
+  EGONN_DENSE_CASE(96)
+  EGONN_DENSE_CASE(128)
+  EGONN_DENSE_CASE(192)
+  EGONN_DENSE_CASE(256)
+#undef EGONN_DENSE_CASE
+  set_error("dense: cin=%d not supported (32, 64, 96, 128, 192, 256)", cin);
+  return EGONN_ERR_INVALID;
 }
 
 // ------------------------------------------------------------------ BatchNorm folding (eval mode)

@@ -8,8 +8,11 @@ const char* last_error();
 
 // conv.hip -------------------------------------------------------------------------------------
 // out[o] = act( (sum_k in[nbr[o][k]] @ W[k]) * scale + shift ), nbr: [n_out][K] rows or -1, W: [K][cin][cout]
+// scratch (nullable): scratch_floats floats for the split-over-offsets path used on small levels
 int sconv_forward(const float* in, const int32_t* nbr, const float* W, const float* scale, const float* shift,
-                  int relu, float* out, int32_t n_out, int K, int cin, int cout, hipStream_t stream);
+                  int relu, float* out, int32_t n_out, int K, int cin, int cout, float* scratch,
+                  size_t scratch_floats, hipStream_t stream);
+static constexpr size_t SCONV_SCRATCH_FLOATS = (size_t)8 << 20;   // 32 MB: >= 512 tiles x 64 rows x 128 ch
 void sconv_set_naive(bool on);
 int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, const float* scale,
                      const float* shift, int relu, float* out, hipStream_t stream);

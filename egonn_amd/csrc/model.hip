@@ -92,12 +92,13 @@ API int egonn_ctx_create(egonn_ctx** out, int device, int coord_bits) {
   const size_t hc = sizeof(int32_t) * (32 + (size_t)EGONN_NUM_LEVELS * (EGONN_MAX_BATCH + 1));
   if (hipHostMalloc(reinterpret_cast<void**>(&c->host_counts), hc) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&c->dev_counts), sizeof(int32_t) * 32) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&c->dev_flags), sizeof(int32_t) * 4) != hipSuccess ||
+      false ||
       hipMalloc(reinterpret_cast<void**>(&c->dev_pairs), sizeof(unsigned long long) * 16) != hipSuccess) {
     set_error("ctx_create: allocation failed");
     delete c;
     return EGONN_ERR_HIP;
   }
+  c->dev_flags = c->dev_counts + 16;   // counts[0..10], flags at [16]: fetched by one copy
   *out = c;
   return EGONN_OK;
 }
@@ -111,7 +112,6 @@ API void egonn_ctx_destroy(egonn_ctx* c) {
   c->sort_arena.release();
   if (c->host_counts) (void)hipHostFree(c->host_counts);
   if (c->dev_counts) (void)hipFree(c->dev_counts);
-  if (c->dev_flags) (void)hipFree(c->dev_flags);
   if (c->dev_pairs) (void)hipFree(c->dev_pairs);
   for (auto& r : c->prof.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : c->prof.pool) (void)hipEventDestroy(e);
@@ -189,6 +189,14 @@ API int egonn_input_index(egonn_ctx* c, int64_t* out, void* stream) {
 }
 
 // ------------------------------------------------------------------------------------------ operators
+// scratch for the stand-alone operator entry points (the forward carves its own from the work arena)
+static float* op_scratch(egonn_ctx* c) {
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
+  if (c->work_arena.ensure(SCONV_SCRATCH_FLOATS * sizeof(float) + 4096) != EGONN_OK) return nullptr;
+  c->work_arena.reset();
+  return c->work_arena.alloc<float>(SCONV_SCRATCH_FLOATS);
+}
+
 API int egonn_conv(egonn_ctx* c, int level_in, int level_out, int ks, const float* in, int cin, const float* kernel,
                    int cout, const float* scale, const float* shift, int relu, float* out, void* stream) {
   REQUIRE_PLAN(c);
@@ -211,12 +219,12 @@ API int egonn_conv(egonn_ctx* c, int level_in, int level_out, int ks, const floa
     EGONN_REQUIRE(level_in == level_out && level_in >= 1, EGONN_ERR_INVALID,
                   "k=3 convolution is implemented for levels 1..7 (same in/out level)");
     return sconv_forward(in, P.lv[level_in].nbr27, kernel, scale, shift, relu, out, (int32_t)P.lv[level_in].n, 27, cin,
-                         cout, st);
+                         cout, op_scratch(c), SCONV_SCRATCH_FLOATS, st);
   }
   if (ks == 2) {
     EGONN_REQUIRE(level_out == level_in + 1, EGONN_ERR_INVALID, "k=2,s=2 convolution maps level l to l+1");
     return sconv_forward(in, P.lv[level_out].nbr8, kernel, scale, shift, relu, out, (int32_t)P.lv[level_out].n, 8, cin,
-                         cout, st);
+                         cout, op_scratch(c), SCONV_SCRATCH_FLOATS, st);
   }
   set_error("conv: kernel_size %d not supported (1, 2, 3, 5)", ks);
   return EGONN_ERR_INVALID;
@@ -229,7 +237,8 @@ API int egonn_conv_transpose(egonn_ctx* c, int level_in, const float* in, int ci
   EGONN_REQUIRE(level_in >= 2 && level_in < EGONN_NUM_LEVELS, EGONN_ERR_INVALID,
                 "transposed conv: input level %d out of range [2,7]", level_in);
   const Level& L = c->plan.lv[level_in - 1];
-  return sconv_forward(in, L.nbrT, kernel, nullptr, nullptr, 0, out, (int32_t)L.n, 8, cin, cout, (hipStream_t)stream);
+  return sconv_forward(in, L.nbrT, kernel, nullptr, nullptr, 0, out, (int32_t)L.n, 8, cin, cout, op_scratch(c),
+                       SCONV_SCRATCH_FLOATS, (hipStream_t)stream);
 }
 
 __global__ void avg_finish_kernel(const float* __restrict__ partial, const int32_t* __restrict__ boff, int c,
@@ -424,7 +433,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   size_t need = (size_t)P.lv[0].n * (1 + 32) * 4;
   for (int i = 1; i <= 7; ++i) need += (size_t)P.lv[i].n * 128 * 4 * 6;
   need += (size_t)P.lv[5].n * (192 + 256 + 128 * 2) * 4 + (size_t)P.lv[3].n * (96 + 32 + 32 + 3 + 64 * 2) * 4;
-  need += (size_t)B * SEG_CHUNKS * 256 * 4 * 10 + (size_t)P.lv[3].n * 32 + (4u << 20);
+  need += (size_t)B * SEG_CHUNKS * 256 * 4 * 10 + (size_t)P.lv[3].n * 32 + (4u << 20) + SCONV_SCRATCH_FLOATS * 4;
   for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
   EGONN_TRY(c->work_arena.ensure(need));
   Arena& A = c->work_arena;
@@ -433,6 +442,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   float* var = A.alloc<float>((size_t)(count));                                    \
   EGONN_REQUIRE(var != nullptr, EGONN_ERR_STATE, "work arena too small (" #var ")")
 
+  WALLOC(scr, SCONV_SCRATCH_FLOATS);
   // ---- trunk (models/minkgl.py:136-153)
   const int64_t n0 = P.lv[0].n;
   const float* f0 = features;          // voxelize plans: features are already in level-0 row order
@@ -459,20 +469,20 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
       snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k2s2", b.cin, b.cin, i);
       ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, P.lv[i - 1].n, n);
       EGONN_TRY(sconv_forward(x[i - 1], L.nbr8, m->convs[i], m->bn[i].scale, m->bn[i].shift, 1, y, (int32_t)n, 8,
-                              b.cin, b.cin, st));
+                              b.cin, b.cin, scr, SCONV_SCRATCH_FLOATS, st));
     }
     // ECABasicBlock (layers/eca_block.py:56-73)
     WALLOC(t1, n * b.cout);
     {
       snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k3.conv1", b.cin, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cin, b.cout, n, n);
-      EGONN_TRY(sconv_forward(y, L.nbr27, b.conv1, b.n1.scale, b.n1.shift, 1, t1, (int32_t)n, 27, b.cin, b.cout, st));
+      EGONN_TRY(sconv_forward(y, L.nbr27, b.conv1, b.n1.scale, b.n1.shift, 1, t1, (int32_t)n, 27, b.cin, b.cout, scr, SCONV_SCRATCH_FLOATS, st));
     }
     WALLOC(t2, n * b.cout);
     {
       snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k3.conv2", b.cout, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cout, b.cout, n, n);
-      EGONN_TRY(sconv_forward(t1, L.nbr27, b.conv2, b.n2.scale, b.n2.shift, 0, t2, (int32_t)n, 27, b.cout, b.cout, st));
+      EGONN_TRY(sconv_forward(t1, L.nbr27, b.conv2, b.n2.scale, b.n2.shift, 0, t2, (int32_t)n, 27, b.cout, b.cout, scr, SCONV_SCRATCH_FLOATS, st));
     }
     WALLOC(partial, (size_t)B * SEG_CHUNKS * b.cout + (size_t)B * b.cout);
     EGONN_TRY(segment_partial_sums(t2, L.boff, B, b.cout, 0, nullptr, partial, st));
@@ -494,11 +504,11 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     WALLOC(g7, P.lv[7].n * GLOBAL_CH);
     EGONN_TRY(dense_forward(x[7], P.lv[7].n, 128, m->g1x1[7], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, g7, st));
     WALLOC(u6, P.lv[6].n * GLOBAL_CH);
-    EGONN_TRY(sconv_forward(g7, P.lv[6].nbrT, m->gt[7], nullptr, nullptr, 0, u6, (int32_t)P.lv[6].n, 8, GLOBAL_CH, GLOBAL_CH, st));
+    EGONN_TRY(sconv_forward(g7, P.lv[6].nbrT, m->gt[7], nullptr, nullptr, 0, u6, (int32_t)P.lv[6].n, 8, GLOBAL_CH, GLOBAL_CH, scr, SCONV_SCRATCH_FLOATS, st));
     WALLOC(g6, P.lv[6].n * GLOBAL_CH);
     EGONN_TRY(dense_forward(x[6], P.lv[6].n, 128, m->g1x1[6], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u6, g6, st));
     WALLOC(u5, P.lv[5].n * GLOBAL_CH);
-    EGONN_TRY(sconv_forward(g6, P.lv[5].nbrT, m->gt[6], nullptr, nullptr, 0, u5, (int32_t)P.lv[5].n, 8, GLOBAL_CH, GLOBAL_CH, st));
+    EGONN_TRY(sconv_forward(g6, P.lv[5].nbrT, m->gt[6], nullptr, nullptr, 0, u5, (int32_t)P.lv[5].n, 8, GLOBAL_CH, GLOBAL_CH, scr, SCONV_SCRATCH_FLOATS, st));
     WALLOC(g5, P.lv[5].n * GLOBAL_CH);
     EGONN_TRY(dense_forward(x[5], P.lv[5].n, 128, m->g1x1[5], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u5, g5, st));
     WALLOC(gh, P.lv[5].n * m->gdec.mid);
@@ -515,7 +525,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     WALLOC(l4, n4 * LOCAL_CH);
     EGONN_TRY(dense_forward(x[4], n4, 128, m->l1x1[4], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, l4, st));
     WALLOC(u3, n3 * LOCAL_CH);
-    EGONN_TRY(sconv_forward(l4, P.lv[3].nbrT, m->lt[4], nullptr, nullptr, 0, u3, (int32_t)n3, 8, LOCAL_CH, LOCAL_CH, st));
+    EGONN_TRY(sconv_forward(l4, P.lv[3].nbrT, m->lt[4], nullptr, nullptr, 0, u3, (int32_t)n3, 8, LOCAL_CH, LOCAL_CH, scr, SCONV_SCRATCH_FLOATS, st));
     WALLOC(l3, n3 * LOCAL_CH);
     EGONN_TRY(dense_forward(x[3], n3, 64, m->l1x1[3], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u3, l3, st));
     WALLOC(dh, n3 * m->ldec.mid);
