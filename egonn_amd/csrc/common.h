@@ -174,5 +174,6 @@ int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets_
                      const float* step, hipStream_t stream);
 int plan_from_coords(Ctx* ctx, const int32_t* coords, int64_t n, int B, hipStream_t stream);
 int plan_level_coords(Ctx* ctx, int level, int32_t* out, hipStream_t stream);
+int count_map_pairs(Ctx* ctx, hipStream_t stream);   // fills dev_pairs[1..7] from the k=3 tables (profiling only)
 
 }  // namespace egonn

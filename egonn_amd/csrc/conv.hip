@@ -5,23 +5,25 @@
 //
 //   out[o] = sum_k  in[ nbr[o][k] ] @ W[k]          (nbr[o][k] = -1: no contribution)
 //
-// sconv_mfma_kernel — output-stationary, pair-compacted gather -> MFMA -> LDS accumulate:
+// sconv_mfma_kernel — output-stationary, pair-compacted, barrier-free gather -> MFMA -> LDS accumulate:
 //   * a workgroup owns T consecutive output rows (Z-order => spatially clustered => the gathered
 //     input rows are L2-local), keeps their fp32 accumulators in LDS and writes each output row once
 //     (no HBM atomics, deterministic);
 //   * for every kernel offset k the tile's valid (row, input) pairs are compacted with
 //     ballot/popcount, so the MFMA M-dimension only carries real pairs: flops = 2*P*Cin*Cout (+ padding
 //     to 16), not 2*27*N*Cin*Cout;
-//   * 16 gathered rows are staged in LDS ([16][Cin+4], b128 reads), W[k] lives in B-fragment registers
-//     of the wave that owns the column slice, v_mfma_f32_16x16x4_f32 accumulates, results are added
-//     into the LDS accumulator rows of the pairs (rows are distinct within a chunk, column slices are
-//     owned by one wave => plain read-modify-write, no atomics);
+//   * the 16 gathered rows of a chunk go straight from global memory into the MFMA A-operand registers
+//     (float4 per lane, prefetched two chunks ahead), W[k] lives in B-fragment registers of the wave that
+//     owns the column slice, v_mfma_f32_16x16x4_f32 accumulates, results are added into the LDS
+//     accumulator rows of the pairs (rows are distinct within a chunk, column slices are owned by one
+//     wave, chunk groups own separate copies => plain read-modify-write, no atomics, no barriers);
 //   * epilogue: folded BatchNorm scale/shift (+ReLU) fused, one coalesced float4 store per element.
 //
 // conv0_k5_kernel — the 5x5x5, Cin=1 first layer: pure lookup work.  One wave per 4x4x4 block, the 27
 // adjacent blocks' occupancy masks sit in LDS, 125 offsets are bit tests + popcounts spread over the
 // lanes, hits are reduced against the 125x32 weight table in LDS.  No kernel map is materialised.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -61,11 +63,8 @@ struct SconvCfg {
   static constexpr int NT = NW / 16;                      // 16-wide MFMA column tiles per wave
   static constexpr int WAVES_N = COUT / NW;               // waves across the columns
   static constexpr int WAVES_M = 4 / WAVES_N;             // chunk groups working concurrently
-  static constexpr int CPS = (128 / CIN) / WAVES_M > 0 ? (128 / CIN) / WAVES_M : 1;   // chunks per group per step
-  static constexpr int STAGE_ROWS = WAVES_M * CPS * 16;   // gathered rows per step
-  static constexpr int LDA = CIN + 4;                     // A-stage row stride (floats, 16-B aligned)
   static constexpr int LDC = COUT + 4;                    // accumulator row stride
-  static constexpr int KSTEPS = CIN / 16;                 // b128 A reads per chunk
+  static constexpr int KSTEPS = CIN / 16;                 // float4 A loads per lane per chunk
   static_assert(COUT % NW == 0 && 4 % WAVES_N == 0, "bad tiling");
 };
 
@@ -73,18 +72,29 @@ template <int CIN, int COUT>
 static size_t sconv_lds_bytes(int K, int T) {
   using C = SconvCfg<CIN, COUT>;
   size_t b = 0;
-  b += (size_t)C::WAVES_M * T * C::LDC * 4;     // accumulators (one copy per chunk group: no cross-wave RMW)
-  b += std::max((size_t)2 * C::STAGE_ROWS * C::LDA * 4,   // A stage (double buffered) ...
-                (size_t)T * K * 4);                       // ... aliased with the raw neighbour-table tile (phase A only)
-  b += (size_t)T * K * 4;                       // pair input rows
-  b += (size_t)T * K;                           // pair output rows (u8)
-  b += (size_t)(K + 1) * 4 * 2;                 // cnt, cbase
-  b += (size_t)(K * (T / 16) + 1) * 2;          // chunk table (k, c)
+  b += (size_t)C::WAVES_M * (T + 1) * C::LDC * 4;         // accumulators (+1 dummy row) per chunk group
+  b += (size_t)T * K * 4;                                 // raw neighbour-table tile
+  b += (size_t)T * K * 4;                                 // pair input rows, per offset (k-major)
+  b += (size_t)T * K;                                     // pair output rows (u8)
+  b += (size_t)(K + 1) * 4 * 2 + 64;                      // cnt, cbase
+  b += (size_t)(K * (T / 16) + 64);                       // chunk -> k
   return align_up(b, 16) + 64;
 }
 
-// grid = (tiles, nsplit).  Split `blockIdx.y` handles kernel offsets k with k % nsplit == blockIdx.y and, when
-// nsplit > 1, writes raw partial sums to out + split * n_out * COUT (the caller reduces them in fixed order).
+// Barrier-free gather -> MFMA -> accumulate.  grid = (tiles, nsplit): split `blockIdx.y` handles the kernel
+// offsets k with k % nsplit == blockIdx.y and, when nsplit > 1, writes raw partial sums to
+// out + split * n_out * COUT (sconv_reduce_kernel adds them in fixed order and applies the epilogue).
+//   phase A (once per tile): the [T][K] slice of the neighbour table is staged in LDS (coalesced) and compacted
+//     per offset with ballot/popcount into (input row, output row) lists padded to multiples of 16 pairs;
+//   main loop (no workgroup barrier): chunks of 16 pairs are dealt round-robin to the WAVES_M wave groups; the
+//     A fragment of a chunk is loaded straight from global memory into the MFMA operand registers of the lanes
+//     that need it (lane (i = l & 15, g = l >> 4) loads the float4s of row pj[i] at columns 16t + 4g), two
+//     chunks ahead through a register ring; W[k] fragments are reloaded when the offset changes; the 16x16
+//     results are added into the group's LDS accumulator rows (rows are distinct inside a chunk, column slices
+//     belong to one wave, every group has its own copy => plain read-modify-write, race-free, fixed order);
+//   epilogue: group copies are summed, folded BatchNorm (+ReLU) applied, one coalesced float4 store per element.
+// History (profiles/r01*): an LDS-staged variant with a barrier per step spent its time serialised (ablation:
+// gather / W / accumulate / barrier / MFMA each 10-17 %); ds_add_f32 LDS atomics were 3.3x slower than the RMW.
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict__ in,
                                                           const int32_t* __restrict__ nbr,
@@ -93,25 +103,24 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
                                                           const float* __restrict__ shift, int relu,
                                                           float* __restrict__ out, int32_t n_out, int K, int T) {
   using C = SconvCfg<CIN, COUT>;
+  constexpr int DDEPTH = 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* accL = reinterpret_cast<float*>(smem);                               // [WAVES_M][T][LDC]
-  float* As = accL + (size_t)C::WAVES_M * T * C::LDC;                         // [2][STAGE_ROWS][LDA]
-  int32_t* tbl = reinterpret_cast<int32_t*>(As);                              // [T][K], dead before As is written
-  const size_t stage_words = max((size_t)2 * C::STAGE_ROWS * C::LDA, (size_t)T * K);
-  int32_t* pj = reinterpret_cast<int32_t*>(As) + stage_words;                 // [K][T]
-  int32_t* cnt = pj + (size_t)K * T;                                          // [K+1]
-  int32_t* cbase = cnt + (K + 1);                                             // [K+1]
-  uint8_t* pr = reinterpret_cast<uint8_t*>(cbase + (K + 1));                  // [K][T]
-  uint8_t* ck = pr + (size_t)K * T;                                           // chunk -> k
-  uint8_t* cc = ck + (size_t)K * (T / 16);                                    // chunk -> index inside k
+  float* accL = reinterpret_cast<float*>(smem);                               // [WAVES_M][T+1][LDC]
+  int32_t* tbl = reinterpret_cast<int32_t*>(accL + (size_t)C::WAVES_M * (T + 1) * C::LDC);   // [T][K]
+  int32_t* pj = tbl + (size_t)T * K;                                          // [K][T] input row or -1
+  int32_t* cnt = pj + (size_t)T * K;                                          // [K+1]
+  int32_t* cbase = cnt + (K + 1);                                             // [K+1] first chunk of offset k
+  uint8_t* pr = reinterpret_cast<uint8_t*>(cbase + (K + 1) + 8);              // [K][T] output row (T = dummy)
+  uint8_t* ck = pr + (size_t)T * K;                                           // chunk -> k
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t row0 = blockIdx.x * T;
   const int32_t rows = min(T, n_out - row0);
   const int nsplit = gridDim.y, split = blockIdx.y;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
   // ---- zero accumulators, stage the tile of the neighbour table (coalesced)
-  for (int i = tid; i < C::WAVES_M * T * C::LDC / 4; i += 256)
+  for (int i = tid; i < C::WAVES_M * (T + 1) * C::LDC / 4; i += 256)
     reinterpret_cast<float4*>(accL)[i] = make_float4(0, 0, 0, 0);
   {
     const int32_t* src = nbr + (int64_t)row0 * K;
@@ -120,147 +129,132 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
   }
   __syncthreads();
 
-  // ---- phase A: compact the tile's (row, input) pairs per offset with ballot/popcount
-  {
-    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int k = wave; k < K; k += 4) {
-      int32_t running = 0;
-      if (k % nsplit == split) {
-        for (int base = 0; base < T; base += 64) {
-          const int r = base + lane;
-          const int32_t j = (r < rows) ? tbl[r * K + k] : -1;
-          const uint64_t m = __ballot(j >= 0);
-          if (j >= 0) {
-            const int pos = running + __popcll(m & lt);
-            pj[k * T + pos] = j;
-            pr[k * T + pos] = (uint8_t)r;
-          }
-          running += __popcll(m);
+  // ---- phase A: per-offset compaction of the tile's (input row, output row) pairs, padded to 16
+  for (int k = wave; k < K; k += 4) {
+    int32_t running = 0;
+    if (k % nsplit == split) {
+      for (int base = 0; base < T; base += 64) {
+        const int r = base + lane;
+        const int32_t j = (r < rows) ? tbl[r * K + k] : -1;
+        const uint64_t m = __ballot(j >= 0);
+        if (j >= 0) {
+          const int pos = k * T + running + __popcll(m & lt);
+          pj[pos] = j;
+          pr[pos] = (uint8_t)r;
         }
+        running += __popcll(m);
       }
-      if (lane == 0) cnt[k] = running;
+      const int padded = ((running + 15) >> 4) << 4;          // <= T because T is a multiple of 16
+      if (lane < padded - running) {
+        pj[k * T + running + lane] = -1;
+        pr[k * T + running + lane] = (uint8_t)T;
+      }
     }
+    if (lane == 0) cnt[k] = running;
   }
   __syncthreads();
-  if (tid == 0) {
-    int32_t q = 0;
-    for (int k = 0; k < K; ++k) {
-      cbase[k] = q;
-      const int nc = (cnt[k] + 15) >> 4;
-      for (int c = 0; c < nc; ++c) {
-        ck[q] = (uint8_t)k;
-        cc[q] = (uint8_t)c;
-        ++q;
-      }
+  if (tid < 64) {                      // chunk table by one wave: prefix over the <= 27 offsets with shuffles
+    const int nc = (tid < K) ? ((cnt[tid] + 15) >> 4) : 0;
+    int incl = nc;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
     }
-    cbase[K] = q;
+    const int first = incl - nc;
+    if (tid < K) {
+      cbase[tid] = first;
+      for (int c = 0; c < nc; ++c) ck[first + c] = (uint8_t)tid;
+    }
+    if (tid == K - 1) cbase[K] = incl;
   }
   __syncthreads();
   const int total_chunks = cbase[K];
-  constexpr int CHUNKS_PER_STEP = C::WAVES_M * C::CPS;
-  const int steps = (total_chunks + CHUNKS_PER_STEP - 1) / CHUNKS_PER_STEP;
 
-  const int grp = wave / C::WAVES_N;          // chunk group of this wave
+  const int grp = wave / C::WAVES_N;          // chunk group of this wave (chunks are dealt round-robin to groups)
   const int nsl = wave % C::WAVES_N;          // column slice of this wave
   const int n0 = nsl * C::NW;
   const int l15 = lane & 15, g4 = lane >> 4;
+  const int my_chunks = (total_chunks - grp + C::WAVES_M - 1) / C::WAVES_M;   // chunks q = i*WAVES_M + grp
+  float* myacc = accL + (size_t)grp * (T + 1) * C::LDC + n0 + l15;
 
-  // gather assignment: thread -> (row of the step's A stage, float4 column)
-  constexpr int F4_PER_ROW = CIN / 4;
-  constexpr int GATHER_ITERS = (C::STAGE_ROWS * F4_PER_ROW + 255) / 256;
-
-  float4 greg[GATHER_ITERS];
-  auto gather_issue = [&](int step) {
-#pragma unroll
-    for (int it = 0; it < GATHER_ITERS; ++it) {
-      const int e = it * 256 + tid;
-      const int srow = e / F4_PER_ROW, c4 = e - srow * F4_PER_ROW;
-      float4 v = make_float4(0, 0, 0, 0);
-      if (srow < C::STAGE_ROWS) {
-        const int q = step * CHUNKS_PER_STEP + (srow >> 4);     // stage row block b <-> chunk q = step*CPS_total + b
-        if (q < total_chunks) {
-          const int k = ck[q], c = cc[q];
-          const int p = c * 16 + (srow & 15);
-          if (p < cnt[k]) {
-            const int32_t j = pj[k * T + p];
-            v = reinterpret_cast<const float4*>(in + (int64_t)j * CIN)[c4];
-          }
-        }
-      }
-      greg[it] = v;
-    }
+  // pair-list position of chunk q: offset k = ck[q], chunk c = q - cbase[k] inside it
+  auto chunk_base = [&](int q) {
+    const int k = ck[q];
+    return k * T + (q - cbase[k]) * 16;
   };
-  auto gather_commit = [&](int buf) {
+
+  float4 aring[DDEPTH][C::KSTEPS];
+  auto a_issue = [&](int i, auto RS) {
+    constexpr int rs = decltype(RS)::value;
+    const int q = i * C::WAVES_M + grp;
+    int32_t j = -1;
+    if (q < total_chunks) j = pj[chunk_base(q) + l15];
+    const float* src = in + (int64_t)(j >= 0 ? j : 0) * CIN + 4 * g4;
 #pragma unroll
-    for (int it = 0; it < GATHER_ITERS; ++it) {
-      const int e = it * 256 + tid;
-      const int srow = e / F4_PER_ROW, c4 = e - srow * F4_PER_ROW;
-      if (srow < C::STAGE_ROWS)
-        *reinterpret_cast<float4*>(As + ((size_t)buf * C::STAGE_ROWS + srow) * C::LDA + c4 * 4) = greg[it];
-    }
+    for (int t = 0; t < C::KSTEPS; ++t)
+      aring[rs][t] = (j >= 0) ? *reinterpret_cast<const float4*>(src + 16 * t) : make_float4(0, 0, 0, 0);
   };
 
   float breg[C::NT][CIN / 4];
   int cur_k = -1;
-  float* myacc = accL + (size_t)grp * T * C::LDC;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  a_issue(0, I0{});
+  a_issue(1, I1{});
 
-  if (steps > 0) {
-    gather_issue(0);
-    gather_commit(0);
+  auto body = [&](int i, auto RS) {
+    constexpr int rs = decltype(RS)::value;
+    const int q = i * C::WAVES_M + grp;
+    const int k = ck[q];
+    const int pbase = k * T + (q - cbase[k]) * 16;
+    // W first, A prefetch second: the MFMAs then wait with a counted vmcnt that leaves the prefetch in flight
+    if (k != cur_k) {
+      cur_k = k;
+      const float* wk = W + (size_t)k * CIN * COUT + n0 + l15;
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+        for (int t = 0; t < C::KSTEPS; ++t)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) breg[nt][t * 4 + u] = wk[(size_t)(16 * t + 4 * g4 + u) * COUT + nt * 16];
+    }
+    a_issue(i + 2, std::integral_constant<int, (rs + 2) % DDEPTH>{});
+    const uint32_t orows = *reinterpret_cast<const uint32_t*>(pr + pbase + 4 * g4);   // 4 output rows
+    f32x4 acc[C::NT];
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < C::KSTEPS; ++t) {
+      const float4 a4 = aring[rs][t];
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], breg[nt][t * 4 + u], acc[nt], 0, 0, 0);
+    }
+    float old[4][C::NT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int orow = (orows >> (8 * r)) & 0xFF;
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) old[r][nt] = myacc[orow * C::LDC + nt * 16];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int orow = (orows >> (8 * r)) & 0xFF;
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) myacc[orow * C::LDC + nt * 16] = old[r][nt] + acc[nt][r];
+    }
+  };
+  for (int i = 0; i < my_chunks; i += DDEPTH) {
+    body(i, I0{});
+    if (i + 1 < my_chunks) body(i + 1, I1{});
+    if (i + 2 < my_chunks) body(i + 2, I2{});
   }
   __syncthreads();
-
-  for (int s = 0; s < steps; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < steps) gather_issue(s + 1);
-#pragma unroll
-    for (int ci = 0; ci < C::CPS; ++ci) {
-      const int blk = grp * C::CPS + ci;                 // block of 16 stage rows == chunk inside the step
-      const int q = s * CHUNKS_PER_STEP + blk;
-      if (q < total_chunks) {
-        const int k = ck[q], c = cc[q];
-        if (k != cur_k) {
-          cur_k = k;
-          const float* wk = W + (size_t)k * CIN * COUT;
-#pragma unroll
-          for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-            for (int t = 0; t < C::KSTEPS; ++t)
-#pragma unroll
-              for (int u = 0; u < 4; ++u)
-                breg[nt][t * 4 + u] = wk[(size_t)(16 * t + 4 * g4 + u) * COUT + n0 + nt * 16 + l15];
-        }
-        f32x4 acc[C::NT];
-#pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* arow = As + ((size_t)buf * C::STAGE_ROWS + blk * 16 + l15) * C::LDA + 4 * g4;
-#pragma unroll
-        for (int t = 0; t < C::KSTEPS; ++t) {
-          const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * t);
-          const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int nt = 0; nt < C::NT; ++nt)
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], breg[nt][t * 4 + u], acc[nt], 0, 0, 0);
-        }
-        // accumulate: D[row = 4*g4 + r][col = l15] -> LDS accumulator row of the pair (rows are distinct
-        // inside a chunk, the column slice belongs to this wave, the copy to this group: no conflicts)
-        const int nvalid = cnt[k] - c * 16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int p = 4 * g4 + r;
-          if (p < nvalid) {
-            const int orow = pr[k * T + c * 16 + p];
-#pragma unroll
-            for (int nt = 0; nt < C::NT; ++nt) myacc[orow * C::LDC + n0 + nt * 16 + l15] += acc[nt][r];
-          }
-        }
-      }
-    }
-    if (s + 1 < steps) gather_commit(buf ^ 1);
-    __syncthreads();
-  }
 
   // ---- epilogue: (split: raw partial sums) | BN scale/shift (+ReLU); one coalesced store per element
   constexpr int O4 = COUT / 4;
@@ -270,7 +264,7 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
     float4 v = *reinterpret_cast<const float4*>(accL + r * C::LDC + c4 * 4);
 #pragma unroll
     for (int g = 1; g < C::WAVES_M; ++g) {
-      const float4 w = *reinterpret_cast<const float4*>(accL + ((size_t)g * T + r) * C::LDC + c4 * 4);
+      const float4 w = *reinterpret_cast<const float4*>(accL + ((size_t)g * (T + 1) + r) * C::LDC + c4 * 4);
       v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
     }
     if (nsplit == 1) {
@@ -310,14 +304,17 @@ __global__ void sconv_reduce_kernel(const float* __restrict__ partial, int nspli
   reinterpret_cast<float4*>(out)[e] = v;
 }
 
+static int g_sconv_tile = 0;   // tuning hook: 0 = auto, else forced tile rows (64 / 128)
+void sconv_set_variant(int v) { g_sconv_tile = ((v >> 8) & 3) == 1 ? 64 : ((v >> 8) & 3) == 2 ? 128 : 0; }
+
 template <int CIN, int COUT>
 static int launch_sconv(const float* in, const int32_t* nbr, const float* W, const float* scale, const float* shift,
                         int relu, float* out, int32_t n_out, int K, float* scratch, size_t scratch_floats,
                         hipStream_t stream) {
-  // tile: 128 rows when there is enough work to fill the chip twice over, otherwise 64
-  const int T = (n_out >= 128 * 512) ? 128 : 64;
+  // 64-row tiles: the kernel is latency bound, more resident workgroups beat better chunk fill (tools/bench_sconv.py)
+  const int T = g_sconv_tile ? g_sconv_tile : 64;
   const int tiles = (int)cdiv(n_out, T);
-  // small levels are latency bound: split the kernel offsets over workgroups until the chip is busy
+  // small levels: split the kernel offsets over workgroups until the chip is busy
   int nsplit = 1;
   if (scratch && tiles < 384) {
     nsplit = (int)std::min<int64_t>(K, cdiv(512, tiles));
@@ -483,7 +480,12 @@ __global__ __launch_bounds__(256) void conv0_k5_kernel(const float* __restrict__
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) npairs += __shfl_xor(npairs, o, 64);
-  if (lane == 0 && npairs) atomicAdd(pair_counter, (unsigned long long)npairs);
+  __shared__ int32_t s_np[4];
+  if (lane == 0) s_np[wave] = npairs;
+  __syncthreads();
+  // one atomic per workgroup, spread over 8 addresses (same-address atomics cost ~12 ns each: profiles/r01b)
+  if (tid == 0)
+    atomicAdd(pair_counter + 8 + (blockIdx.x & 7), (unsigned long long)(s_np[0] + s_np[1] + s_np[2] + s_np[3]));
 }
 
 int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, const float* scale,

@@ -400,8 +400,7 @@ __global__ __launch_bounds__(256) void nbr27_kernel(const uint64_t* __restrict__
                                                      const int32_t* __restrict__ badj,        // [nblocks][27] level l+2
                                                      const uint64_t* __restrict__ bmask,
                                                      const int32_t* __restrict__ bstart, int32_t nblocks,
-                                                     int32_t nvox, int32_t* __restrict__ nbr,
-                                                     unsigned long long* __restrict__ pair_counter) {
+                                                     int32_t nvox, int32_t* __restrict__ nbr) {
   __shared__ uint64_t s_m[4][27];
   __shared__ int32_t s_s[4][27];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -417,20 +416,39 @@ __global__ __launch_bounds__(256) void nbr27_kernel(const uint64_t* __restrict__
   const int32_t s = bstart[j];
   const int32_t e = (j + 1 < nblocks) ? bstart[j + 1] : nvox;
   const int32_t items = (e - s) * 27;
-  int32_t found = 0;
   for (int32_t t = lane; t < items; t += 64) {
     const int32_t v = t / 27, k = t - v * 27;
     const uint32_t lk = (uint32_t)(vkeys[s + v] & 63);
     const int32_t lx = (lk & 1) | ((lk >> 2) & 2), ly = ((lk >> 1) & 1) | ((lk >> 3) & 2),
                   lz = ((lk >> 2) & 1) | ((lk >> 4) & 2);
     const int32_t nx = lx + (k % 3) - 1, ny = ly + (k / 3) % 3 - 1, nz = lz + k / 9 - 1;
-    const int32_t r = lookup_local(s_m[wave], s_s[wave], nx, ny, nz);
-    nbr[(int64_t)s * 27 + t] = r;
-    found += (r >= 0);
+    nbr[(int64_t)s * 27 + t] = lookup_local(s_m[wave], s_s[wave], nx, ny, nz);
   }
+}
+
+// Number of valid entries of a kernel map (pairs P of SURVEY.md §8d).  Only launched by egonn_profile_fetch —
+// a same-address atomic per wave inside the map builder costs ~12 ns each and dominated it (profiles/r01b).
+__global__ void count_valid_kernel(const int32_t* __restrict__ tbl, int64_t n, unsigned long long* __restrict__ out) {
+  __shared__ int32_t red[4];
+  int32_t c = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    c += (tbl[i] >= 0);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) found += __shfl_xor(found, o, 64);
-  if (lane == 0 && found) atomicAdd(pair_counter, (unsigned long long)found);
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(red[0] + red[1] + red[2] + red[3]));
+}
+int count_map_pairs(Ctx* ctx, hipStream_t stream) {
+  const Plan& P = ctx->plan;
+  HIP_CHECK(hipMemsetAsync(ctx->dev_pairs + 1, 0, sizeof(unsigned long long) * 7, stream));
+  for (int l = 1; l < EGONN_NUM_LEVELS; ++l) {
+    const int64_t n = P.lv[l].n * 27;
+    if (n == 0) continue;
+    hipLaunchKernelGGL(count_valid_kernel, dim3(256), dim3(256), 0, stream, P.lv[l].nbr27, n, ctx->dev_pairs + l);
+  }
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
 }
 
 // ------------------------------------------------------------------ k=2,s=2 tables
@@ -574,7 +592,7 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
     } else {
       const Level& Bk = P.lv[l + 2];
       hipLaunchKernelGGL(nbr27_kernel, dim3((unsigned)cdiv(Bk.n, 4)), dim3(256), 0, stream, V.keys, Bk.nbr27, Bk.mask,
-                         Bk.bstart, (int32_t)Bk.n, nv, V.nbr27, ctx->dev_pairs + l);
+                         Bk.bstart, (int32_t)Bk.n, nv, V.nbr27);
     }
   }
   for (int l = 1; l < EGONN_NUM_LEVELS; ++l) {

@@ -14,6 +14,7 @@ int sconv_forward(const float* in, const int32_t* nbr, const float* W, const flo
                   size_t scratch_floats, hipStream_t stream);
 static constexpr size_t SCONV_SCRATCH_FLOATS = (size_t)8 << 20;   // 32 MB: >= 512 tiles x 64 rows x 128 ch
 void sconv_set_naive(bool on);
+void sconv_set_variant(int v);
 int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, const float* scale,
                      const float* shift, int relu, float* out, hipStream_t stream);
 

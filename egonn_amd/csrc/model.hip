@@ -71,7 +71,8 @@ struct egonn_model {
 API const char* egonn_last_error(void) { return last_error(); }
 
 API int egonn_debug_set_naive_conv(int on) {
-  sconv_set_naive(on != 0);
+  sconv_set_naive((on & 1) != 0);
+  if (on & 0x100) sconv_set_variant(((on >> 4) & 7) | (((on >> 12) & 3) << 8));   // tuning hook: variant, tile
   return EGONN_OK;
 }
 
@@ -592,9 +593,12 @@ API int egonn_profile_fetch(egonn_ctx* c, int cap, int* n, char* names, float* m
                             void* stream) {
   EGONN_REQUIRE(c && n && names && ms && bytes && flops, EGONN_ERR_INVALID, "profile_fetch: null argument");
   HIP_CHECK(hipSetDevice(c->device));
+  if (c->plan.valid) EGONN_TRY(count_map_pairs(c, (hipStream_t)stream));
   HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   unsigned long long pairs[16];
   HIP_CHECK(hipMemcpy(pairs, c->dev_pairs, sizeof(pairs), hipMemcpyDeviceToHost));
+  pairs[0] = 0;
+  for (int i = 8; i < 16; ++i) pairs[0] += pairs[i];   // conv0 counters of the LAST forward
   int w = 0;
   for (auto& r : c->prof.recs) {
     float t = 0.f;
