@@ -24,6 +24,7 @@
 // lanes, hits are reduced against the 125x32 weight table in LDS.  No kernel map is materialised.
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "kernels.h"
@@ -74,10 +75,10 @@ static size_t sconv_lds_bytes(int K, int T) {
   size_t b = 0;
   b += (size_t)C::WAVES_M * (T + 1) * C::LDC * 4;         // accumulators (+1 dummy row) per chunk group
   b += (size_t)T * K * 4;                                 // raw neighbour-table tile
-  b += (size_t)T * K * 4;                                 // pair input rows, per offset (k-major)
-  b += (size_t)T * K;                                     // pair output rows (u8)
+  b += (size_t)(T * K + 16 * K + 16) * 4;                 // pair input rows, chunk-major (+ padding)
+  b += (size_t)(T * K + 16 * K + 16);                     // pair output rows (u8)
   b += (size_t)(K + 1) * 4 * 2 + 64;                      // cnt, cbase
-  b += (size_t)(K * (T / 16) + 64);                       // chunk -> k
+  b += (size_t)(K * (T / 16) + K + 64);                   // chunk -> k
   return align_up(b, 16) + 64;
 }
 
@@ -101,17 +102,21 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
                                                           const float* __restrict__ W,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int relu,
-                                                          float* __restrict__ out, int32_t n_out, int K, int T) {
+                                                          float* __restrict__ out, int32_t n_out, int K, int T,
+                                                          uint32_t in_bytes) {
   using C = SconvCfg<CIN, COUT>;
-  constexpr int DDEPTH = 3;
+  // gather prefetch depth (chunks in flight per wave): the A rows come from L2/HBM at random-access latency
+  constexpr int SLOT_F4 = C::KSTEPS * (1 + C::NT);             // float4 registers per ring slot (A + W)
+  constexpr int DDEPTH = (SLOT_F4 <= 4) ? 4 : ((SLOT_F4 <= 12) ? 3 : 2);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* accL = reinterpret_cast<float*>(smem);                               // [WAVES_M][T+1][LDC]
   int32_t* tbl = reinterpret_cast<int32_t*>(accL + (size_t)C::WAVES_M * (T + 1) * C::LDC);   // [T][K]
-  int32_t* pj = tbl + (size_t)T * K;                                          // [K][T] input row or -1
-  int32_t* cnt = pj + (size_t)T * K;                                          // [K+1]
+  const int list_cap = T * K + 16 * K + 16;
+  int32_t* pj = tbl + (size_t)T * K;                                          // [chunk][16] input row or -1
+  int32_t* cnt = pj + list_cap;                                               // [K+1]
   int32_t* cbase = cnt + (K + 1);                                             // [K+1] first chunk of offset k
-  uint8_t* pr = reinterpret_cast<uint8_t*>(cbase + (K + 1) + 8);              // [K][T] output row (T = dummy)
-  uint8_t* ck = pr + (size_t)T * K;                                           // chunk -> k
+  uint8_t* pr = reinterpret_cast<uint8_t*>(cbase + (K + 1) + 8);              // [chunk][16] output row (T = dummy)
+  uint8_t* ck = pr + list_cap;                                                // chunk -> k
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t row0 = blockIdx.x * T;
@@ -129,25 +134,14 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
   }
   __syncthreads();
 
-  // ---- phase A: per-offset compaction of the tile's (input row, output row) pairs, padded to 16
+  // ---- phase A1: pairs per offset (ballot + popcount)
   for (int k = wave; k < K; k += 4) {
     int32_t running = 0;
     if (k % nsplit == split) {
       for (int base = 0; base < T; base += 64) {
         const int r = base + lane;
         const int32_t j = (r < rows) ? tbl[r * K + k] : -1;
-        const uint64_t m = __ballot(j >= 0);
-        if (j >= 0) {
-          const int pos = k * T + running + __popcll(m & lt);
-          pj[pos] = j;
-          pr[pos] = (uint8_t)r;
-        }
-        running += __popcll(m);
-      }
-      const int padded = ((running + 15) >> 4) << 4;          // <= T because T is a multiple of 16
-      if (lane < padded - running) {
-        pj[k * T + running + lane] = -1;
-        pr[k * T + running + lane] = (uint8_t)T;
+        running += __popcll(__ballot(j >= 0));
       }
     }
     if (lane == 0) cnt[k] = running;
@@ -170,6 +164,34 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
   }
   __syncthreads();
   const int total_chunks = cbase[K];
+  // ---- phase A2: chunk-major compacted (input row, output row) lists; chunk tails padded with (-1, dummy row T)
+  for (int k = wave; k < K; k += 4) {
+    if (k % nsplit != split) continue;
+    const int base_e = cbase[k] * 16;
+    int32_t running = 0;
+    for (int base = 0; base < T; base += 64) {
+      const int r = base + lane;
+      const int32_t j = (r < rows) ? tbl[r * K + k] : -1;
+      const uint64_t m = __ballot(j >= 0);
+      if (j >= 0) {
+        const int pos = base_e + running + __popcll(m & lt);
+        pj[pos] = j;
+        pr[pos] = (uint8_t)r;
+      }
+      running += __popcll(m);
+    }
+    const int padded = ((running + 15) >> 4) << 4;
+    if (lane < padded - running) {
+      pj[base_e + running + lane] = -1;
+      pr[base_e + running + lane] = (uint8_t)T;
+    }
+  }
+  if (tid < 16) {                                              // one all-padding chunk behind the last real one
+    pj[total_chunks * 16 + tid] = -1;
+    pr[total_chunks * 16 + tid] = (uint8_t)T;
+    if (tid == 0) ck[total_chunks] = (uint8_t)(total_chunks ? ck[total_chunks - 1] : 0);
+  }
+  __syncthreads();
 
   const int grp = wave / C::WAVES_N;          // chunk group of this wave (chunks are dealt round-robin to groups)
   const int nsl = wave % C::WAVES_N;          // column slice of this wave
@@ -178,69 +200,68 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
   const int my_chunks = (total_chunks - grp + C::WAVES_M - 1) / C::WAVES_M;   // chunks q = i*WAVES_M + grp
   float* myacc = accL + (size_t)grp * (T + 1) * C::LDC + n0 + l15;
 
-  // pair-list position of chunk q: offset k = ck[q], chunk c = q - cbase[k] inside it
-  auto chunk_base = [&](int q) {
-    const int k = ck[q];
-    return k * T + (q - cbase[k]) * 16;
-  };
-
-  float4 aring[DDEPTH][C::KSTEPS];
-  auto a_issue = [&](int i, auto RS) {
+  // Per-chunk metadata (kernel offset, 4 output rows, gather row of the chunk DDEPTH-1 ahead) is read from LDS
+  // one chunk early, and the accumulator rows are read BEFORE the MFMA chain, so that the whole body has a single
+  // LDS wait that overlaps the MFMAs (the first version had 4-5 serialised LDS round trips per chunk).
+  // ---- operand ring.  One slot = the A fragment (16 gathered rows) AND the W[k] fragment of one chunk; the slot
+  // of chunk i + DDEPTH - 1 is requested while chunk i is computed.  A and W of a chunk are requested together
+  // because s_waitcnt vmcnt is IN ORDER: loads must be issued in the order they are consumed, otherwise waiting
+  // for a late-issued/early-needed load (W one chunk ahead, as in an earlier version) drains the whole ring and
+  // gather, W, MFMA and accumulate time add up instead of overlapping (measured: profiles/r01, tools/bench_sconv).
+  // A rows come in through a buffer resource whose hardware bounds check returns 0 for the padding pairs
+  // (row -1 -> offset beyond num_records): no predicate, no branch, counted waits.
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)in_bytes, 0x00020000);
+  f32x4 aring[DDEPTH][C::KSTEPS];
+  f32x4 wring[DDEPTH][C::NT][C::KSTEPS];
+  auto slot_load = [&](int32_t j, int k, auto RS) {
     constexpr int rs = decltype(RS)::value;
-    const int q = i * C::WAVES_M + grp;
-    int32_t j = -1;
-    if (q < total_chunks) j = pj[chunk_base(q) + l15];
-    const float* src = in + (int64_t)(j >= 0 ? j : 0) * CIN + 4 * g4;
+    // W is pre-packed in fragment order (pack_sconv_weights): one coalesced float4 per lane per (nt, t)
+    const f32x4* wk = reinterpret_cast<const f32x4*>(W + (size_t)k * CIN * COUT) +
+                      (size_t)(nsl * C::NT) * C::KSTEPS * 64 + lane;
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+      for (int t = 0; t < C::KSTEPS; ++t) wring[rs][nt][t] = wk[(nt * C::KSTEPS + t) * 64];
+    const uint32_t off = (uint32_t)j * (uint32_t)(CIN * 4) + (uint32_t)(16 * g4);   // j = -1 -> >= 2^32 - CIN*4
 #pragma unroll
     for (int t = 0; t < C::KSTEPS; ++t)
-      aring[rs][t] = (j >= 0) ? *reinterpret_cast<const float4*>(src + 16 * t) : make_float4(0, 0, 0, 0);
+      aring[rs][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(off + 64 * t), 0, 0));
   };
+  auto chunk_of = [&](int i) { return min(i * C::WAVES_M + grp, total_chunks); };   // total_chunks = padding chunk
 
-  float breg[C::NT][CIN / 4];
-  int cur_k = -1;
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  a_issue(0, I0{});
-  a_issue(1, I1{});
+  // metadata: output rows of the chunk the next body() works on; gather row + offset of the chunk it prefetches
+  uint32_t m_rows = *reinterpret_cast<const uint32_t*>(pr + chunk_of(0) * 16 + 4 * g4);
+  int32_t m_j = pj[chunk_of(DDEPTH - 1) * 16 + l15];
+  int m_k = ck[chunk_of(DDEPTH - 1)];
 
   auto body = [&](int i, auto RS) {
     constexpr int rs = decltype(RS)::value;
-    const int q = i * C::WAVES_M + grp;
-    const int k = ck[q];
-    const int pbase = k * T + (q - cbase[k]) * 16;
-    // W first, A prefetch second: the MFMAs then wait with a counted vmcnt that leaves the prefetch in flight
-    if (k != cur_k) {
-      cur_k = k;
-      const float* wk = W + (size_t)k * CIN * COUT + n0 + l15;
-#pragma unroll
-      for (int nt = 0; nt < C::NT; ++nt)
-#pragma unroll
-        for (int t = 0; t < C::KSTEPS; ++t)
-#pragma unroll
-          for (int u = 0; u < 4; ++u) breg[nt][t * 4 + u] = wk[(size_t)(16 * t + 4 * g4 + u) * COUT + nt * 16];
-    }
-    a_issue(i + 2, std::integral_constant<int, (rs + 2) % DDEPTH>{});
-    const uint32_t orows = *reinterpret_cast<const uint32_t*>(pr + pbase + 4 * g4);   // 4 output rows
-    f32x4 acc[C::NT];
-#pragma unroll
-    for (int nt = 0; nt < C::NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < C::KSTEPS; ++t) {
-      const float4 a4 = aring[rs][t];
-      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], breg[nt][t * 4 + u], acc[nt], 0, 0, 0);
-    }
+    const uint32_t orows = m_rows;
+    slot_load(m_j, m_k, std::integral_constant<int, (rs + DDEPTH - 1) % DDEPTH>{});
+    // LDS reads issued ahead of the MFMA chain: next chunk's metadata + this chunk's accumulator rows
+    m_rows = *reinterpret_cast<const uint32_t*>(pr + chunk_of(i + 1) * 16 + 4 * g4);
+    const int qp = chunk_of(i + DDEPTH);
+    m_j = pj[qp * 16 + l15];
+    m_k = ck[qp];
     float old[4][C::NT];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int orow = (orows >> (8 * r)) & 0xFF;
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt) old[r][nt] = myacc[orow * C::LDC + nt * 16];
+    }
+    f32x4 acc[C::NT];
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < C::KSTEPS; ++t) {
+      const f32x4 a4 = aring[rs][t];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u], wring[rs][nt][t][u], acc[nt], 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -249,10 +270,19 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
       for (int nt = 0; nt < C::NT; ++nt) myacc[orow * C::LDC + nt * 16] = old[r][nt] + acc[nt][r];
     }
   };
-  for (int i = 0; i < my_chunks; i += DDEPTH) {
-    body(i, I0{});
-    if (i + 1 < my_chunks) body(i + 1, I1{});
-    if (i + 2 < my_chunks) body(i + 2, I2{});
+  // prologue: fill the ring; main loop unrolled DDEPTH x so that ring slots are compile-time constants
+  [&]<int... Is>(std::integer_sequence<int, Is...>) {
+    (slot_load(pj[chunk_of(Is) * 16 + l15], ck[chunk_of(Is)], std::integral_constant<int, Is>{}), ...);
+  }(std::make_integer_sequence<int, DDEPTH - 1>{});
+  // Straight-line loop body: the trip count is rounded up to whole groups of DDEPTH chunks (the surplus chunks
+  // are the all-padding chunk: zero A rows, +0 on the dummy accumulator row) and made provably wave-uniform, so
+  // there is no branch between the loads and their waits — with per-chunk bounds checks hipcc emitted
+  // s_waitcnt vmcnt(0) at the head of every group and the ring never overlapped anything.
+  const int n_groups = __builtin_amdgcn_readfirstlane((my_chunks + DDEPTH - 1) / DDEPTH);
+  for (int g = 0; g < n_groups; ++g) {
+    [&]<int... Is>(std::integer_sequence<int, Is...>) {
+      (body(g * DDEPTH + Is, std::integral_constant<int, Is>{}), ...);
+    }(std::make_integer_sequence<int, DDEPTH>{});
   }
   __syncthreads();
 
@@ -273,7 +303,7 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
         const float4 sh = reinterpret_cast<const float4*>(shift)[c4];
         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
       }
-      if (relu) {
+      if (relu & 1) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
     }
@@ -304,13 +334,44 @@ __global__ void sconv_reduce_kernel(const float* __restrict__ partial, int nspli
   reinterpret_cast<float4*>(out)[e] = v;
 }
 
+// W[k][ci][co] (reference layout) -> fragment order Wp[k][nsl][nt][t][lane][u] =
+//   W[k][16t + 4(lane>>4) + u][nsl*NW + nt*16 + (lane&15)], NW = 32 for cout >= 128 else 16
+__global__ void pack_sconv_weights_kernel(const float* __restrict__ W, int K, int cin, int cout,
+                                          float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per_k = (int64_t)cin * cout;
+  if (e >= K * per_k) return;
+  const int k = (int)(e / per_k);
+  int64_t r = e - k * per_k;
+  const int nw = cout >= 128 ? 32 : 16, ntn = nw / 16, ksteps = cin / 16;
+  const int u = (int)(r & 3); r >>= 2;
+  const int lane = (int)(r & 63); r >>= 6;
+  const int t = (int)(r % ksteps); r /= ksteps;
+  const int nt = (int)(r % ntn); r /= ntn;
+  const int nsl = (int)r;
+  const int ci = 16 * t + 4 * (lane >> 4) + u;
+  const int co = nsl * nw + nt * 16 + (lane & 15);
+  out[e] = W[(int64_t)k * per_k + (int64_t)ci * cout + co];
+}
+int pack_sconv_weights(const float* W, int K, int cin, int cout, float* out, hipStream_t stream) {
+  const int64_t n = (int64_t)K * cin * cout;
+  hipLaunchKernelGGL(pack_sconv_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, W, K, cin, cout,
+                     out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
 static int g_sconv_tile = 0;   // tuning hook: 0 = auto, else forced tile rows (64 / 128)
-void sconv_set_variant(int v) { g_sconv_tile = ((v >> 8) & 3) == 1 ? 64 : ((v >> 8) & 3) == 2 ? 128 : 0; }
+static int g_sconv_abl = 0;
+void sconv_set_variant(int v) { g_sconv_abl = v & 7; g_sconv_tile = ((v >> 8) & 3) == 1 ? 64 : ((v >> 8) & 3) == 2 ? 128 : ((v >> 8) & 3) == 3 ? 32 : 0; }
 
 template <int CIN, int COUT>
-static int launch_sconv(const float* in, const int32_t* nbr, const float* W, const float* scale, const float* shift,
-                        int relu, float* out, int32_t n_out, int K, float* scratch, size_t scratch_floats,
-                        hipStream_t stream) {
+static int launch_sconv(const float* in, int64_t n_in, const int32_t* nbr, const float* W, const float* scale,
+                        const float* shift, int relu, float* out, int32_t n_out, int K, float* scratch,
+                        size_t scratch_floats, hipStream_t stream) {
+  EGONN_REQUIRE((uint64_t)n_in * CIN * 4 < (1ull << 32) - 4096, EGONN_ERR_INVALID,
+                "sconv: input feature map of %lld rows exceeds the 4 GiB buffer-resource range", (long long)n_in);
+  const uint32_t in_bytes = (uint32_t)((uint64_t)n_in * CIN * 4);
   // 64-row tiles: the kernel is latency bound, more resident workgroups beat better chunk fill (tools/bench_sconv.py)
   const int T = g_sconv_tile ? g_sconv_tile : 64;
   const int tiles = (int)cdiv(n_out, T);
@@ -329,7 +390,7 @@ static int launch_sconv(const float* in, const int32_t* nbr, const float* W, con
   }
   float* dst = nsplit > 1 ? scratch : out;
   hipLaunchKernelGGL((sconv_mfma_kernel<CIN, COUT>), dim3((unsigned)tiles, (unsigned)nsplit), dim3(256), lds, stream,
-                     in, nbr, W, scale, shift, relu, dst, n_out, K, T);
+                     in, nbr, W, scale, shift, (relu ? 1 : 0), dst, n_out, K, T, in_bytes);
   if (nsplit > 1) {
     const int64_t n4 = (int64_t)n_out * COUT / 4;
     hipLaunchKernelGGL(sconv_reduce_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, stream, scratch, nsplit, n4,
@@ -342,15 +403,26 @@ static int launch_sconv(const float* in, const int32_t* nbr, const float* W, con
 static bool g_force_naive = false;
 void sconv_set_naive(bool on) { g_force_naive = on; }
 
-int sconv_forward(const float* in, const int32_t* nbr, const float* W, const float* scale, const float* shift,
-                  int relu, float* out, int32_t n_out, int K, int cin, int cout, float* scratch,
+int sconv_forward(const float* in, int64_t n_in, const int32_t* nbr, const float* W, const float* Wp, const float* scale,
+                  const float* shift, int relu, float* out, int32_t n_out, int K, int cin, int cout, float* scratch,
                   size_t scratch_floats, hipStream_t stream) {
   if (n_out == 0) return EGONN_OK;
   EGONN_REQUIRE(K == 27 || K == 8, EGONN_ERR_INVALID, "sconv: kernel volume %d not supported", K);
-  if (!g_force_naive) {
+  const bool mfma_shape = (cin == 32 && (cout == 32 || cout == 64)) || (cin == 64 && (cout == 64 || cout == 128)) ||
+                          (cin == 128 && cout == 128);
+  if (!g_force_naive && mfma_shape) {
+    if (!Wp) {   // stand-alone operator call: pack into the tail of the scratch buffer
+      const size_t wn = (size_t)K * cin * cout;
+      EGONN_REQUIRE(scratch && scratch_floats > wn, EGONN_ERR_STATE, "sconv: no scratch to pack the kernel into");
+      float* packed = scratch + (scratch_floats - wn);
+      EGONN_TRY(pack_sconv_weights(W, K, cin, cout, packed, stream));
+      Wp = packed;
+      scratch_floats -= wn;
+    }
+    W = Wp;
 #define EGONN_SCONV_CASE(CI, CO)  \
   if (cin == CI && cout == CO)    \
-    return launch_sconv<CI, CO>(in, nbr, W, scale, shift, relu, out, n_out, K, scratch, scratch_floats, stream);
+    return launch_sconv<CI, CO>(in, n_in, nbr, W, scale, shift, relu, out, n_out, K, scratch, scratch_floats, stream);
     EGONN_SCONV_CASE(32, 32)
     EGONN_SCONV_CASE(32, 64)
     EGONN_SCONV_CASE(64, 64)

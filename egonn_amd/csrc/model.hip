@@ -65,6 +65,10 @@ struct egonn_model {
   const float *g1x1[8] = {}, *gt[8] = {}, *l1x1[8] = {}, *lt[8] = {};
   const float* gem_p = nullptr;
   MlpRef gdec, ldec, kp, sg;
+  // sparse-conv kernels repacked into MFMA fragment order (one buffer, carved in finalize)
+  float* packed = nullptr;
+  size_t packed_cap = 0;
+  const float *p_convs[8] = {}, *p_c1[8] = {}, *p_c2[8] = {}, *p_gt[8] = {}, *p_lt[8] = {};
 };
 
 // ------------------------------------------------------------------------------------------ lifecycle
@@ -219,12 +223,12 @@ API int egonn_conv(egonn_ctx* c, int level_in, int level_out, int ks, const floa
   if (ks == 3) {
     EGONN_REQUIRE(level_in == level_out && level_in >= 1, EGONN_ERR_INVALID,
                   "k=3 convolution is implemented for levels 1..7 (same in/out level)");
-    return sconv_forward(in, P.lv[level_in].nbr27, kernel, scale, shift, relu, out, (int32_t)P.lv[level_in].n, 27, cin,
+    return sconv_forward(in, P.lv[level_in].n, P.lv[level_in].nbr27, kernel, nullptr, scale, shift, relu, out, (int32_t)P.lv[level_in].n, 27, cin,
                          cout, op_scratch(c), SCONV_SCRATCH_FLOATS, st);
   }
   if (ks == 2) {
     EGONN_REQUIRE(level_out == level_in + 1, EGONN_ERR_INVALID, "k=2,s=2 convolution maps level l to l+1");
-    return sconv_forward(in, P.lv[level_out].nbr8, kernel, scale, shift, relu, out, (int32_t)P.lv[level_out].n, 8, cin,
+    return sconv_forward(in, P.lv[level_in].n, P.lv[level_out].nbr8, kernel, nullptr, scale, shift, relu, out, (int32_t)P.lv[level_out].n, 8, cin,
                          cout, op_scratch(c), SCONV_SCRATCH_FLOATS, st);
   }
   set_error("conv: kernel_size %d not supported (1, 2, 3, 5)", ks);
@@ -238,7 +242,7 @@ API int egonn_conv_transpose(egonn_ctx* c, int level_in, const float* in, int ci
   EGONN_REQUIRE(level_in >= 2 && level_in < EGONN_NUM_LEVELS, EGONN_ERR_INVALID,
                 "transposed conv: input level %d out of range [2,7]", level_in);
   const Level& L = c->plan.lv[level_in - 1];
-  return sconv_forward(in, L.nbrT, kernel, nullptr, nullptr, 0, out, (int32_t)L.n, 8, cin, cout, op_scratch(c),
+  return sconv_forward(in, c->plan.lv[level_in].n, L.nbrT, kernel, nullptr, nullptr, nullptr, 0, out, (int32_t)L.n, 8, cin, cout, op_scratch(c),
                        SCONV_SCRATCH_FLOATS, (hipStream_t)stream);
 }
 
@@ -278,6 +282,7 @@ API int egonn_model_create(egonn_model** m) {
 API void egonn_model_destroy(egonn_model* m) {
   if (!m) return;
   if (m->folded) (void)hipFree(m->folded);
+  if (m->packed) (void)hipFree(m->packed);
   delete m;
 }
 
@@ -395,6 +400,36 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
   EGONN_TRY(get_mlp(m, "local_keypoint_regressor", LOCAL_CH, LOCAL_CH / 2, 3, &m->kp));
   EGONN_TRY(get_mlp(m, "local_sigma_regressor", LOCAL_CH, LOCAL_CH / 2, 1, &m->sg));
 
+  // ---- repack every sparse-conv kernel into fragment order
+  {
+    size_t need_p = 0;
+    for (int i = 1; i <= 7; ++i) {
+      const BlockRef& b = m->blk[i];
+      need_p += (size_t)8 * b.cin * b.cin + (size_t)27 * b.cin * b.cout + (size_t)27 * b.cout * b.cout;
+    }
+    need_p += (size_t)2 * 8 * GLOBAL_CH * GLOBAL_CH + (size_t)8 * LOCAL_CH * LOCAL_CH;
+    if (m->packed_cap < need_p) {
+      if (m->packed) HIP_CHECK(hipFree(m->packed));
+      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->packed), need_p * sizeof(float)));
+      m->packed_cap = need_p;
+    }
+    float* pc = m->packed;
+    auto pack = [&](const float* w, int K, int ci, int co, const float** dst) -> int {
+      EGONN_TRY(pack_sconv_weights(w, K, ci, co, pc, st));
+      *dst = pc;
+      pc += (size_t)K * ci * co;
+      return EGONN_OK;
+    };
+    for (int i = 1; i <= 7; ++i) {
+      const BlockRef& b = m->blk[i];
+      EGONN_TRY(pack(m->convs[i], 8, b.cin, b.cin, &m->p_convs[i]));
+      EGONN_TRY(pack(b.conv1, 27, b.cin, b.cout, &m->p_c1[i]));
+      EGONN_TRY(pack(b.conv2, 27, b.cout, b.cout, &m->p_c2[i]));
+    }
+    EGONN_TRY(pack(m->gt[6], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[6]));
+    EGONN_TRY(pack(m->gt[7], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[7]));
+    EGONN_TRY(pack(m->lt[4], 8, LOCAL_CH, LOCAL_CH, &m->p_lt[4]));
+  }
   EGONN_TRY(fold(m->bn[0], st));
   for (int i = 1; i <= 7; ++i) {
     EGONN_TRY(fold(m->bn[i], st));
@@ -469,7 +504,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     {
       snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k2s2", b.cin, b.cin, i);
       ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, P.lv[i - 1].n, n);
-      EGONN_TRY(sconv_forward(x[i - 1], L.nbr8, m->convs[i], m->bn[i].scale, m->bn[i].shift, 1, y, (int32_t)n, 8,
+      EGONN_TRY(sconv_forward(x[i - 1], P.lv[i - 1].n, L.nbr8, m->convs[i], m->p_convs[i], m->bn[i].scale, m->bn[i].shift, 1, y, (int32_t)n, 8,
                               b.cin, b.cin, scr, SCONV_SCRATCH_FLOATS, st));
     }
     // ECABasicBlock (layers/eca_block.py:56-73)
@@ -477,13 +512,13 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     {
       snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k3.conv1", b.cin, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cin, b.cout, n, n);
-      EGONN_TRY(sconv_forward(y, L.nbr27, b.conv1, b.n1.scale, b.n1.shift, 1, t1, (int32_t)n, 27, b.cin, b.cout, scr, SCONV_SCRATCH_FLOATS, st));
+      EGONN_TRY(sconv_forward(y, n, L.nbr27, b.conv1, m->p_c1[i], b.n1.scale, b.n1.shift, 1, t1, (int32_t)n, 27, b.cin, b.cout, scr, SCONV_SCRATCH_FLOATS, st));
     }
     WALLOC(t2, n * b.cout);
     {
       snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k3.conv2", b.cout, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cout, b.cout, n, n);
-      EGONN_TRY(sconv_forward(t1, L.nbr27, b.conv2, b.n2.scale, b.n2.shift, 0, t2, (int32_t)n, 27, b.cout, b.cout, scr, SCONV_SCRATCH_FLOATS, st));
+      EGONN_TRY(sconv_forward(t1, n, L.nbr27, b.conv2, m->p_c2[i], b.n2.scale, b.n2.shift, 0, t2, (int32_t)n, 27, b.cout, b.cout, scr, SCONV_SCRATCH_FLOATS, st));
     }
     WALLOC(partial, (size_t)B * SEG_CHUNKS * b.cout + (size_t)B * b.cout);
     EGONN_TRY(segment_partial_sums(t2, L.boff, B, b.cout, 0, nullptr, partial, st));
@@ -505,11 +540,11 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     WALLOC(g7, P.lv[7].n * GLOBAL_CH);
     EGONN_TRY(dense_forward(x[7], P.lv[7].n, 128, m->g1x1[7], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, g7, st));
     WALLOC(u6, P.lv[6].n * GLOBAL_CH);
-    EGONN_TRY(sconv_forward(g7, P.lv[6].nbrT, m->gt[7], nullptr, nullptr, 0, u6, (int32_t)P.lv[6].n, 8, GLOBAL_CH, GLOBAL_CH, scr, SCONV_SCRATCH_FLOATS, st));
+    EGONN_TRY(sconv_forward(g7, P.lv[7].n, P.lv[6].nbrT, m->gt[7], m->p_gt[7], nullptr, nullptr, 0, u6, (int32_t)P.lv[6].n, 8, GLOBAL_CH, GLOBAL_CH, scr, SCONV_SCRATCH_FLOATS, st));
     WALLOC(g6, P.lv[6].n * GLOBAL_CH);
     EGONN_TRY(dense_forward(x[6], P.lv[6].n, 128, m->g1x1[6], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u6, g6, st));
     WALLOC(u5, P.lv[5].n * GLOBAL_CH);
-    EGONN_TRY(sconv_forward(g6, P.lv[5].nbrT, m->gt[6], nullptr, nullptr, 0, u5, (int32_t)P.lv[5].n, 8, GLOBAL_CH, GLOBAL_CH, scr, SCONV_SCRATCH_FLOATS, st));
+    EGONN_TRY(sconv_forward(g6, P.lv[6].n, P.lv[5].nbrT, m->gt[6], m->p_gt[6], nullptr, nullptr, 0, u5, (int32_t)P.lv[5].n, 8, GLOBAL_CH, GLOBAL_CH, scr, SCONV_SCRATCH_FLOATS, st));
     WALLOC(g5, P.lv[5].n * GLOBAL_CH);
     EGONN_TRY(dense_forward(x[5], P.lv[5].n, 128, m->g1x1[5], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u5, g5, st));
     WALLOC(gh, P.lv[5].n * m->gdec.mid);
@@ -526,7 +561,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     WALLOC(l4, n4 * LOCAL_CH);
     EGONN_TRY(dense_forward(x[4], n4, 128, m->l1x1[4], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, l4, st));
     WALLOC(u3, n3 * LOCAL_CH);
-    EGONN_TRY(sconv_forward(l4, P.lv[3].nbrT, m->lt[4], nullptr, nullptr, 0, u3, (int32_t)n3, 8, LOCAL_CH, LOCAL_CH, scr, SCONV_SCRATCH_FLOATS, st));
+    EGONN_TRY(sconv_forward(l4, n4, P.lv[3].nbrT, m->lt[4], m->p_lt[4], nullptr, nullptr, 0, u3, (int32_t)n3, 8, LOCAL_CH, LOCAL_CH, scr, SCONV_SCRATCH_FLOATS, st));
     WALLOC(l3, n3 * LOCAL_CH);
     EGONN_TRY(dense_forward(x[3], n3, 64, m->l1x1[3], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u3, l3, st));
     WALLOC(dh, n3 * m->ldec.mid);
