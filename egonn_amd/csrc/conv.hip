@@ -60,7 +60,7 @@ __global__ void sconv_naive_kernel(const float* __restrict__ in, const int32_t* 
 // ------------------------------------------------------------------ MFMA kernel
 template <int CIN, int COUT>
 struct SconvCfg {
-  static constexpr int NW = (COUT >= 128) ? 32 : 16;      // columns per wave
+  static constexpr int NW = (COUT <= 32) ? 16 : 32;       // columns per wave (measured: tools/bench_sconv.py)
   static constexpr int NT = NW / 16;                      // 16-wide MFMA column tiles per wave
   static constexpr int WAVES_N = COUT / NW;               // waves across the columns
   static constexpr int WAVES_M = 4 / WAVES_N;             // chunk groups working concurrently
@@ -335,7 +335,7 @@ __global__ void sconv_reduce_kernel(const float* __restrict__ partial, int nspli
 }
 
 // W[k][ci][co] (reference layout) -> fragment order Wp[k][nsl][nt][t][lane][u] =
-//   W[k][16t + 4(lane>>4) + u][nsl*NW + nt*16 + (lane&15)], NW = 32 for cout >= 128 else 16
+//   W[k][16t + 4(lane>>4) + u][nsl*NW + nt*16 + (lane&15)], NW = 16 for cout <= 32 else 32
 __global__ void pack_sconv_weights_kernel(const float* __restrict__ W, int K, int cin, int cout,
                                           float* __restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -343,7 +343,7 @@ __global__ void pack_sconv_weights_kernel(const float* __restrict__ W, int K, in
   if (e >= K * per_k) return;
   const int k = (int)(e / per_k);
   int64_t r = e - k * per_k;
-  const int nw = cout >= 128 ? 32 : 16, ntn = nw / 16, ksteps = cin / 16;
+  const int nw = cout <= 32 ? 16 : 32, ntn = nw / 16, ksteps = cin / 16;
   const int u = (int)(r & 3); r >>= 2;
   const int lane = (int)(r & 63); r >>= 6;
   const int t = (int)(r % ksteps); r /= ksteps;
