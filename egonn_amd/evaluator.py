@@ -59,10 +59,11 @@ class DescriptorExtractor:
         return self.extract_packed(allpts, offsets, model)
 
     @torch.no_grad()
-    def extract_packed(self, points: torch.Tensor, offsets: List[int], model: MinkGL = None):
-        """points: (sum n_i, 3) float32 already resident on the device; offsets: host list of B+1 scan bounds."""
+    def extract_packed(self, points: torch.Tensor, offsets: List[int], model: MinkGL = None, slot: int = 0):
+        """points: (sum n_i, 3) float32 already resident on the device; offsets: host list of B+1 scan bounds.
+        `slot` selects the egonn_ctx (plan + workspace): batches on different slots may be in flight at once."""
         model = model or self.model
-        ctx = model.context()
+        ctx = model.context(slot)
         q = self.quantizer
         ctx.voxelize(points, offsets, q.mode, q.step)
         n0 = ctx.level_count(0)
@@ -72,9 +73,29 @@ class DescriptorExtractor:
         sel_kp, sel_desc, rows, cnt = ctx.select_keypoints(s, k, d, self.n_k)
         return {'global': y['global'], 'keypoints': sel_kp, 'descriptors': sel_desc, 'count': cnt, 'rows': rows}
 
+    @torch.no_grad()
+    def extract_stream(self, batches, n_streams: int = 2, model: MinkGL = None):
+        """Throughput mode: `batches` yields (points, offsets) with the points resident on the device; batch i runs
+        on HIP stream i % n_streams with its own egonn_ctx, so the latency-bound tail of one batch (small levels,
+        heads, top-k: few workgroups) overlaps the bandwidth/MFMA-bound head of the next.  The per-batch size query
+        only blocks the host on that batch's stream.  Yields the per-batch result dicts in order; results are valid
+        after `torch.cuda.synchronize()` (or a sync on the batch's stream)."""
+        model = model or self.model
+        dev = model.context(0).device
+        model._sync_weights()
+        if getattr(self, '_streams', None) is None or len(self._streams) != n_streams:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+        torch.cuda.current_stream(dev).synchronize()
+        for i, (points, offsets) in enumerate(batches):
+            slot = i % n_streams
+            with torch.cuda.stream(self._streams[slot]):
+                yield self.extract_packed(points, offsets, model, slot=slot)
+
     def _ones(self, n, dev):
+        # shared read-only buffer (filled once on the default stream before any side stream uses it)
         buf = getattr(self, '_ones_buf', None)
         if buf is None or buf.shape[0] < n or buf.device != dev:
             buf = torch.ones((max(n, 1) * 5 // 4 + 1024, 1), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize(dev)
             self._ones_buf = buf
         return buf[:n]

@@ -225,11 +225,16 @@ class MinkGL(nn.Module):
                                "(`model.to('cuda')`); there is no CPU fallback.")
         return dev
 
-    def context(self) -> _lib.Context:
+    def context(self, slot: int = 0) -> _lib.Context:
+        """egonn_ctx number `slot` of this model's device (one per batch in flight: each owns its plan+workspace)."""
         dev = self._device()
-        if self._ctx is None or self._ctx.device != dev:
-            self._ctx = _lib.Context(dev, coord_bits=self.coord_bits)
-        return self._ctx
+        if self._ctx is None or not isinstance(self._ctx, dict):
+            self._ctx = {}
+        c = self._ctx.get(slot)
+        if c is None or c.device != dev:
+            c = _lib.Context(dev, coord_bits=self.coord_bits)
+            self._ctx[slot] = c
+        return c
 
     def _float_state(self):
         for k, v in self.state_dict(keep_vars=True).items():

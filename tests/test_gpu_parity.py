@@ -410,3 +410,29 @@ def test_full_size_properties_batch16(gpu):
     same = np.all(got_c[:, 1:] == kc_ref[:, 1:], axis=1)
     assert same.mean() > 0.9                                    # near-tie swaps only
     assert H.cosine_err(_np(d1[3])[same], desc_ref[same]).max() < 1e-4
+
+
+def test_streamed_batches_equal_sequential(gpu):
+    """throughput mode: several batches in flight on separate HIP streams / contexts must give exactly the
+    results of running them one after the other (bitwise: same kernels, same order inside a batch)."""
+    from egonn_amd.synth import lidar_scan
+    m, _ = _model(gpu, seed=41)
+    ex = gpu.DescriptorExtractor(m, n_k=64)
+    batches = []
+    for b in range(5):
+        scans = [lidar_scan(500 + 10 * b + i, 4000 + 700 * i) for i in range(3)]
+        off = [0]
+        for s in scans:
+            off.append(off[-1] + len(s))
+        batches.append((torch.from_numpy(np.concatenate(scans)).cuda(), off))
+    seq = []
+    for p, o in batches:
+        r = ex.extract_packed(p, o)
+        seq.append({k: v.clone() for k, v in r.items()})
+    torch.cuda.synchronize()
+    for n_streams in (2, 3):
+        got = [r for r in ex.extract_stream(iter(batches), n_streams=n_streams)]
+        torch.cuda.synchronize()
+        for a, b in zip(seq, got):
+            for k in ("global", "keypoints", "descriptors", "count", "rows"):
+                assert torch.equal(a[k], b[k]), (n_streams, k)
