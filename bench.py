@@ -145,9 +145,19 @@ def main():
         fl = np.array([r[3] for r in recs])
         achieved = float(by.mean() / (ms.mean() * 1e-3) / 1e9)
         layers = sorted({r[0].split("/", 1)[1] for r in recs})
+        # HBM bytes per launch from the PMC passes of this same command (separate FETCH_SIZE / WRITE_SIZE passes,
+        # gfx950 correction applied: tools/pmc_traffic.py) — rocprofv3 cannot wrap itself, so the committed summary
+        # of the latest passes is read back; null when the kernel is not in it
+        traffic = None
+        try:
+            with open(os.path.join(REPO, "profiles", "traffic_latest.json")) as f:
+                traffic = json.load(f).get(dominant, {}).get("traffic_bytes_per_launch")
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": dominant, "layers": layers,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "batches_in_flight": args.streams,
                     "launches": int(len(ms)), "avg_launch_us": round(float(ms.mean()) * 1e3, 2),
                     "algorithmic_bytes_per_launch": float(by.mean()),
                     "tflops": round(float(fl.mean() / (ms.mean() * 1e-3) / 1e12), 2)}
