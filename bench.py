@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--cpu-scans", type=int, default=6, help="scans of the workload timed on the CPU oracle")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--layer-table", type=str, default="", help="write a per-layer timing table (json) here")
+    p.add_argument("--tune", type=int, default=-1, help="library tuning hook value (debug)")
     p.add_argument("--streams", type=int, default=3, help="batches in flight (HIP streams, one egonn_ctx each)")
     return p.parse_args()
 
@@ -92,6 +93,8 @@ def main():
     points = torch.from_numpy(np.concatenate(scans, axis=0)).to(dev).contiguous()   # resident in HBM
 
     ctx = model.context()
+    if args.tune >= 0:
+        ctx.lib.egonn_debug_set_naive_conv(0x100 | ((args.tune & 7) << 4) | ((args.tune >> 4) << 12))
 
     def step():
         return ex.extract_packed(points, offsets)

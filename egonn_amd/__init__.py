@@ -8,7 +8,8 @@ gfx950, C ABI in include/egonn_hip.h); importing the package does not need a GPU
 from .params import ModelParams
 from .quantization import CartesianQuantizer, PolarQuantizer, Quantizer
 from .model import MinkGL, MinkHead, MinkTrunk, model_factory, create_egonn_model
+from .minkloc import MinkFPN, MinkLoc, MinkLoc3D
 from .evaluator import DescriptorExtractor
 
 __all__ = ["ModelParams", "model_factory", "create_egonn_model", "MinkGL", "MinkHead", "MinkTrunk",
-           "CartesianQuantizer", "PolarQuantizer", "Quantizer", "DescriptorExtractor"]
+           "CartesianQuantizer", "PolarQuantizer", "Quantizer", "DescriptorExtractor", "MinkFPN", "MinkLoc", "MinkLoc3D"]

@@ -33,6 +33,11 @@ _SIGS = [
     ("egonn_conv", C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P]),
     ("egonn_conv_transpose", C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P]),
     ("egonn_global_avg_pool", C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
+    ("egonn_bn_fold", C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int, _P, _P, _P]),
+    ("egonn_block_tail", C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, _P]),
+    ("egonn_gem", C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P]),
+    ("egonn_add", C.c_int, [_P, _P, C.c_int64, _P, _P]),
+    ("egonn_gather_input", C.c_int, [_P, _P, C.c_int, _P, _P]),
     ("egonn_model_create", C.c_int, [C.POINTER(_P)]),
     ("egonn_model_destroy", None, [_P]),
     ("egonn_model_set_tensor", C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64)]),
@@ -192,6 +197,50 @@ class Context:
         out = torch.empty((self.batch_size, x.shape[1]), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             check(self.lib.egonn_global_avg_pool(self.h, level, x.data_ptr(), x.shape[1], out.data_ptr(), _stream()))
+        return out
+
+    def bn_fold(self, bn: torch.nn.BatchNorm1d):
+        """(scale, shift) of an eval-mode BatchNorm1d, computed on the device by the library."""
+        c = bn.num_features
+        w, b, rm, rv = (_dev_f32(t.detach(), self.device) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        scale = torch.empty(c, dtype=torch.float32, device=self.device)
+        shift = torch.empty(c, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_bn_fold(w.data_ptr(), b.data_ptr(), rm.data_ptr(), rv.data_ptr(), float(bn.eps), c,
+                                         scale.data_ptr(), shift.data_ptr(), _stream()))
+        return scale, shift
+
+    def block_tail(self, level: int, x: torch.Tensor, residual: torch.Tensor, eca_weight: Optional[torch.Tensor] = None):
+        x, residual = _dev_f32(x, self.device), _dev_f32(residual, self.device)
+        assert x.shape == residual.shape == (self.level_count(level), x.shape[1])
+        out = torch.empty_like(x)
+        ew = None if eca_weight is None else _dev_f32(eca_weight.detach().reshape(-1), self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_block_tail(self.h, level, x.data_ptr(), residual.data_ptr(), x.shape[1], _ptr(ew),
+                                            0 if ew is None else ew.numel(), out.data_ptr(), _stream()))
+        return out
+
+    def add(self, a: torch.Tensor, b: torch.Tensor):
+        a, b = _dev_f32(a, self.device), _dev_f32(b, self.device)
+        assert a.shape == b.shape
+        out = torch.empty_like(a)
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_add(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), _stream()))
+        return out
+
+    def gather_input(self, feats: torch.Tensor):
+        feats = _dev_f32(feats, self.device)
+        out = torch.empty((self.level_count(0), feats.shape[1]), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_gather_input(self.h, feats.data_ptr(), feats.shape[1], out.data_ptr(), _stream()))
+        return out
+
+    def gem(self, level: int, x: torch.Tensor, p: torch.Tensor):
+        x = _dev_f32(x, self.device)
+        pp = _dev_f32(p.detach().reshape(-1), self.device)
+        out = torch.empty((self.batch_size, x.shape[1]), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_gem(self.h, level, x.data_ptr(), x.shape[1], pp.data_ptr(), out.data_ptr(), _stream()))
         return out
 
     def forward_level_features(self, level: int, channels: int) -> torch.Tensor:

@@ -363,7 +363,8 @@ int pack_sconv_weights(const float* W, int K, int cin, int cout, float* out, hip
 
 static int g_sconv_tile = 0;   // tuning hook: 0 = auto, else forced tile rows (64 / 128)
 static int g_sconv_abl = 0;
-void sconv_set_variant(int v) { g_sconv_abl = v & 7; g_sconv_tile = ((v >> 8) & 3) == 1 ? 64 : ((v >> 8) & 3) == 2 ? 128 : ((v >> 8) & 3) == 3 ? 32 : 0; }
+static int g_sconv_split_target = 128;   // workgroups wanted per launch before kernel offsets are split
+void sconv_set_variant(int v) { g_sconv_abl = v & 7; g_sconv_split_target = (v & 4) ? 1 : ((v & 2) ? 512 : 128); g_sconv_tile = ((v >> 8) & 3) == 1 ? 64 : ((v >> 8) & 3) == 2 ? 128 : ((v >> 8) & 3) == 3 ? 32 : 0; }
 
 template <int CIN, int COUT>
 static int launch_sconv(const float* in, int64_t n_in, const int32_t* nbr, const float* W, const float* scale,
@@ -377,8 +378,8 @@ static int launch_sconv(const float* in, int64_t n_in, const int32_t* nbr, const
   const int tiles = (int)cdiv(n_out, T);
   // small levels: split the kernel offsets over workgroups until the chip is busy
   int nsplit = 1;
-  if (scratch && tiles < 384) {
-    nsplit = (int)std::min<int64_t>(K, cdiv(512, tiles));
+  if (scratch && tiles < g_sconv_split_target) {
+    nsplit = (int)std::min<int64_t>(K, cdiv(g_sconv_split_target, tiles));
     while (nsplit > 1 && (size_t)nsplit * n_out * COUT > scratch_floats) --nsplit;
   }
   const size_t lds = sconv_lds_bytes<CIN, COUT>(K, T);

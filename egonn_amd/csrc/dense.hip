@@ -269,6 +269,20 @@ int eca_apply(const float* x, const float* res, const float* partial, const int3
   return EGONN_OK;
 }
 
+__global__ void add_act_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, int relu,
+                               float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const float v = a[t] + b[t];
+  out[t] = relu ? fmaxf(v, 0.f) : v;
+}
+int add_act(const float* a, const float* b, int64_t n, int relu, float* out, hipStream_t stream) {
+  if (n == 0) return EGONN_OK;
+  hipLaunchKernelGGL(add_act_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, a, b, n, relu, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
 // ------------------------------------------------------------------ GeM finish
 __global__ void gem_finish_kernel(const float* __restrict__ partial, const int32_t* __restrict__ boff, int c,
                                   const float* __restrict__ pexp, float* __restrict__ out) {

@@ -41,6 +41,7 @@ int eca_apply(const float* x, const float* res, const float* partial, const int3
 int gem_finish(const float* partial, const int32_t* boff, int B, int c, const float* p, float* out,
                hipStream_t stream);
 int l2_normalize_rows(float* x, int64_t n, int c, hipStream_t stream);
+int add_act(const float* a, const float* b, int64_t n, int relu, float* out, hipStream_t stream);
 // keypoint positions (reference datasets/quantization.py:60-72, 93-103)
 int keypoint_positions(const uint64_t* keys, int64_t n, int level, int cb, const float* offsets, int mode,
                        const float* step, int ignore_offsets, float* out, hipStream_t stream);

@@ -272,6 +272,70 @@ API int egonn_global_avg_pool(egonn_ctx* c, int level, const float* in, int ch, 
   return EGONN_OK;
 }
 
+// eval-mode MinkowskiBatchNorm folded to scale/shift (nn.BatchNorm1d eps as given): scale = w / sqrt(var + eps)
+API int egonn_bn_fold(const float* weight, const float* bias, const float* running_mean, const float* running_var,
+                      float eps, int channels, float* scale, float* shift, void* stream) {
+  EGONN_REQUIRE(weight && bias && running_mean && running_var && scale && shift && channels > 0, EGONN_ERR_INVALID,
+                "bn_fold: bad argument");
+  return bn_fold(weight, bias, running_mean, running_var, eps, channels, scale, shift, (hipStream_t)stream);
+}
+
+// Tail of a residual block on level `level`:  out = relu(x * gate + residual)
+//   eca_weight != NULL: gate = sigmoid(conv1d_k(per-sample mean of x))  (ECABasicBlock, layers/eca_block.py:21-36,66-71)
+//   eca_weight == NULL: gate = 1                                        (ME BasicBlock: out += residual; relu)
+API int egonn_block_tail(egonn_ctx* c, int level, const float* x, const float* residual, int channels,
+                         const float* eca_weight, int eca_ksize, float* out, void* stream) {
+  REQUIRE_PLAN(c);
+  EGONN_REQUIRE(level >= 0 && level < EGONN_NUM_LEVELS && x && residual && out, EGONN_ERR_INVALID, "block_tail: bad argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int B = c->plan.batch;
+  const Level& L = c->plan.lv[level];
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
+  EGONN_TRY(c->work_arena.ensure(((size_t)B * SEG_CHUNKS * channels + (size_t)B * channels + 64) * 4 + 4096));
+  c->work_arena.reset();
+  float* partial = c->work_arena.alloc<float>((size_t)B * SEG_CHUNKS * channels + (size_t)B * channels);
+  EGONN_REQUIRE(partial, EGONN_ERR_STATE, "work arena too small");
+  float ones[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)ones;
+  if (eca_weight) {
+    EGONN_TRY(segment_partial_sums(x, L.boff, B, channels, 0, nullptr, partial, st));
+    return eca_apply(x, residual, partial, L.boff, B, L.n, channels, eca_weight, eca_ksize, out, st);
+  }
+  return add_act(x, residual, L.n * channels, 1, out, st);
+}
+
+// SparseTensor + SparseTensor on the same coordinate map (models/minkfpn.py:91, minkgl.py:56): out = a + b
+API int egonn_add(const float* a, const float* b, int64_t n, float* out, void* stream) {
+  EGONN_REQUIRE(a && b && out && n >= 0, EGONN_ERR_INVALID, "add: bad argument");
+  return add_act(a, b, n, 0, out, (hipStream_t)stream);
+}
+
+// Features handed in in the caller's row order -> plan (Z-order) row order: out[i] = features[input_index[i]]
+API int egonn_gather_input(egonn_ctx* c, const float* features, int channels, float* out, void* stream) {
+  REQUIRE_PLAN(c);
+  EGONN_REQUIRE(features && out && channels >= 1, EGONN_ERR_INVALID, "gather_input: bad argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  EGONN_REQUIRE(!c->from_points, EGONN_ERR_STATE, "gather_input: voxelize plans have no caller row order");
+  return gather_rows(features, c->plan.perm0, c->plan.lv[0].n, channels, out, (hipStream_t)stream);
+}
+
+// GeM pooling over the rows of level `level` (layers/pooling.py:82-86): out (B, channels)
+API int egonn_gem(egonn_ctx* c, int level, const float* x, int channels, const float* p, float* out, void* stream) {
+  REQUIRE_PLAN(c);
+  EGONN_REQUIRE(level >= 0 && level < EGONN_NUM_LEVELS && x && p && out, EGONN_ERR_INVALID, "gem: bad argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int B = c->plan.batch;
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
+  EGONN_TRY(c->work_arena.ensure((size_t)B * SEG_CHUNKS * channels * 4 + 4096));
+  c->work_arena.reset();
+  float* partial = c->work_arena.alloc<float>((size_t)B * SEG_CHUNKS * channels);
+  EGONN_REQUIRE(partial, EGONN_ERR_STATE, "work arena too small");
+  EGONN_TRY(segment_partial_sums(x, c->plan.lv[level].boff, B, channels, 1, p, partial, st));
+  return gem_finish(partial, c->plan.lv[level].boff, B, channels, p, out, st);
+}
+
 // ------------------------------------------------------------------------------------------ model
 API int egonn_model_create(egonn_model** m) {
   EGONN_REQUIRE(m, EGONN_ERR_INVALID, "model_create: null out pointer");

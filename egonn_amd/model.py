@@ -360,6 +360,15 @@ def create_egonn_model(model_params):
 
 def model_factory(model_params):
     """reference models/model_factory.py:12-28"""
+    if model_params.model == 'MinkLoc':
+        from .minkloc import MinkLoc
+        return MinkLoc(in_channels=1, feature_size=model_params.feature_size, output_dim=model_params.output_dim,
+                       planes=model_params.planes, layers=model_params.layers,
+                       num_top_down=model_params.num_top_down, conv0_kernel_size=model_params.conv0_kernel_size,
+                       block=model_params.block, pooling_method=model_params.pooling)
+    if model_params.model == 'MinkLoc3D':
+        from .minkloc import MinkLoc3D
+        return MinkLoc3D()
     if 'egonn' in model_params.model:
         return create_egonn_model(model_params)
     raise NotImplementedError('Model not implemented: {}'.format(model_params.model))

@@ -9,7 +9,7 @@ from .quantization import CartesianQuantizer, PolarQuantizer
 
 class ModelParams:
     def __init__(self, model_params_path=None, *, model: str = "egonn", coordinates: str = "polar",
-                 quantization_step=None):
+                 quantization_step=None, **minkloc_kwargs):
         if model_params_path is not None:
             config = configparser.ConfigParser()
             read = config.read(model_params_path)
@@ -21,7 +21,10 @@ class ModelParams:
             self.output_dim = params.getint('output_dim', 256)
             self.coordinates = params.get('coordinates', 'polar')
             raw_step = params.get('quantization_step', None)
+            mk = {k: params[k] for k in ('feature_size', 'planes', 'layers', 'num_top_down', 'conv0_kernel_size',
+                                         'block', 'pooling') if k in params}
         else:
+            mk = dict(minkloc_kwargs)
             self.model_params_path = None
             self.model = model
             self.output_dim = 256
@@ -38,6 +41,18 @@ class ModelParams:
         else:
             self.quantization_step = float(raw_step)
             self.quantizer = CartesianQuantizer(quant_step=self.quantization_step)
+        if 'MinkLoc' in self.model:                       # reference misc/utils.py:41-58
+            def ints(v, default):
+                if v is None:
+                    return default
+                return [int(e) for e in v.split(',')] if isinstance(v, str) else [int(e) for e in v]
+            self.feature_size = int(mk.get('feature_size', 256))
+            self.planes = ints(mk.get('planes'), [32, 64, 64])
+            self.layers = ints(mk.get('layers'), [1, 1, 1])
+            self.num_top_down = int(mk.get('num_top_down', 1))
+            self.conv0_kernel_size = int(mk.get('conv0_kernel_size', 5))
+            self.block = mk.get('block', 'BasicBlock')
+            self.pooling = mk.get('pooling', 'GeM')
 
     def print(self):
         print('Model parameters:')

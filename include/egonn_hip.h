@@ -78,6 +78,22 @@ int egonn_conv_transpose(egonn_ctx* ctx, int level_in, const float* in, int cin,
 /* MinkowskiGlobalAvgPooling: layers/eca_block.py:16, layers/pooling.py:80.  out (B,C) */
 int egonn_global_avg_pool(egonn_ctx* ctx, int level, const float* in, int channels, float* out, void* stream);
 
+/* MinkowskiBatchNorm in eval mode (= nn.BatchNorm1d on the rows) folded to per-channel scale/shift for the fused
+ * epilogue of egonn_conv:  scale = weight / sqrt(running_var + eps),  shift = bias - running_mean * scale. */
+int egonn_bn_fold(const float* weight, const float* bias, const float* running_mean, const float* running_var,
+                  float eps, int channels, float* scale, float* shift, void* stream);
+/* Tail of a residual block: out = relu(x * gate + residual).  eca_weight (k,) non-NULL: ECALayer gate
+ * (MinkowskiGlobalPooling -> Conv1d over channels -> sigmoid -> MinkowskiBroadcastMultiplication,
+ * layers/eca_block.py:21-36,66-71); NULL: plain ME BasicBlock tail (out += residual; relu). */
+int egonn_block_tail(egonn_ctx* ctx, int level, const float* x, const float* residual, int channels,
+                     const float* eca_weight, int eca_ksize, float* out, void* stream);
+/* SparseTensor + SparseTensor on the same coordinate map (models/minkfpn.py:91, models/minkgl.py:56). */
+int egonn_add(const float* a, const float* b, int64_t n, float* out, void* stream);
+/* batch['features'] (caller row order of egonn_coords_set) -> plan row order, (N0, channels). */
+int egonn_gather_input(egonn_ctx* ctx, const float* features, int channels, float* out, void* stream);
+/* GeM pooling (layers/pooling.py:82-86, third_party/minkloc3d/minkloc.py:47-59): out (B, channels). */
+int egonn_gem(egonn_ctx* ctx, int level, const float* x, int channels, const float* p, float* out, void* stream);
+
 /* ------------------------------------------------------------------ model
  * replaces model_factory(...) / MinkGL.forward: models/model_factory.py:31-76, models/minkgl.py:267-315       */
 int egonn_model_create(egonn_model** model);

@@ -282,3 +282,64 @@ def compute_embedding(oracle: EgoNNOracle, pc: np.ndarray, n_k: int = 128):
     y = oracle.forward(bc, np.ones((len(bc), 1), dtype=F32))
     idx = select_keypoints(y["sigma"][0], y["keypoint_coords"][0], n_k)
     return y["global"], y["keypoints"][0][idx], y["descriptors"][0][idx], y["keypoint_coords"][0][idx]
+
+
+# ----------------------------------------------------------------------------- MinkLoc / MinkLoc3D (MinkFPN + GeM)
+class MinkLocOracle:
+    """reference models/minkfpn.py:65-93 (MinkFPN.forward) + GeM, as used by models/minkloc.py:44-61 and
+    third_party/minkloc3d/minkloc.py:22-33.  `gem_key` is 'pooling.p' (MinkLoc3D) or 'pooling.pooling.p' (MinkLoc);
+    blocks are ME BasicBlocks, with the ECA gate when the state_dict holds '...eca.conv.weight'."""
+
+    def __init__(self, state_dict: Dict[str, np.ndarray], planes=(32, 64, 64), layers=(1, 1, 1), num_top_down=1):
+        self.sd = {k: np.asarray(v) for k, v in state_dict.items()}
+        self.planes, self.layers, self.num_top_down = list(planes), list(layers), num_top_down
+        self.gem_key = "pooling.p" if "pooling.p" in self.sd else "pooling.pooling.p"
+
+    def _block(self, x, lv: SparseLevels, level: int, prefix: str):
+        sd = self.sd
+        maps = lv.kmap(level, level, 3)
+        n = lv.n(level)
+        out = relu(batchnorm_eval(ops.conv_forward(x, sd[prefix + ".conv1.kernel"], maps, n), sd, prefix + ".norm1"))
+        out = batchnorm_eval(ops.conv_forward(out, sd[prefix + ".conv2.kernel"], maps, n), sd, prefix + ".norm2")
+        if (prefix + ".eca.conv.weight") in sd:
+            c4 = lv.coords[level]
+            y = ops.global_avg_pool(out, c4, lv.batch_size)
+            y = sigmoid(conv1d_channels(y, sd[prefix + ".eca.conv.weight"].reshape(-1)))
+            out = ops.broadcast_mul(out, c4, y)
+        if (prefix + ".downsample.0.kernel") in sd:
+            res = batchnorm_eval((x @ sd[prefix + ".downsample.0.kernel"]).astype(F32), sd, prefix + ".downsample.1")
+        else:
+            res = x
+        return relu(out + res)
+
+    def backbone(self, coords, features):
+        sd = self.sd
+        nb = len(self.planes)
+        lv = SparseLevels(np.asarray(coords, dtype=np.int32), n_levels=nb)
+        x = ops.conv_forward(np.asarray(features, dtype=F32), sd["backbone.conv0.kernel"], lv.kmap(0, 0, 5), lv.n(0))
+        x = relu(batchnorm_eval(x, sd, "backbone.bn0"))
+        fmaps = []
+        if self.num_top_down == nb:
+            fmaps.append(x)
+        for ndx in range(nb):
+            x = ops.conv_forward(x, sd[f"backbone.convs.{ndx}.kernel"], lv.kmap(ndx, ndx + 1, 2), lv.n(ndx + 1))
+            x = relu(batchnorm_eval(x, sd, f"backbone.bn.{ndx}"))
+            for b in range(self.layers[ndx]):
+                x = self._block(x, lv, ndx + 1, f"backbone.blocks.{ndx}.{b}")
+            if nb - 1 - self.num_top_down <= ndx < nb - 1:
+                fmaps.append(x)
+        x = (x @ sd["backbone.conv1x1.0.kernel"]).astype(F32)
+        level = nb
+        for ndx in range(self.num_top_down):
+            x = ops.conv_transpose_forward(x, sd[f"backbone.tconvs.{ndx}.kernel"], lv.kmap(level - 1, level, 2),
+                                           lv.n(level - 1))
+            level -= 1
+            x = (x + fmaps[-ndx - 1] @ sd[f"backbone.conv1x1.{ndx + 1}.kernel"]).astype(F32)
+        return lv, level, x
+
+    def forward(self, coords, features):
+        lv, level, x = self.backbone(coords, features)
+        p = F32(self.sd[self.gem_key].reshape(-1)[0])
+        t = np.power(np.maximum(x, F32(1e-6)), p).astype(F32)
+        t = ops.global_avg_pool(t, lv.coords[level], lv.batch_size)
+        return {"global": np.power(t, F32(1.0) / p).astype(F32), "_coords": lv.coords[level], "_feats": x}

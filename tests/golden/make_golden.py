@@ -48,6 +48,25 @@ def model_params(coordinates: str, step):
     return mp
 
 
+def minkloc_params(model: str, step: str, block: str = "BasicBlock"):
+    from misc.utils import ModelParams
+    f = tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False)
+    f.write(f"[MODEL]\nmodel = {model}\ncoordinates = cartesian\nquantization_step = {step}\n"
+            f"planes = 32,64,64\nlayers = 1,1,1\nnum_top_down = 1\nconv0_kernel_size = 5\nfeature_size = 256\n"
+            f"block = {block}\npooling = GeM\n")
+    f.close()
+    mp = ModelParams(f.name)
+    os.unlink(f.name)
+    return mp
+
+
+MINKLOC_CASES = [
+    # name,                 model,       block,            step,  scans,                      weight seed
+    ("minkloc3d_cart03_b2", "MinkLoc3D", "BasicBlock",     "0.3", [(7, 30000), (8, 20000)],  21),
+    ("minkloc_eca_cart03",  "MinkLoc",   "ECABasicBlock",  "0.3", [(9, 30000)],              22),
+]
+
+
 def kitti_like_filter(pc):
     """drop all-zero points, keep z > -1.5 (reference datasets/kitti/kitti_raw.py:12-14,
     misc/point_clouds.py:103-109) — applied to the synthetic cloud of the C0 case."""
@@ -134,6 +153,40 @@ def main():
         np.savez_compressed(path, **out)
         print(name, "voxels", bc.shape[0], "keypoints", [len(k) for k in y["keypoints"]],
               f"{os.path.getsize(path) / 1e6:.2f} MB")
+
+    # ---- MinkLoc3D / MinkLoc (MinkFPN backbone + GeM): reference models/minkfpn.py, models/minkloc.py,
+    #      third_party/minkloc3d/minkloc.py executed on the stand-in
+    for name, mname, block, step, scans, wseed in MINKLOC_CASES:
+        mp = minkloc_params(mname, step, block)
+        model = model_factory(mp)
+        model.eval()
+        sd = model.state_dict()
+        shapes = {k: [int(s) for s in v.shape] for k, v in sd.items()}
+        with open(os.path.join(HERE, f"{name}_state_dict_shapes.json"), "w") as f:
+            json.dump(shapes, f, indent=0)                      # insertion order = reference state_dict order
+        new = seeded_state_dict(wseed, {k: tuple(v) for k, v in shapes.items()})
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()})
+        out = {"weight_seed": np.int64(wseed), "coordinates": np.array("cartesian"), "block": np.array(block),
+               "model": np.array(mname), "quantization_step": np.array([float(step)]), "n_scans": np.int64(len(scans))}
+        coords_list = []
+        for b, (seed, n) in enumerate(scans):
+            pc = kitti_like_filter(lidar_scan(seed, n_points=n))
+            coords, _ = mp.quantizer(torch.from_numpy(pc))
+            coords_list.append(coords)
+        bc = ME.utils.batched_coordinates(coords_list)
+        feats = torch.ones((bc.shape[0], 1), dtype=torch.float32)
+        with torch.no_grad():
+            y = model({"coords": bc, "features": feats})
+            xb = model.backbone(ME.SparseTensor(feats, coordinates=bc))
+        out["coords"] = bc.numpy().astype(np.int32)
+        out["global"] = y["global"].numpy()
+        c = xb.C.numpy().astype(np.int32)
+        order = np.lexsort((c[:, 3], c[:, 2], c[:, 1], c[:, 0]))
+        out["backbone_coords"] = c[order]
+        out["backbone_feats"] = xb.F.numpy()[order].astype(np.float16)      # (N2, 256): stored as fp16 to stay small
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(name, "voxels", bc.shape[0], "backbone rows", len(c), f"{os.path.getsize(path) / 1e6:.2f} MB")
 
 
 if __name__ == "__main__":

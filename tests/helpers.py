@@ -18,14 +18,17 @@ def load_case(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 
 
-def state_dict_shapes():
-    with open(os.path.join(GOLDEN, "egonn_state_dict_shapes.json")) as f:
-        return {k: tuple(v) for k, v in json.load(f).items()}
+MINKLOC_CASES = ["minkloc3d_cart03_b2", "minkloc_eca_cart03"]
 
 
-def seeded_weights(seed):
+def state_dict_shapes(name="egonn"):
+    with open(os.path.join(GOLDEN, f"{name}_state_dict_shapes.json")) as f:
+        return {k: tuple(v) for k, v in json.load(f).items()}        # dict order = reference state_dict order
+
+
+def seeded_weights(seed, name="egonn"):
     from egonn_amd.synth import seeded_state_dict
-    return seeded_state_dict(int(seed), state_dict_shapes())
+    return seeded_state_dict(int(seed), state_dict_shapes(name))
 
 
 def rowkey(c4):

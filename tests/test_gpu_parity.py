@@ -436,3 +436,26 @@ def test_streamed_batches_equal_sequential(gpu):
         for a, b in zip(seq, got):
             for k in ("global", "keypoints", "descriptors", "count", "rows"):
                 assert torch.equal(a[k], b[k]), (n_streams, k)
+
+
+@pytest.mark.parametrize("name", H.MINKLOC_CASES)
+def test_minkloc_forward_matches_reference_graph(gpu, name):
+    """row a12: MinkFPN backbone + GeM through the per-operator C ABI vs the reference graph fixtures."""
+    case = H.load_case(name)
+    if str(case["model"]) == "MinkLoc3D":
+        mp = gpu.ModelParams(model="MinkLoc3D", coordinates="cartesian", quantization_step=0.3)
+    else:
+        mp = gpu.ModelParams(model="MinkLoc", coordinates="cartesian", quantization_step=0.3, block=str(case["block"]))
+    m = gpu.model_factory(mp)
+    w = H.seeded_weights(case["weight_seed"], name)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    m = m.to("cuda").eval()
+    c4 = case["coords"]
+    order = np.random.default_rng(3).permutation(len(c4))
+    y = m({"coords": torch.from_numpy(c4[order]), "features": torch.ones((len(c4), 1))})
+    g = _np(y["global"])
+    assert g.shape == case["global"].shape and set(y.keys()) == {"global"}
+    assert H.cosine_err(g, case["global"]).max() < 1e-4
+    np.testing.assert_allclose(g, case["global"], rtol=1e-3, atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        m.train()(  {"coords": torch.from_numpy(c4), "features": torch.ones((len(c4), 1))})

@@ -82,3 +82,19 @@ def test_synthetic_generator_is_deterministic():
     assert a.shape == (5000, 3) and a.dtype.name == "float32" and (a == b).all()
     case = H.load_case("egonn_cart01_b1")
     assert (lidar_scan(3, 12000) == case["points_0"]).all()      # fixtures are reproducible from the seed
+
+
+@pytest.mark.parametrize("name,kind", [("minkloc3d_cart03_b2", "MinkLoc3D"), ("minkloc_eca_cart03", "MinkLoc")])
+def test_minkloc_state_dict_matches_reference(built, name, kind):
+    """MinkLoc3D / MinkLoc(ECABasicBlock): same keys, shapes AND order as the reference modules."""
+    import egonn_amd
+    if kind == "MinkLoc3D":
+        m = egonn_amd.model_factory(egonn_amd.ModelParams(model="MinkLoc3D", coordinates="cartesian", quantization_step=0.3))
+    else:
+        m = egonn_amd.model_factory(egonn_amd.ModelParams(model="MinkLoc", coordinates="cartesian", quantization_step=0.3,
+                                                         block="ECABasicBlock", planes="32,64,64", layers="1,1,1"))
+    sd = m.state_dict()
+    ref = H.state_dict_shapes(name)
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == ref[k], k

@@ -127,3 +127,16 @@ def test_forward_matches_reference_graph(name):
         assert np.array_equal(sel_sigma, case[f"topk_sigma_{b}"])
         if len(np.unique(sel_sigma)) == len(sel_sigma):      # no ties -> order is fully determined
             assert np.array_equal(case[f"kp_coords_{b}"][idx], case[f"topk_coords_{b}"])
+
+
+@pytest.mark.parametrize("name", H.MINKLOC_CASES)
+def test_minkloc_oracle_matches_reference_graph(name):
+    """MinkFPN + GeM (models/minkfpn.py, models/minkloc.py, third_party/minkloc3d/minkloc.py)."""
+    case = H.load_case(name)
+    oracle = ref.MinkLocOracle(H.seeded_weights(case["weight_seed"], name))
+    c4 = case["coords"]
+    y = oracle.forward(c4, np.ones((len(c4), 1), np.float32))
+    assert H.cosine_err(y["global"], case["global"]).max() < 1e-6
+    np.testing.assert_allclose(y["global"], case["global"], rtol=1e-4, atol=1e-5)
+    perm = H.join_perm(y["_coords"], case["backbone_coords"])
+    np.testing.assert_allclose(y["_feats"][perm], case["backbone_feats"].astype(np.float32), rtol=2e-3, atol=2e-3)
