@@ -45,6 +45,8 @@ _SIGS = [
     ("egonn_forward", C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_float), C.c_int, _P, _P, _P, _P, _P]),
     ("egonn_forward_level_features", C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     ("egonn_select_keypoints", C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
+    ("egonn_triplet_loss_scratch_floats", C.c_int64, [C.c_int]),
+    ("egonn_triplet_loss", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
     ("egonn_profile_enable", C.c_int, [_P, C.c_int, C.c_char_p]),
     ("egonn_profile_fetch", C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.POINTER(C.c_float),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),

@@ -51,4 +51,9 @@ int topk_select(Ctx* ctx, const float* sigma, const int32_t* boff_dev, const int
 int gather_topk(const int32_t* sel_rows, const int32_t* sel_count, int B, int k, const float* kp, const float* desc,
                 int dc, float* out_kp, float* out_desc, hipStream_t stream);
 
+// loss.hip ---------------------------------------------------------------------------------------
+size_t triplet_loss_scratch_floats(int n);
+int triplet_loss_forward(const float* emb, int n, int d, const uint8_t* pos, const uint8_t* neg, float margin,
+                         float* out10, int32_t* triplets, float* grad, float* scratch, hipStream_t stream);
+
 }  // namespace egonn

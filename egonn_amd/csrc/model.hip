@@ -725,3 +725,16 @@ API int egonn_profile_fetch(egonn_ctx* c, int cap, int* n, char* names, float* m
   *n = w;
   return EGONN_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------ batch-hard triplet loss
+API int64_t egonn_triplet_loss_scratch_floats(int n) { return (int64_t)triplet_loss_scratch_floats(n); }
+
+API int egonn_triplet_loss(const float* embeddings, int n, int d, const uint8_t* positives_mask,
+                           const uint8_t* negatives_mask, float margin, float* out_stats, int32_t* out_triplets,
+                           float* out_grad, float* scratch, void* stream) {
+  EGONN_REQUIRE(embeddings && positives_mask && negatives_mask && out_stats && out_triplets && scratch, EGONN_ERR_INVALID,
+                "triplet_loss: null argument");
+  return triplet_loss_forward(embeddings, n, d, positives_mask, negatives_mask, margin, out_stats, out_triplets, out_grad,
+                              scratch, (hipStream_t)stream);
+}

@@ -85,3 +85,39 @@ class DatabaseBuilder:
         if keep_local and kps:
             result.update(keypoints=torch.cat(kps), descriptors=torch.cat(descs), count=torch.cat(counts))
         return result
+
+
+class _AllGatherEmbeddings(torch.autograd.Function):
+    """Forward: all-gather of the per-rank (b_local, D) global descriptors into the (B, D) matrix the batch-hard
+    miner needs (training/trainer.py:163-165 computes the loss on the whole batch).  Backward: every rank evaluates
+    the SAME loss on the SAME gathered matrix, so dLoss/dE is identical everywhere and each rank keeps the rows it
+    produced — no second collective; the later SUM all-reduce of parameter gradients then yields the full-batch
+    gradient."""
+
+    @staticmethod
+    def forward(ctx, local):
+        rank, world = _world()
+        ctx.n_local = local.shape[0]
+        if world == 1:
+            ctx.lo = 0
+            return local.clone()
+        counts = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        all_counts = [torch.zeros_like(counts) for _ in range(world)]
+        dist.all_gather(all_counts, counts)
+        sizes = [int(c.item()) for c in all_counts]
+        ctx.lo = sum(sizes[:rank])
+        mx = max(sizes)
+        pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad[ctx.lo: ctx.lo + ctx.n_local].contiguous()
+
+
+def all_gather_embeddings(local: torch.Tensor) -> torch.Tensor:
+    """(b_local, D) -> (sum b_local, D) on every rank, differentiable (see _AllGatherEmbeddings)."""
+    return _AllGatherEmbeddings.apply(local)

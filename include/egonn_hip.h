@@ -124,6 +124,19 @@ int egonn_select_keypoints(egonn_ctx* ctx, const float* sigma, const float* keyp
                            int n_k, float* sel_keypoints, float* sel_descriptors, int32_t* sel_rows,
                            int32_t* sel_count, void* stream);
 
+/* ------------------------------------------------------------------ batch-hard triplet loss (training, configs[3])
+ * replaces BatchHardTripletLossWithMasks.__call__ (models/loss.py:146-172; miner :114-143; the distance / loss /
+ * reducer it calls are pytorch_metric_learning's LpDistance(p=2), TripletMarginLoss(swap=True), AvgNonZeroReducer).
+ * embeddings (n,d) f32 — in the sharded step the RCCL all-gathered matrix; masks (n,n) u8.
+ * out_stats (10 f32, device): loss, num_triplets, num_non_zero_triplets, avg_embedding_norm, mean/max/min hardest
+ * positive distance, mean/max/min hardest negative distance.  out_triplets (n,3) i32: anchor (or -1 if dropped),
+ * hardest positive, hardest negative.  out_grad (n,d) nullable: dLoss/dEmbeddings.  scratch: device floats,
+ * egonn_triplet_loss_scratch_floats(n) of them.  No host sync. */
+int64_t egonn_triplet_loss_scratch_floats(int n);
+int egonn_triplet_loss(const float* embeddings, int n, int d, const uint8_t* positives_mask,
+                       const uint8_t* negatives_mask, float margin, float* out_stats, int32_t* out_triplets,
+                       float* out_grad, float* scratch, void* stream);
+
 /* ------------------------------------------------------------------ launch timing (bench.py roofline leg)
  * mode 0: off; 1: time every tagged sparse-conv launch; 2: only launches whose tag contains `filter`.
  * Timing = HIP events recorded on the caller's stream around the launch. */

@@ -343,3 +343,32 @@ class MinkLocOracle:
         t = np.power(np.maximum(x, F32(1e-6)), p).astype(F32)
         t = ops.global_avg_pool(t, lv.coords[level], lv.batch_size)
         return {"global": np.power(t, F32(1.0) / p).astype(F32), "_coords": lv.coords[level], "_feats": x}
+
+
+# ----------------------------------------------------------------------------- batch-hard triplet loss
+def batch_hard_triplet_loss(emb: np.ndarray, pos_mask: np.ndarray, neg_mask: np.ndarray, margin: float):
+    """reference models/loss.py:114-172 — miner (in-tree: get_max_per_row / get_min_per_row :132-143) + the
+    pytorch_metric_learning pieces it calls, restated per SURVEY.md Appendix A.9 (parity unpinned for those):
+    LpDistance(p=2), TripletMarginLoss(margin, swap=True), AvgNonZeroReducer.  Returns (loss, stats, (a, p, n))."""
+    e = np.asarray(emb, dtype=np.float64)
+    n = len(e)
+    diff = e[:, None, :] - e[None, :, :]
+    D = np.sqrt((diff * diff).sum(-1))
+    pm, nm = np.asarray(pos_mask, bool), np.asarray(neg_mask, bool)
+    mp = np.where(pm, D, 0.0)
+    mn = np.where(nm, D, np.inf)
+    hp_idx, hn_idx = mp.argmax(1), mn.argmin(1)
+    hp, hn = mp.max(1), mn.min(1)
+    keep = pm.any(1) & nm.any(1)
+    a = np.arange(n)[keep]
+    p, q = hp_idx[keep], hn_idx[keep]
+    d_ap, d_an = D[a, p], np.minimum(D[a, q], D[p, q])
+    li = np.maximum(d_ap - d_an + margin, 0.0)
+    nz = int((li > 0).sum())
+    loss = float(li[li > 0].mean()) if nz else 0.0
+    stats = {"loss": loss, "num_triplets": int(len(a)), "num_non_zero_triplets": nz,
+             "avg_embedding_norm": float(np.linalg.norm(e, axis=1).mean()),
+             "mean_pos_pair_dist": float(hp.mean()), "max_pos_pair_dist": float(hp.max()),
+             "min_pos_pair_dist": float(hp.min()), "mean_neg_pair_dist": float(hn.mean()),
+             "max_neg_pair_dist": float(hn.max()), "min_neg_pair_dist": float(hn.min())}
+    return loss, stats, (a, p, q)

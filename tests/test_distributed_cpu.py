@@ -79,3 +79,37 @@ def test_database_build_world2_gloo(n_scans):
 def test_all_gather_rows_single_process():
     x = torch.arange(12.0).reshape(4, 3)
     assert torch.equal(all_gather_rows(x, 4), x)
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from egonn_amd.distributed import all_gather_embeddings
+        torch.manual_seed(0)
+        full = torch.randn(7, 5)
+        lo, hi = (0, 4) if rank == 0 else (4, 7)                     # ragged shards
+        local = full[lo:hi].clone().requires_grad_(True)
+        g = all_gather_embeddings(local)
+        w = torch.arange(35.0).reshape(7, 5)
+        (g * w).sum().backward()                                      # same "loss" on every rank
+        q.put((rank, g.detach().numpy(), local.grad.numpy(), w[lo:hi].numpy(), full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_embeddings_autograd_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, g, grad, want_grad, full in got:
+        assert np.array_equal(g, full)                 # every rank sees the whole batch, rank order
+        assert np.array_equal(grad, want_grad)         # and back-propagates exactly its own rows

@@ -459,3 +459,31 @@ def test_minkloc_forward_matches_reference_graph(gpu, name):
     np.testing.assert_allclose(g, case["global"], rtol=1e-3, atol=1e-4)
     with pytest.raises(NotImplementedError):
         m.train()(  {"coords": torch.from_numpy(c4), "features": torch.ones((len(c4), 1))})
+
+
+def test_triplet_loss_matches_oracle(gpu):
+    """row a13 (forward + dLoss/dE): HIP batch-hard triplet loss vs the oracle and vs torch autograd of the same
+    formula on the CPU."""
+    from oracle import egonn_ref as ref
+    from egonn_amd.loss import BatchHardTripletLossWithMasks
+    rng = np.random.default_rng(5)
+    for n, d in ((64, 256), (200, 256), (7, 32)):
+        e = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
+        lab = rng.integers(0, max(2, n // 6), n)
+        pm = (lab[:, None] == lab[None, :]) & ~np.eye(n, dtype=bool)
+        nm = lab[:, None] != lab[None, :]
+        pm[0] = False
+        et = torch.from_numpy(e).cuda().requires_grad_(True)
+        loss, stats, (a, p, q) = BatchHardTripletLossWithMasks(0.2)(et, torch.from_numpy(pm), torch.from_numpy(nm))
+        want, wstats, (wa, wp, wq) = ref.batch_hard_triplet_loss(e, pm, nm, 0.2)
+        assert np.array_equal(_np(a), wa) and np.array_equal(_np(p), wp) and np.array_equal(_np(q), wq)
+        assert abs(float(loss) - want) < 1e-5
+        for k, v in wstats.items():
+            assert abs(stats[k] - v) <= 1e-4 * max(1.0, abs(v)), k
+        loss.backward()
+        ec = torch.from_numpy(e).double().requires_grad_(True)
+        D = torch.cdist(ec, ec, p=2)
+        ta, tp_, tq = (torch.from_numpy(x) for x in (wa, wp, wq))
+        li = torch.relu(D[ta, tp_] - torch.minimum(D[ta, tq], D[tp_, tq]) + 0.2)
+        (li[li > 0].mean() if (li > 0).any() else li.sum() * 0).backward()
+        np.testing.assert_allclose(_np(et.grad), ec.grad.numpy(), rtol=1e-3, atol=1e-6)

@@ -140,3 +140,33 @@ def test_minkloc_oracle_matches_reference_graph(name):
     np.testing.assert_allclose(y["global"], case["global"], rtol=1e-4, atol=1e-5)
     perm = H.join_perm(y["_coords"], case["backbone_coords"])
     np.testing.assert_allclose(y["_feats"][perm], case["backbone_feats"].astype(np.float32), rtol=2e-3, atol=2e-3)
+
+
+def test_triplet_miner_matches_reference_formulas():
+    """The in-tree miner of models/loss.py:114-143 is plain torch (its file cannot be imported because of the
+    pytorch_metric_learning import at the top), so its formulas are evaluated with torch here and compared with
+    the oracle's index choice."""
+    rng = np.random.default_rng(0)
+    n = 40
+    e = rng.standard_normal((n, 16)).astype(np.float32)
+    lab = rng.integers(0, 6, n)
+    pm = (lab[:, None] == lab[None, :]) & ~np.eye(n, dtype=bool)
+    nm = (np.abs(lab[:, None] - lab[None, :]) >= 2)
+    pm[3] = False                                              # anchor without positives is dropped
+    D = torch.cdist(torch.from_numpy(e), torch.from_numpy(e), p=2)
+    tp, tn = torch.from_numpy(pm), torch.from_numpy(nm)
+    mm = D.clone(); mm[~tp] = 0
+    (hpd, hpi) = torch.max(mm, dim=1)
+    mm = D.clone(); mm[~tn] = float('inf')
+    (hnd, hni) = torch.min(mm, dim=1)
+    keep = torch.any(tp, dim=1) & torch.any(tn, dim=1)
+    loss, stats, (a, p, q) = ref.batch_hard_triplet_loss(e, pm, nm, 0.2)
+    assert np.array_equal(a, torch.where(keep)[0].numpy())
+    assert np.array_equal(p, hpi[keep].numpy()) and np.array_equal(q, hni[keep].numpy())
+    assert abs(stats["max_pos_pair_dist"] - hpd.max().item()) < 1e-5
+    assert abs(stats["mean_neg_pair_dist"] - hnd.mean().item()) < 1e-5
+    # swap + AvgNonZero (Appendix A.9), evaluated with torch
+    d_ap, d_an, d_pn = D[a, p], D[a, q], D[p, q]
+    li = torch.relu(d_ap - torch.minimum(d_an, d_pn) + 0.2)
+    want = li[li > 0].mean().item() if (li > 0).any() else 0.0
+    assert abs(loss - want) < 1e-5
