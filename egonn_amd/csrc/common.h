@@ -118,6 +118,9 @@ struct Plan {
   int64_t n_input = 0;        // rows/points handed in by the caller
   Level lv[EGONN_MAX_LEVELS];
   int32_t* perm0 = nullptr;   // [n0] caller row / point index that became sorted row i (first occurrence)
+  int32_t* g0 = nullptr;      // [n0] level-2 row (4x4x4 block) of every level-0 row
+  uint64_t* t2m = nullptr;    // [n2][27] occupancy masks of the 27 blocks around every level-2 row (0 = absent)
+  int32_t* t2s = nullptr;     // [n2][27] first level-0 row of those blocks
   std::vector<int32_t> boff_host[EGONN_NUM_LEVELS];   // host copies of boff (size B+1)
 };
 
@@ -139,6 +142,7 @@ struct Profiler {
 
 struct Ctx {
   Profiler prof;
+  uint16_t* conv0_lut = nullptr;             // first-layer lookup table (64 positions x 128 offsets), built on first use
   unsigned long long* dev_pairs = nullptr;   // [16] kernel-map pair counters: [0] conv0 k5, [l] k3 map of level l
   int device = 0;
   int coord_bits = 16;

@@ -451,6 +451,22 @@ int count_map_pairs(Ctx* ctx, hipStream_t stream) {
   return EGONN_OK;
 }
 
+// first-layer helpers: level-2 block of every level-0 row, and per block the (mask, first row) of its 27 neighbours
+__global__ void grandparent_kernel(const int32_t* __restrict__ parent0, const int32_t* __restrict__ parent1, int32_t n,
+                                   int32_t* __restrict__ g0) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) g0[i] = parent1[parent0[i]];
+}
+__global__ void blk27_kernel(const int32_t* __restrict__ badj, const uint64_t* __restrict__ bmask,
+                             const int32_t* __restrict__ bstart, int32_t n27, uint64_t* __restrict__ t2m,
+                             int32_t* __restrict__ t2s) {
+  const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n27) return;
+  const int32_t a = badj[t];
+  t2m[t] = a >= 0 ? bmask[a] : 0ull;
+  t2s[t] = a >= 0 ? bstart[a] : 0;
+}
+
 // ------------------------------------------------------------------ k=2,s=2 tables
 __global__ void nbr8_kernel(const int32_t* __restrict__ cstart, const uint64_t* __restrict__ ckeys, int32_t n,
                             int32_t* __restrict__ nbr8) {
@@ -595,6 +611,19 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
                          Bk.bstart, (int32_t)Bk.n, nv, V.nbr27);
     }
   }
+  {   // first-layer (k=5) helpers
+    const int32_t n0 = (int32_t)P.lv[0].n, n2 = (int32_t)P.lv[2].n;
+    P.g0 = A.alloc<int32_t>(n0);
+    P.t2m = A.alloc<uint64_t>((size_t)n2 * 27);
+    P.t2s = A.alloc<int32_t>((size_t)n2 * 27);
+    EGONN_REQUIRE(P.g0 && P.t2m && P.t2s, EGONN_ERR_STATE, "plan arena too small");
+    if (n0 > 0) {
+      hipLaunchKernelGGL(grandparent_kernel, dim3((unsigned)cdiv(n0, 256)), dim3(256), 0, stream, P.lv[0].parent,
+                         P.lv[1].parent, n0, P.g0);
+      hipLaunchKernelGGL(blk27_kernel, dim3((unsigned)cdiv((int64_t)n2 * 27, 256)), dim3(256), 0, stream, P.lv[2].nbr27,
+                         P.lv[2].mask, P.lv[2].bstart, n2 * 27, P.t2m, P.t2s);
+    }
+  }
   for (int l = 1; l < EGONN_NUM_LEVELS; ++l) {
     Level& V = P.lv[l];
     const int32_t nv = (int32_t)V.n;
@@ -614,7 +643,7 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
 
 static size_t plan_arena_bytes(int64_t n, int B) {
   // raw+sorted keys/vals, 10 levels x (keys, parent, cstart, mask, bstart), perm, maps of levels 1..7 (<= n rows each)
-  size_t per_row = 2 * (8 + 4) + NL * (8 + 4 + 4 + 8 + 4) + 4 + 9 * 27 * 4 + 7 * (8 + 8) * 4;
+  size_t per_row = 2 * (8 + 4) + NL * (8 + 4 + 4 + 8 + 4) + 4 + 9 * 27 * 4 + 7 * (8 + 8) * 4 + 4 + 27 * 12;
   return (size_t)(n + 8) * per_row + (size_t)(B + 1) * 4 * EGONN_NUM_LEVELS + (size_t)cdiv(n, PYR_TILE) * NL * 4 +
          (1 << 20);
 }

@@ -118,6 +118,7 @@ API void egonn_ctx_destroy(egonn_ctx* c) {
   if (c->host_counts) (void)hipHostFree(c->host_counts);
   if (c->dev_counts) (void)hipFree(c->dev_counts);
   if (c->dev_pairs) (void)hipFree(c->dev_pairs);
+  if (c->conv0_lut) (void)hipFree(c->conv0_lut);
   for (auto& r : c->prof.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : c->prof.pool) (void)hipEventDestroy(e);
   delete c;
@@ -519,7 +520,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
                       float* out_global, float* out_desc, float* out_kp, float* out_sigma, void* stream) {
   REQUIRE_PLAN(c);
   EGONN_REQUIRE(m && m->ready, EGONN_ERR_STATE, "model not finalized (call egonn_model_finalize)");
-  EGONN_REQUIRE(features && step, EGONN_ERR_INVALID, "forward: null argument");
+  EGONN_REQUIRE(step, EGONN_ERR_INVALID, "forward: null argument");
   HIP_CHECK(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
   const Plan& P = c->plan;
@@ -545,8 +546,8 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   WALLOC(scr, SCONV_SCRATCH_FLOATS);
   // ---- trunk (models/minkgl.py:136-153)
   const int64_t n0 = P.lv[0].n;
-  const float* f0 = features;          // voxelize plans: features are already in level-0 row order
-  if (!c->from_points) {
+  const float* f0 = features;          // voxelize plans: features are already in level-0 row order; NULL = all ones
+  if (features && !c->from_points) {
     WALLOC(fg, n0);
     EGONN_TRY(gather_rows(features, P.perm0, n0, 1, fg, st));
     f0 = fg;

@@ -66,9 +66,7 @@ class DescriptorExtractor:
         ctx = model.context(slot)
         q = self.quantizer
         ctx.voxelize(points, offsets, q.mode, q.step)
-        n0 = ctx.level_count(0)
-        feats = self._ones(n0, ctx.device)
-        y = model._forward_on_plan(ctx, feats)
+        y = model._forward_on_plan(ctx, None)          # unit features (eval/evaluate.py:334) -> occupancy-only conv0
         d, k, s = model._last_local
         sel_kp, sel_desc, rows, cnt = ctx.select_keypoints(s, k, d, self.n_k)
         return {'global': y['global'], 'keypoints': sel_kp, 'descriptors': sel_desc, 'count': cnt, 'rows': rows}

@@ -298,7 +298,7 @@ class MinkGL(nn.Module):
         q = self.quantizer
         step = (_lib.C.c_float * 3)(*([float(s) for s in q.step] + [0.0, 0.0])[:3])
         with torch.cuda.device(dev):
-            _lib.check(ctx.lib.egonn_forward(ctx.h, self._handle.h, feats.data_ptr(), q.mode, step, flags,
+            _lib.check(ctx.lib.egonn_forward(ctx.h, self._handle.h, _lib._ptr(feats), q.mode, step, flags,
                                              _lib._ptr(out_g), _lib._ptr(out_d), _lib._ptr(out_k), _lib._ptr(out_s),
                                              _lib._stream()))
         y = {}

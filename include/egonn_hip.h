@@ -106,7 +106,8 @@ int egonn_model_finalize(egonn_model* model, void* stream);
 
 /* Forward on the current plan.  features: for an egonn_coords_set plan (n_input, 1) f32 in the CALLER's row
  * order (batch['features'], eval/evaluate.py:334); for an egonn_voxelize plan (N0, 1) in level-0 row order
- * (the voxels did not exist before the call, so there is no caller order).  Outputs (caller-allocated, sizes from egonn_level_count):
+ * (the voxels did not exist before the call, so there is no caller order).  features == NULL means "all ones" (what
+ * the reference always feeds, eval/evaluate.py:334) and selects the occupancy-only first layer.  Outputs (caller-allocated, sizes from egonn_level_count):
  *   out_global (B,256) ; out_descriptors (N3,128) unit-L2 ; out_keypoints (N3,3) metres ; out_sigma (N3,1)
  * rows in level-3 row order (per-sample splits = egonn_level_batch_offsets(3)).  Any output may be NULL when
  * the corresponding head is disabled through `flags`.  quant_mode/step as in egonn_voxelize (needed for

@@ -477,7 +477,7 @@ def test_triplet_loss_matches_oracle(gpu):
         loss, stats, (a, p, q) = BatchHardTripletLossWithMasks(0.2)(et, torch.from_numpy(pm), torch.from_numpy(nm))
         want, wstats, (wa, wp, wq) = ref.batch_hard_triplet_loss(e, pm, nm, 0.2)
         assert np.array_equal(_np(a), wa) and np.array_equal(_np(p), wp) and np.array_equal(_np(q), wq)
-        assert abs(float(loss) - want) < 1e-5
+        assert abs(float(loss.detach()) - want) < 1e-5
         for k, v in wstats.items():
             assert abs(stats[k] - v) <= 1e-4 * max(1.0, abs(v)), k
         loss.backward()
@@ -487,3 +487,50 @@ def test_triplet_loss_matches_oracle(gpu):
         li = torch.relu(D[ta, tp_] - torch.minimum(D[ta, tq], D[tp_, tq]) + 0.2)
         (li[li > 0].mean() if (li > 0).any() else li.sum() * 0).backward()
         np.testing.assert_allclose(_np(et.grad), ec.grad.numpy(), rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("coordinates,step", [("polar", [1.0, 0.3, 0.2]), ("cartesian", 0.3)])
+def test_config0_kitti_shaped_scan(gpu, coordinates, step):
+    """BASELINE.json configs[0] as restated in SURVEY.md §8(d): one ~120k-point scan after KITTI-style filtering
+    (drop zero points, keep z > -1.5), polar (1 deg, 0.3 m, 0.2 m) and Cartesian 0.3 m, seeded weights, through the
+    whole path vs the CPU oracle."""
+    from egonn_amd.synth import lidar_scan
+    from oracle import egonn_ref as ref
+    pc = lidar_scan(1, n_points=120_000)
+    pc = pc[~np.all(pc == 0, axis=1)]
+    pc = pc[pc[:, 2] > -1.5]
+    m, w = _model(gpu, seed=51, coordinates=coordinates, step=step)
+    ex = gpu.DescriptorExtractor(m, n_k=128)
+    g, kp, desc = ex.compute_embedding(torch.from_numpy(pc))
+    q = ref.PolarQuantizer(step) if coordinates == "polar" else ref.CartesianQuantizer(step)
+    g_ref, kp_ref, desc_ref, kc_ref = ref.compute_embedding(ref.EgoNNOracle(w, q), pc, 128)
+    # polar bins can differ for points on a bin edge (atan2 ulp), which perturbs the descriptor slightly
+    tol = 1e-4 if coordinates == "cartesian" else 5e-4
+    assert H.cosine_err(g, g_ref).max() < tol
+    assert kp.shape == kp_ref.shape == (128, 3)
+    if coordinates == "cartesian":
+        same = np.isclose(kp.numpy(), kp_ref, atol=2e-3).all(axis=1)
+        assert same.mean() > 0.9
+        assert H.cosine_err(desc.numpy()[same], desc_ref[same]).max() < 1e-4
+
+
+def test_config4_database_build_mulran_shaped(gpu):
+    """BASELINE.json configs[4] on one GPU: MulRan-shaped scans (64 x 1024 returns, ground cut z > -0.9,
+    datasets/mulran/mulran_raw.py:15-25) streamed through DatabaseBuilder; rows keep scan order and equal the
+    per-scan extraction."""
+    from egonn_amd.synth import lidar_scan
+    from egonn_amd.distributed import DatabaseBuilder
+    m, _ = _model(gpu, seed=61)
+    ex = gpu.DescriptorExtractor(m, n_k=128)
+
+    def load(i):
+        pc = lidar_scan(7000 + i, n_points=65_536, n_azimuth=1024)
+        return torch.from_numpy(pc[pc[:, 2] > -0.9])
+
+    n = 11
+    db = DatabaseBuilder(ex, batch_size=4).build(load, n)
+    assert db["global"].shape == (n, 256) and db["count"].shape == (n,) and db["range"] == (0, n)
+    for i in (0, 5, 10):
+        solo = ex.extract([load(i)])
+        assert H.cosine_err(_np(solo["global"]), _np(db["global"][[i]])).max() < 1e-5
+        assert int(solo["count"][0]) == int(db["count"][i])
