@@ -137,6 +137,15 @@ def main():
         elapsed = float(tt.item())
 
     recs = ctx.profile_fetch()
+    # the same kernel with ONE batch in flight (after the timed region): rocprofv3 serialises dispatches of different
+    # streams, so its per-kernel average is this "exclusive" duration, not the one measured while three batches
+    # share the CUs
+    excl = []
+    if args.streams > 1:
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        excl = ctx.profile_fetch()
     ctx.profile_enable(0)
     n_levels = [ctx.level_count(l) for l in range(8)]
 
@@ -164,6 +173,13 @@ def main():
                     "launches": int(len(ms)), "avg_launch_us": round(float(ms.mean()) * 1e3, 2),
                     "algorithmic_bytes_per_launch": float(by.mean()),
                     "tflops": round(float(fl.mean() / (ms.mean() * 1e-3) / 1e12), 2)}
+        if excl:
+            ems = np.array([r[1] for r in excl]); eby = np.array([r[2] for r in excl])
+            ea = float(eby.mean() / (ems.mean() * 1e-3) / 1e9)
+            roofline["exclusive"] = {"note": "same kernel, one batch in flight, timed after the timed region; this is "
+                                             "what rocprofv3 --kernel-trace (which serialises streams) reports",
+                                     "avg_launch_us": round(float(ems.mean()) * 1e3, 2), "achieved": round(ea, 1),
+                                     "frac": round(ea / HBM_PEAK_GBS, 4)}
 
     # ---------------- optional per-layer table (outside the timed region)
     if args.layer_table and rank == 0:

@@ -157,10 +157,16 @@ struct Ctx {
 };
 
 // RAII launch timer: records events on `stream` around the enclosed launches when profiling is enabled.
+// In mode 2 the scope does not record anything itself: it parks its event pair in `prof_kernel_events()` and the
+// sparse-conv launcher attaches them to the kernel dispatch (hipExtLaunchKernelGGL start/stop events), so that the
+// elapsed time is the kernel's own begin..end — the figure rocprofv3 --kernel-trace reports — even when other
+// streams share the GPU.  Mode 1 brackets all launches of the scope with ordinary stream events.
+hipEvent_t* prof_kernel_events();     // thread-local [2]; {nullptr, nullptr} when no exact timing is requested
 struct ProfScope {
   Ctx* ctx;
   hipStream_t st;
   int idx = -1;
+  bool exact = false;
   ProfScope(Ctx* c, hipStream_t s, const char* name, int kind, int level, int K, int cin, int cout, int64_t n_in,
             int64_t n_out);
   ~ProfScope();

@@ -65,12 +65,27 @@ ProfScope::ProfScope(Ctx* c, hipStream_t s, const char* name, int kind, int leve
   r.kind = kind; r.level = level; r.K = K; r.cin = cin; r.cout = cout; r.n_in = n_in; r.n_out = n_out;
   r.e0 = c->prof.get();
   r.e1 = c->prof.get();
-  (void)hipEventRecord(r.e0, s);
+  exact = c->prof.mode == 2 && (kind == PK_K3 || kind == PK_K2S2);
+  if (exact) {
+    prof_kernel_events()[0] = r.e0;
+    prof_kernel_events()[1] = r.e1;
+  } else {
+    (void)hipEventRecord(r.e0, s);
+  }
   idx = (int)c->prof.recs.size();
   c->prof.recs.push_back(r);
 }
 ProfScope::~ProfScope() {
-  if (idx >= 0) (void)hipEventRecord(ctx->prof.recs[idx].e1, st);
+  if (idx < 0) return;
+  if (exact) {
+    prof_kernel_events()[0] = prof_kernel_events()[1] = nullptr;
+  } else {
+    (void)hipEventRecord(ctx->prof.recs[idx].e1, st);
+  }
+}
+hipEvent_t* prof_kernel_events() {
+  static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+  return ev;
 }
 
 // ------------------------------------------------------------------ key construction
