@@ -47,6 +47,19 @@ _SIGS = [
     ("egonn_select_keypoints", C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
     ("egonn_triplet_loss_scratch_floats", C.c_int64, [C.c_int]),
     ("egonn_triplet_loss", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
+    ("egonn_dense", C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
+    ("egonn_dense_backward_weight", C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, _P, _P, C.c_int64, _P]),
+    ("egonn_conv_backward_weight", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P,
+                                             C.c_int64, _P]),
+    ("egonn_col_stats", C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int, _P, _P, C.c_int64, _P]),
+    ("egonn_affine_act", C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P]),
+    ("egonn_affine3", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, _P, _P]),
+    ("egonn_relu_backward", C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P]),
+    ("egonn_gate_residual", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    ("egonn_gate_residual_backward", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P]),
+    ("egonn_segment_sums", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, C.c_int64, _P]),
+    ("egonn_segment_broadcast", C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
+    ("egonn_gem_backward", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P]),
     ("egonn_profile_enable", C.c_int, [_P, C.c_int, C.c_char_p]),
     ("egonn_profile_fetch", C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.POINTER(C.c_float),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
@@ -171,15 +184,18 @@ class Context:
     # ------------------------------------------------------------------ operators
     def conv(self, level_in: int, level_out: int, kernel_size: int, x: torch.Tensor, kernel: torch.Tensor,
              scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, relu: bool = False):
-        x = _dev_f32(x, self.device)
         kernel = _dev_f32(kernel, self.device)
         cin, cout = kernel.shape[-2], kernel.shape[-1]
-        assert x.shape == (self.level_count(level_in), cin), (x.shape, self.level_count(level_in), cin)
+        if x is None:
+            assert kernel_size == 5 and cin == 1, "x=None (all-ones features) is the k=5 input layer only"
+        else:
+            x = _dev_f32(x, self.device)
+            assert x.shape == (self.level_count(level_in), cin), (x.shape, self.level_count(level_in), cin)
         out = torch.empty((self.level_count(level_out), cout), dtype=torch.float32, device=self.device)
         sc = None if scale is None else _dev_f32(scale, self.device)
         sh = None if shift is None else _dev_f32(shift, self.device)
         with torch.cuda.device(self.device):
-            check(self.lib.egonn_conv(self.h, level_in, level_out, kernel_size, x.data_ptr(), cin, kernel.data_ptr(),
+            check(self.lib.egonn_conv(self.h, level_in, level_out, kernel_size, _ptr(x), cin, kernel.data_ptr(),
                                       cout, _ptr(sc), _ptr(sh), int(relu), out.data_ptr(), _stream()))
         return out
 
@@ -244,6 +260,117 @@ class Context:
         with torch.cuda.device(self.device):
             check(self.lib.egonn_gem(self.h, level, x.data_ptr(), x.shape[1], pp.data_ptr(), out.data_ptr(), _stream()))
         return out
+
+    # ------------------------------------------------------------------ training-mode operators (egonn_amd/train.py)
+    def scratch(self, nfloats: int) -> torch.Tensor:
+        """caller-owned scratch for the two-stage reductions (grown on demand, reused)."""
+        buf = getattr(self, "_scratch", None)
+        if buf is None or buf.numel() < nfloats:
+            buf = torch.empty(max(int(nfloats), 1 << 24), dtype=torch.float32, device=self.device)
+            self._scratch = buf
+        return buf
+
+    def _call(self, fn, *args):
+        with torch.cuda.device(self.device):
+            check(fn(*args, _stream()))
+
+    def dense(self, x, weight, out_in: bool, bias=None, act: int = 0):
+        x, weight = _dev_f32(x, self.device), _dev_f32(weight, self.device)
+        cin, cout = (weight.shape[1], weight.shape[0]) if out_in else (weight.shape[0], weight.shape[1])
+        assert x.dim() == 2 and x.shape[1] == cin, (x.shape, weight.shape, out_in)
+        b = None if bias is None else _dev_f32(bias, self.device)
+        out = torch.empty((x.shape[0], cout), dtype=torch.float32, device=self.device)
+        self._call(self.lib.egonn_dense, x.data_ptr(), x.shape[0], cin, weight.data_ptr(), int(out_in), _ptr(b), cout,
+                   act, out.data_ptr())
+        return out
+
+    def dense_backward_weight(self, a, b):
+        """a^T b over the rows: (ca, cb)."""
+        a, b = _dev_f32(a, self.device), _dev_f32(b, self.device)
+        assert a.shape[0] == b.shape[0]
+        ca, cb = a.shape[1], b.shape[1]
+        out = torch.empty((ca, cb), dtype=torch.float32, device=self.device)
+        sc = self.scratch(64 * ca * cb)
+        self._call(self.lib.egonn_dense_backward_weight, a.data_ptr(), ca, b.data_ptr(), cb, a.shape[0], out.data_ptr(),
+                   sc.data_ptr(), sc.numel())
+        return out
+
+    def conv_backward_weight(self, level_in, level_out, kernel_size, transposed, x, grad_out, kernel_shape):
+        g = _dev_f32(grad_out, self.device)
+        xx = None if x is None else _dev_f32(x, self.device)
+        cin, cout = kernel_shape[-2], kernel_shape[-1]
+        out = torch.empty(tuple(kernel_shape), dtype=torch.float32, device=self.device)
+        sc = self.scratch(16 * out.numel())
+        self._call(self.lib.egonn_conv_backward_weight, self.h, level_in, level_out, kernel_size, int(transposed), _ptr(xx),
+                   cin, g.data_ptr(), cout, out.data_ptr(), sc.data_ptr(), sc.numel())
+        return out
+
+    def col_stats(self, mode: int, a, b=None, mask=None, mean=None):
+        a = _dev_f32(a, self.device)
+        n, c = a.shape
+        out = torch.empty((2, c), dtype=torch.float32, device=self.device)
+        sc = self.scratch(2 * c * (n // 2048 + 2))
+        self._call(self.lib.egonn_col_stats, mode, a.data_ptr(), _ptr(b), _ptr(mask), _ptr(mean), n, c, out.data_ptr(),
+                   sc.data_ptr(), sc.numel())
+        return out
+
+    def affine_act(self, x, scale, shift, relu: bool):
+        x = _dev_f32(x, self.device)
+        out = torch.empty_like(x)
+        self._call(self.lib.egonn_affine_act, x.data_ptr(), scale.data_ptr(), shift.data_ptr(), x.shape[0], x.shape[1],
+                   int(relu), out.data_ptr())
+        return out
+
+    def affine3(self, g, mask, x, A, B, Cc):
+        g, x = _dev_f32(g, self.device), _dev_f32(x, self.device)
+        out = torch.empty_like(x)
+        self._call(self.lib.egonn_affine3, g.data_ptr(), _ptr(mask), x.data_ptr(), A.data_ptr(), B.data_ptr(),
+                   Cc.data_ptr(), x.shape[0], x.shape[1], out.data_ptr())
+        return out
+
+    def relu_backward(self, grad_out, out):
+        g = _dev_f32(grad_out, self.device)
+        dx = torch.empty_like(g)
+        self._call(self.lib.egonn_relu_backward, g.data_ptr(), out.data_ptr(), g.shape[0], g.shape[1], dx.data_ptr())
+        return dx
+
+    def gate_residual(self, level, x, gate, residual, relu: bool = True):
+        x = _dev_f32(x, self.device)
+        assert x.shape[0] == self.level_count(level)
+        out = torch.empty_like(x)
+        self._call(self.lib.egonn_gate_residual, self.h, level, x.data_ptr(), _ptr(gate), _ptr(residual), x.shape[1],
+                   int(relu), out.data_ptr())
+        return out
+
+    def gate_residual_backward(self, level, grad_out, out, gate, want_residual: bool = True):
+        g = _dev_f32(grad_out, self.device)
+        dx = torch.empty_like(g)
+        dres = torch.empty_like(g) if want_residual else None
+        self._call(self.lib.egonn_gate_residual_backward, self.h, level, g.data_ptr(), _ptr(out), _ptr(gate), g.shape[1],
+                   dx.data_ptr(), _ptr(dres))
+        return dx, dres
+
+    def segment_sums(self, level, mode, a, b=None, x2=None, p=None):
+        a = _dev_f32(a, self.device)
+        c = a.shape[1]
+        out = torch.empty((self.batch_size, c), dtype=torch.float32, device=self.device)
+        sc = self.scratch(32 * self.batch_size * c)
+        self._call(self.lib.egonn_segment_sums, self.h, level, mode, a.data_ptr(), _ptr(b), _ptr(x2), _ptr(p), c,
+                   out.data_ptr(), sc.data_ptr(), sc.numel())
+        return out
+
+    def segment_broadcast(self, level, v, mean: bool):
+        v = _dev_f32(v, self.device)
+        out = torch.empty((self.level_count(level), v.shape[1]), dtype=torch.float32, device=self.device)
+        self._call(self.lib.egonn_segment_broadcast, self.h, level, v.data_ptr(), v.shape[1], int(mean), out.data_ptr())
+        return out
+
+    def gem_backward(self, level, x, coef, p):
+        x, coef = _dev_f32(x, self.device), _dev_f32(coef, self.device)
+        dx = torch.empty_like(x)
+        self._call(self.lib.egonn_gem_backward, self.h, level, x.data_ptr(), coef.data_ptr(), p.data_ptr(), x.shape[1],
+                   dx.data_ptr())
+        return dx
 
     def forward_level_features(self, level: int, channels: int) -> torch.Tensor:
         out = torch.empty((self.level_count(level), channels), dtype=torch.float32, device=self.device)

@@ -172,6 +172,8 @@ struct ProfScope {
   ~ProfScope();
 };
 
+int ensure_level0_parent_table(Ctx* ctx, hipStream_t stream);   // coords.hip
+
 // ------------------------------------------------------------------ sort.hip
 // LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits).  Result lands in (keys_out, vals_out).
 // Stable.  keys_in/vals_in are clobbered.  Scratch comes from ctx->sort_arena.

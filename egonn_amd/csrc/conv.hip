@@ -419,7 +419,7 @@ int sconv_forward(const float* in, int64_t n_in, const int32_t* nbr, const float
   if (n_out == 0) return EGONN_OK;
   EGONN_REQUIRE(K == 27 || K == 8, EGONN_ERR_INVALID, "sconv: kernel volume %d not supported", K);
   const bool mfma_shape = (cin == 32 && (cout == 32 || cout == 64)) || (cin == 64 && (cout == 64 || cout == 128)) ||
-                          (cin == 128 && cout == 128);
+                          (cin == 128 && cout == 128) || (cin == 64 && cout == 32) || (cin == 128 && cout == 64);
   if (!g_force_naive && mfma_shape) {
     if (!Wp) {   // stand-alone operator call: pack into the tail of the scratch buffer
       const size_t wn = (size_t)K * cin * cout;
@@ -438,6 +438,8 @@ int sconv_forward(const float* in, int64_t n_in, const int32_t* nbr, const float
     EGONN_SCONV_CASE(64, 64)
     EGONN_SCONV_CASE(64, 128)
     EGONN_SCONV_CASE(128, 128)
+    EGONN_SCONV_CASE(64, 32)      // input gradients of the 32->64 / 64->128 layers (training)
+    EGONN_SCONV_CASE(128, 64)
 #undef EGONN_SCONV_CASE
   }
   const int64_t total = (int64_t)n_out * cout;

@@ -656,9 +656,22 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
   return EGONN_OK;
 }
 
+// level-0 parent table (input gradient of the first strided convolution): built on first use, training only
+int ensure_level0_parent_table(Ctx* ctx, hipStream_t stream) {
+  Plan& P = ctx->plan;
+  Level& V = P.lv[0];
+  if (V.nbrT || V.n == 0) return EGONN_OK;
+  V.nbrT = ctx->plan_arena.alloc<int32_t>((size_t)V.n * 8);
+  EGONN_REQUIRE(V.nbrT, EGONN_ERR_STATE, "plan arena too small for the level-0 parent table");
+  hipLaunchKernelGGL(nbrT_kernel, dim3((unsigned)cdiv(V.n, 256)), dim3(256), 0, stream, V.parent, V.keys, (int32_t)V.n,
+                     V.nbrT);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
 static size_t plan_arena_bytes(int64_t n, int B) {
   // raw+sorted keys/vals, 10 levels x (keys, parent, cstart, mask, bstart), perm, maps of levels 1..7 (<= n rows each)
-  size_t per_row = 2 * (8 + 4) + NL * (8 + 4 + 4 + 8 + 4) + 4 + 9 * 27 * 4 + 7 * (8 + 8) * 4 + 4 + 27 * 12;
+  size_t per_row = 2 * (8 + 4) + NL * (8 + 4 + 4 + 8 + 4) + 4 + 9 * 27 * 4 + 7 * (8 + 8) * 4 + 4 + 27 * 12 + 8 * 4;
   return (size_t)(n + 8) * per_row + (size_t)(B + 1) * 4 * EGONN_NUM_LEVELS + (size_t)cdiv(n, PYR_TILE) * NL * 4 +
          (1 << 20);
 }

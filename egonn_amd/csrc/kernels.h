@@ -56,4 +56,25 @@ size_t triplet_loss_scratch_floats(int n);
 int triplet_loss_forward(const float* emb, int n, int d, const uint8_t* pos, const uint8_t* neg, float margin,
                          float* out10, int32_t* triplets, float* grad, float* scratch, hipStream_t stream);
 
+// train.hip --------------------------------------------------------------------------------------
+// dW[k][ci][co] = sum_o in[nbr[o][k]][ci] * dout[o][co]; nbr == nullptr: identity map (K = 1, dense layer)
+int conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int64_t n_out, int K, int cin, int cout,
+               float* dW, float* scratch, size_t scratch_floats, hipStream_t stream);
+int conv0_wgrad(Ctx* ctx, const float* feat, const float* dout, float* dW, float* scratch, size_t scratch_floats,
+                hipStream_t stream);
+int col_stats(int mode, const float* a, const float* b, const float* mask, const float* m, int64_t n, int c, float* out2c,
+              float* scratch, size_t scratch_floats, hipStream_t stream);
+int affine_act(const float* x, const float* A, const float* B, int64_t n, int c, int relu, float* out, hipStream_t stream);
+int affine3(const float* g, const float* mask, const float* x, const float* A, const float* B, const float* C, int64_t n,
+            int c, float* out, hipStream_t stream);
+int gate_residual_forward(const float* x, const float* gate, const float* res, const int32_t* boff, int B, int64_t n, int c,
+                          int relu, float* out, hipStream_t stream);
+int gate_residual_backward(const float* dout, const float* out, const float* gate, const int32_t* boff, int B, int64_t n,
+                           int c, float* dx, float* dres, hipStream_t stream);
+int seg_broadcast(const float* v, const int32_t* boff, int B, int64_t n, int c, int mean, float* out, hipStream_t stream);
+int seg_sums2(int mode, const float* a, const float* b, const float* x2, const float* p, const int32_t* boff, int B, int c,
+              float* out_bc, float* scratch, size_t scratch_floats, hipStream_t stream);
+int gem_backward_rows(const float* x, const float* coef, const float* p, const int32_t* boff, int B, int64_t n, int c,
+                      float* dx, hipStream_t stream);
+
 }  // namespace egonn

@@ -240,8 +240,9 @@ API int egonn_conv_transpose(egonn_ctx* c, int level_in, const float* in, int ci
                              float* out, void* stream) {
   REQUIRE_PLAN(c);
   HIP_CHECK(hipSetDevice(c->device));
-  EGONN_REQUIRE(level_in >= 2 && level_in < EGONN_NUM_LEVELS, EGONN_ERR_INVALID,
-                "transposed conv: input level %d out of range [2,7]", level_in);
+  EGONN_REQUIRE(level_in >= 1 && level_in < EGONN_NUM_LEVELS, EGONN_ERR_INVALID,
+                "transposed conv: input level %d out of range [1,7]", level_in);
+  if (level_in == 1) EGONN_TRY(ensure_level0_parent_table(c, (hipStream_t)stream));
   const Level& L = c->plan.lv[level_in - 1];
   return sconv_forward(in, c->plan.lv[level_in].n, L.nbrT, kernel, nullptr, nullptr, nullptr, 0, out, (int32_t)L.n, 8, cin, cout, op_scratch(c),
                        SCONV_SCRATCH_FLOATS, (hipStream_t)stream);
@@ -738,4 +739,117 @@ API int egonn_triplet_loss(const float* embeddings, int n, int d, const uint8_t*
                 "triplet_loss: null argument");
   return triplet_loss_forward(embeddings, n, d, positives_mask, negatives_mask, margin, out_stats, out_triplets, out_grad,
                               scratch, (hipStream_t)stream);
+}
+
+
+// ------------------------------------------------------------------------------------------ training-mode operators
+#define REQUIRE_LEVEL(c, level)                                                                              \
+  REQUIRE_PLAN(c);                                                                                           \
+  HIP_CHECK(hipSetDevice((c)->device));                                                                      \
+  EGONN_REQUIRE((level) >= 0 && (level) < EGONN_NUM_LEVELS, EGONN_ERR_INVALID, "level %d out of range", (level))
+
+API int egonn_dense(const float* x, int64_t n, int cin, const float* weight, int weight_out_in, const float* bias, int cout,
+                    int act, float* out, void* stream) {
+  EGONN_REQUIRE(x && weight && out && n >= 0 && cin >= 1 && cout >= 1 && act >= 0 && act <= 4, EGONN_ERR_INVALID,
+                "dense: bad arguments");
+  return dense_forward(x, n, cin, weight, weight_out_in ? 1 : 0, cout, bias, nullptr, nullptr, act, nullptr, out,
+                       (hipStream_t)stream);
+}
+
+API int egonn_dense_backward_weight(const float* a, int ca, const float* b, int cb, int64_t n, float* out, float* scratch,
+                                    int64_t scratch_floats, void* stream) {
+  EGONN_REQUIRE(a && b && out && ca >= 1 && cb >= 1 && n >= 0, EGONN_ERR_INVALID, "dense_backward_weight: bad arguments");
+  return conv_wgrad(a, b, nullptr, n, 1, ca, cb, out, scratch, (size_t)scratch_floats, (hipStream_t)stream);
+}
+
+API int egonn_conv_backward_weight(egonn_ctx* c, int level_in, int level_out, int ks, int transposed, const float* in,
+                                   int cin, const float* grad_out, int cout, float* grad_kernel, float* scratch,
+                                   int64_t scratch_floats, void* stream) {
+  REQUIRE_LEVEL(c, level_in);
+  EGONN_REQUIRE(level_out >= 0 && level_out < EGONN_NUM_LEVELS, EGONN_ERR_INVALID, "level %d out of range", level_out);
+  EGONN_REQUIRE(grad_out && grad_kernel, EGONN_ERR_INVALID, "conv_backward_weight: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const Plan& P = c->plan;
+  if (ks == 5) {
+    EGONN_REQUIRE(level_in == 0 && level_out == 0 && cin == 1 && cout == 32 && !transposed, EGONN_ERR_INVALID,
+                  "conv_backward_weight: k=5 is the 1->32 input layer only");
+    return conv0_wgrad(c, in, grad_out, grad_kernel, scratch, (size_t)scratch_floats, st);   // in == NULL: all ones
+  }
+  EGONN_REQUIRE(in, EGONN_ERR_INVALID, "conv_backward_weight: null input");
+  if (ks == 1) {
+    EGONN_REQUIRE(level_in == level_out && !transposed, EGONN_ERR_INVALID, "1x1 conv cannot change the level");
+    return conv_wgrad(in, grad_out, nullptr, P.lv[level_in].n, 1, cin, cout, grad_kernel, scratch, (size_t)scratch_floats, st);
+  }
+  if (ks == 3) {
+    EGONN_REQUIRE(level_in == level_out && level_in >= 1 && !transposed, EGONN_ERR_INVALID,
+                  "k=3 convolution: levels 1..7, same in/out level");
+    return conv_wgrad(in, grad_out, P.lv[level_in].nbr27, P.lv[level_in].n, 27, cin, cout, grad_kernel, scratch,
+                      (size_t)scratch_floats, st);
+  }
+  if (ks == 2 && !transposed) {
+    EGONN_REQUIRE(level_out == level_in + 1, EGONN_ERR_INVALID, "k=2,s=2 convolution maps level l to l+1");
+    return conv_wgrad(in, grad_out, P.lv[level_out].nbr8, P.lv[level_out].n, 8, cin, cout, grad_kernel, scratch,
+                      (size_t)scratch_floats, st);
+  }
+  if (ks == 2 && transposed) {
+    EGONN_REQUIRE(level_out == level_in - 1 && level_out >= 0, EGONN_ERR_INVALID, "transposed conv maps level l to l-1");
+    if (level_out == 0) EGONN_TRY(ensure_level0_parent_table(c, st));
+    return conv_wgrad(in, grad_out, P.lv[level_out].nbrT, P.lv[level_out].n, 8, cin, cout, grad_kernel, scratch,
+                      (size_t)scratch_floats, st);
+  }
+  set_error("conv_backward_weight: kernel_size %d not supported", ks);
+  return EGONN_ERR_INVALID;
+}
+
+API int egonn_col_stats(int mode, const float* a, const float* b, const float* mask, const float* mean, int64_t n, int c,
+                        float* out, float* scratch, int64_t scratch_floats, void* stream) {
+  return col_stats(mode, a, b, mask, mean, n, c, out, scratch, (size_t)scratch_floats, (hipStream_t)stream);
+}
+API int egonn_affine_act(const float* x, const float* scale, const float* shift, int64_t n, int c, int relu, float* out,
+                         void* stream) {
+  EGONN_REQUIRE(x && scale && shift && out, EGONN_ERR_INVALID, "affine_act: null argument");
+  return affine_act(x, scale, shift, n, c, relu, out, (hipStream_t)stream);
+}
+API int egonn_affine3(const float* g, const float* mask, const float* x, const float* A, const float* B, const float* C,
+                      int64_t n, int c, float* out, void* stream) {
+  EGONN_REQUIRE(g && x && A && B && C && out, EGONN_ERR_INVALID, "affine3: null argument");
+  return affine3(g, mask, x, A, B, C, n, c, out, (hipStream_t)stream);
+}
+API int egonn_relu_backward(const float* grad_out, const float* out, int64_t n, int c, float* grad_in, void* stream) {
+  EGONN_REQUIRE(grad_out && out && grad_in, EGONN_ERR_INVALID, "relu_backward: null argument");
+  return gate_residual_backward(grad_out, out, nullptr, nullptr, 0, n, c, grad_in, nullptr, (hipStream_t)stream);
+}
+API int egonn_gate_residual(egonn_ctx* c, int level, const float* x, const float* gate, const float* residual, int ch,
+                            int relu, float* out, void* stream) {
+  REQUIRE_LEVEL(c, level);
+  EGONN_REQUIRE(x && out, EGONN_ERR_INVALID, "gate_residual: null argument");
+  return gate_residual_forward(x, gate, residual, c->plan.lv[level].boff, c->plan.batch, c->plan.lv[level].n, ch, relu, out,
+                               (hipStream_t)stream);
+}
+API int egonn_gate_residual_backward(egonn_ctx* c, int level, const float* grad_out, const float* out, const float* gate,
+                                     int ch, float* grad_x, float* grad_residual, void* stream) {
+  REQUIRE_LEVEL(c, level);
+  EGONN_REQUIRE(grad_out && grad_x, EGONN_ERR_INVALID, "gate_residual_backward: null argument");
+  return gate_residual_backward(grad_out, out, gate, c->plan.lv[level].boff, c->plan.batch, c->plan.lv[level].n, ch, grad_x,
+                                grad_residual, (hipStream_t)stream);
+}
+API int egonn_segment_sums(egonn_ctx* c, int level, int mode, const float* a, const float* b, const float* x2, const float* p,
+                           int ch, float* out, float* scratch, int64_t scratch_floats, void* stream) {
+  REQUIRE_LEVEL(c, level);
+  EGONN_REQUIRE(a && out && mode >= 0 && mode <= 2 && (mode == 1 || b) && (mode != 2 || x2) && (mode != 1 || p),
+                EGONN_ERR_INVALID, "segment_sums: bad arguments");
+  return seg_sums2(mode, a, b, x2, p, c->plan.lv[level].boff, c->plan.batch, ch, out, scratch, (size_t)scratch_floats,
+                   (hipStream_t)stream);
+}
+API int egonn_segment_broadcast(egonn_ctx* c, int level, const float* v, int ch, int mean, float* out, void* stream) {
+  REQUIRE_LEVEL(c, level);
+  EGONN_REQUIRE(v && out, EGONN_ERR_INVALID, "segment_broadcast: null argument");
+  return seg_broadcast(v, c->plan.lv[level].boff, c->plan.batch, c->plan.lv[level].n, ch, mean, out, (hipStream_t)stream);
+}
+API int egonn_gem_backward(egonn_ctx* c, int level, const float* x, const float* coef, const float* p, int ch, float* grad_x,
+                           void* stream) {
+  REQUIRE_LEVEL(c, level);
+  EGONN_REQUIRE(x && coef && p && grad_x, EGONN_ERR_INVALID, "gem_backward: null argument");
+  return gem_backward_rows(x, coef, p, c->plan.lv[level].boff, c->plan.batch, c->plan.lv[level].n, ch, grad_x,
+                           (hipStream_t)stream);
 }

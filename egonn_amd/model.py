@@ -259,9 +259,6 @@ class MinkGL(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, batch: Dict[str, torch.Tensor], disable_global_head: bool = False,
                 disable_local_head: bool = False):
-        if self.training:
-            raise NotImplementedError("training-mode forward (batch-statistics BatchNorm + backward) is not part "
-                                      "of the inference path built so far; call model.eval()")
         dev = self._device()
         ctx = self.context()
         coords, feats = batch['coords'], batch['features']
@@ -272,7 +269,26 @@ class MinkGL(nn.Module):
         if bs is None:
             bs = int(coords[:, 0].max().item()) + 1
         ctx.coords_set(coords, bs)
+        if self.training:
+            return self._forward_train(ctx, feats, disable_global_head)
         return self._forward_on_plan(ctx, feats, disable_global_head, disable_local_head)
+
+    # process group for SyncBN statistics in train mode (None = this process only); set by the sharded step
+    sync_bn_group = None
+
+    def _forward_train(self, ctx: _lib.Context, feats: torch.Tensor, disable_global_head: bool):
+        """train mode (reference training/trainer.py:160-175): batch-statistics BatchNorm, autograd through the HIP
+        operators (egonn_amd/train.py).  Only the global branch is differentiable so far; the local-head outputs
+        (and the losses of models/loss_utils.py that train them) are not produced in train mode."""
+        from . import train
+        if not bool((feats == 1).all()):
+            raise NotImplementedError("train mode supports the reference's all-ones input features only")
+        y = {}
+        if not disable_global_head:
+            g = train.global_branch(self, ctx, self.sync_bn_group)
+            assert g.dim() == 2 and g.shape[1] == self.global_descriptor_size
+            y['global'] = g
+        return y
 
     def _forward_on_plan(self, ctx: _lib.Context, feats: torch.Tensor, disable_global_head=False,
                          disable_local_head=False):

@@ -1,0 +1,313 @@
+"""Training-mode EgoNN graph on the MI355X operators (BASELINE configs[3]: the sharded training step).
+
+The reference trains through MinkowskiEngine's autograd (training/trainer.py:160-175: `model.train()`,
+`y = model(batch)`, `loss.backward()`, `optimizer.step()`).  Here `MinkGL.forward` in train mode builds the same
+graph (models/minkgl.py:136-153 trunk, layers/eca_block.py:56-73 block, models/minkgl.py:46-60 head,
+:207-225 decoder, layers/pooling.py:82-86 GeM) out of `torch.autograd.Function`s whose forward AND backward are
+libegonn_hip kernels; PyTorch only owns the tensors, the tape and the optimiser.  Vectors of C or (B, C) values
+(batch-norm statistics, the ECA gate's Conv1d over channels, GeM's exponent) are combined with tiny tensor ops.
+
+BatchNorm uses the statistics of ALL rows of the batch (`nn.BatchNorm1d` on SparseTensor.F); with a process group
+the per-channel sums are all-reduced (SyncBN) so that a sharded batch reproduces the single-GPU
+statistics.  There is no CPU path: every Function needs the HIP library.
+
+Scope: the global branch (trunk + global head + decoder + GeM), which is what the batch-hard triplet loss of
+models/loss.py back-propagates through.  The local-head losses (models/loss_utils.py) are not built.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+
+ACT_NONE, ACT_RELU = 0, 1
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------- sparse convolution
+class SparseConvFn(Function):
+    """ME.MinkowskiConvolution / MinkowskiConvolutionTranspose on the cached maps of the current plan."""
+
+    @staticmethod
+    def forward(fctx, x, kernel, ctx: _lib.Context, level_in: int, level_out: int, ks: int, transposed: bool):
+        k = _c(kernel.detach())
+        if transposed:
+            out = ctx.conv_transpose(level_in, x, k)
+        else:
+            out = ctx.conv(level_in, level_out, ks, x, k)
+        fctx.save_for_backward(x, kernel)
+        fctx.meta = (ctx, level_in, level_out, ks, transposed)
+        return out
+
+    @staticmethod
+    def backward(fctx, g):
+        x, kernel = fctx.saved_tensors
+        ctx, lin, lout, ks, transposed = fctx.meta
+        g = _c(g)
+        k = kernel.detach()
+        dx = dk = None
+        if x is not None and fctx.needs_input_grad[0]:
+            if ks == 1:                                   # dX = dY @ W^T, W (cin, cout) read as an (out=cin, in=cout) matrix
+                dx = ctx.dense(g, _c(k), out_in=True)
+            elif ks == 3:                                 # nbr[o][k] = j  <=>  nbr[j][26-k] = o
+                dx = ctx.conv(lin, lin, 3, g, _c(k.flip(0).transpose(1, 2)))
+            elif ks == 2 and not transposed:              # strided conv  <->  transposed conv on the same map
+                dx = ctx.conv_transpose(lout, g, _c(k.transpose(1, 2)))
+            elif ks == 2 and transposed:
+                dx = ctx.conv(lout, lin, 2, g, _c(k.transpose(1, 2)))
+            else:
+                raise NotImplementedError(f"input gradient of a k={ks} convolution")
+        if fctx.needs_input_grad[1]:
+            dk = ctx.conv_backward_weight(lin, lout, ks, transposed, x, g, tuple(kernel.shape))
+        return dx, dk, None, None, None, None, None
+
+
+def sparse_conv(ctx, x, conv_module, level_in, level_out):
+    return SparseConvFn.apply(x, conv_module.kernel, ctx, level_in, level_out, conv_module.kernel_size,
+                              bool(conv_module.transpose))
+
+
+# ----------------------------------------------------------------------------- batch norm (batch statistics)
+def _all_reduce(t: torch.Tensor, group):
+    if group is not None:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def combine_batch_stats(sum_x: torch.Tensor, count: torch.Tensor, group=None):
+    """(sum, count) of this rank -> global (mean, total count); one all-reduce of C+1 values."""
+    buf = torch.cat([sum_x.double(), count.double().reshape(1)])
+    _all_reduce(buf, group)
+    total = buf[-1]
+    return (buf[:-1] / total).float(), total
+
+
+class BatchNormFn(Function):
+    """nn.BatchNorm1d over all rows in train mode (MinkowskiBatchNorm), optional fused ReLU, optional SyncBN."""
+
+    @staticmethod
+    def forward(fctx, x, weight, bias, ctx: _lib.Context, bn: torch.nn.BatchNorm1d, relu: bool, group):
+        n, c = x.shape
+        dev = x.device
+        s = ctx.col_stats(0, x)
+        mean, total = combine_batch_stats(s[0], torch.tensor(float(n), device=dev), group)
+        m2 = ctx.col_stats(1, x, mean=mean)[0].double()
+        _all_reduce(m2, group)
+        var = m2 / total                                            # biased, used for normalisation
+        invstd = torch.rsqrt(var + bn.eps).float()
+        scale = weight.detach() * invstd
+        shift = bias.detach() - mean * scale
+        y = ctx.affine_act(x, _c(scale), _c(shift), relu)
+        if bn.track_running_stats and bn.running_mean is not None:
+            with torch.no_grad():
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                unbiased = (m2 / torch.clamp(total - 1, min=1)).float()
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(unbiased, alpha=mom)
+                bn.num_batches_tracked += 1
+        fctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
+        fctx.meta = (ctx, relu, group, total)
+        return y
+
+    @staticmethod
+    def backward(fctx, g):
+        x, y, mean, invstd, weight = fctx.saved_tensors
+        ctx, relu, group, total = fctx.meta
+        g = _c(g)
+        s = ctx.col_stats(2, g, b=x, mask=y, mean=mean)             # sum g', sum g' (x - mean)   (this rank's rows)
+        dbeta = s[0].clone()
+        dgamma = s[1] * invstd
+        sg = _all_reduce(s.double(), group)                         # whole-batch sums for the input gradient
+        w = weight.detach().double()
+        inv = invstd.double()
+        A = w * inv
+        Bc = -w * inv ** 3 * sg[1] / total
+        Cc = -Bc * mean.double() - A * sg[0] / total
+        dx = ctx.affine3(g, y, x, _c(A.float()), _c(Bc.float()), _c(Cc.float()))
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def batch_norm(ctx, x, bn_module, relu: bool, group=None):
+    bn = bn_module.bn
+    return BatchNormFn.apply(x, bn.weight, bn.bias, ctx, bn, relu, group)
+
+
+# ----------------------------------------------------------------------------- per-sample pooling / ECA tail
+class SegmentMeanFn(Function):
+    """ME.MinkowskiGlobalPooling (per-sample mean of the rows) -> (B, C)."""
+
+    @staticmethod
+    def forward(fctx, x, ctx: _lib.Context, level: int):
+        fctx.meta = (ctx, level)
+        return ctx.global_avg_pool(level, x)
+
+    @staticmethod
+    def backward(fctx, g):
+        ctx, level = fctx.meta
+        return ctx.segment_broadcast(level, _c(g), mean=True), None, None
+
+
+class GateResidualFn(Function):
+    """relu(x * gate[sample] + residual): MinkowskiBroadcastMultiplication + `out += residual` + MinkowskiReLU."""
+
+    @staticmethod
+    def forward(fctx, x, gate, residual, ctx: _lib.Context, level: int):
+        out = ctx.gate_residual(level, x, _c(gate.detach()), residual, relu=True)
+        fctx.save_for_backward(x, gate, out)
+        fctx.meta = (ctx, level)
+        return out
+
+    @staticmethod
+    def backward(fctx, g):
+        x, gate, out = fctx.saved_tensors
+        ctx, level = fctx.meta
+        g = _c(g)
+        dx, dres = ctx.gate_residual_backward(level, g, out, _c(gate.detach()), want_residual=fctx.needs_input_grad[2])
+        dgate = ctx.segment_sums(level, 2, g, b=out, x2=x) if fctx.needs_input_grad[1] else None
+        return dx, dgate, dres, None, None
+
+
+def eca_tail(ctx, level, x, residual, eca_module):
+    """layers/eca_block.py:21-36,66-73: gate = sigmoid(Conv1d_k(mean_b(x))), out = relu(x * gate + residual)."""
+    m = SegmentMeanFn.apply(x, ctx, level)                                       # (B, C)
+    conv = eca_module.conv
+    z = F.conv1d(m.unsqueeze(1), conv.weight, padding=conv.padding[0]).squeeze(1)   # (B, C): Conv1d over channels
+    return GateResidualFn.apply(x, torch.sigmoid(z), residual, ctx, level)
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(fctx, a, b, ctx: _lib.Context):
+        return ctx.add(a, b)
+
+    @staticmethod
+    def backward(fctx, g):
+        return g, g, None
+
+
+# ----------------------------------------------------------------------------- dense layers / GeM
+class LinearFn(Function):
+    """ME.MinkowskiLinear (+ fused MinkowskiReLU): rows @ W^T + b, W (out, in)."""
+
+    @staticmethod
+    def forward(fctx, x, weight, bias, ctx: _lib.Context, relu: bool):
+        y = ctx.dense(x, _c(weight.detach()), out_in=True, bias=None if bias is None else _c(bias.detach()),
+                      act=ACT_RELU if relu else ACT_NONE)
+        fctx.save_for_backward(x, weight, y if relu else None)
+        fctx.meta = (ctx, relu, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(fctx, g):
+        x, weight, y = fctx.saved_tensors
+        ctx, relu, has_bias = fctx.meta
+        g = _c(g)
+        if relu:
+            g = ctx.relu_backward(g, y)
+        dx = ctx.dense(g, _c(weight.detach()), out_in=False) if fctx.needs_input_grad[0] else None
+        dw = ctx.dense_backward_weight(g, x) if fctx.needs_input_grad[1] else None
+        db = ctx.col_stats(0, g)[0].clone() if has_bias and fctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None
+
+
+class GeMFn(Function):
+    """layers/pooling.py:82-86: (mean_b clamp(x, 1e-6)^p)^(1/p)."""
+
+    @staticmethod
+    def forward(fctx, x, p, ctx: _lib.Context, level: int):
+        out = ctx.gem(level, x, p)
+        fctx.save_for_backward(x, p, out)
+        fctx.meta = (ctx, level)
+        return out
+
+    @staticmethod
+    def backward(fctx, g):
+        x, p, out = fctx.saved_tensors
+        ctx, level = fctx.meta
+        off = ctx.level_batch_offsets(level)
+        cnt = torch.tensor([off[b + 1] - off[b] for b in range(ctx.batch_size)], dtype=torch.float32,
+                           device=x.device).clamp_(min=1).unsqueeze(1)
+        pv = p.detach().reshape(()).float()
+        g = _c(g)
+        dx = dp = None
+        if fctx.needs_input_grad[0]:
+            coef = g * out.pow(1.0 - pv) / cnt
+            dx = ctx.gem_backward(level, x, _c(coef), _c(p.detach().reshape(-1).float()))
+        if fctx.needs_input_grad[1]:
+            T = ctx.segment_sums(level, 1, x, p=_c(p.detach().reshape(-1).float()))    # sum_r t^p ln t
+            S = out.pow(pv) * cnt                                                       # sum_r t^p
+            dout_dp = out * (-(torch.log(out.pow(pv))) / (pv * pv) + T / (pv * S))
+            dp = (g * dout_dp).sum().reshape(p.shape)
+        return dx, dp, None, None
+
+
+# ----------------------------------------------------------------------------- the graph
+def trunk_forward(model, ctx, group=None) -> Dict[int, torch.Tensor]:
+    """MinkTrunk.forward (reference models/minkgl.py:136-153) with all-ones input features."""
+    t = model.trunk
+    x = SparseConvFn.apply(None, t.convs['0'].kernel, ctx, 0, 0, t.convs['0'].kernel_size, False)
+    x = batch_norm(ctx, x, t.bn['0'], True, group)
+    levels = {}
+    for i in range(1, len(t.planes) + 1):
+        x = sparse_conv(ctx, x, t.convs[str(i)], i - 1, i)
+        x = batch_norm(ctx, x, t.bn[str(i)], True, group)
+        for blk in t.blocks[str(i)]:
+            y = sparse_conv(ctx, x, blk.conv1, i, i)
+            y = batch_norm(ctx, y, blk.norm1, True, group)
+            y = sparse_conv(ctx, y, blk.conv2, i, i)
+            y = batch_norm(ctx, y, blk.norm2, False, group)
+            res = x
+            if blk.downsample is not None:
+                res = sparse_conv(ctx, x, blk.downsample[0], i, i)
+                res = batch_norm(ctx, res, blk.downsample[1], False, group)
+            x = eca_tail(ctx, i, y, res, blk.eca)
+        levels[i] = x
+    return levels
+
+
+def head_forward(head, ctx, levels: Dict[int, torch.Tensor]):
+    """MinkHead.forward (reference models/minkgl.py:46-60)."""
+    y = sparse_conv(ctx, levels[head.max_level], head.conv1x1[str(head.max_level)], head.max_level, head.max_level)
+    for level in range(head.max_level - 1, head.min_level - 1, -1):
+        y = sparse_conv(ctx, y, head.tconv[str(level + 1)], level + 1, level)
+        if level in head.in_levels:
+            y = AddFn.apply(y, sparse_conv(ctx, levels[level], head.conv1x1[str(level)], level, level), ctx)
+    return head.min_level, y
+
+
+def global_branch(model, ctx, group=None) -> torch.Tensor:
+    """trunk -> global head -> descriptor decoder -> GeM  (reference models/minkgl.py:269-287)."""
+    levels = trunk_forward(model, ctx, group)
+    lvl, x = head_forward(model.global_head, ctx, levels)
+    net = model.global_descriptor_decoder.net
+    x = LinearFn.apply(x, net[0].linear.weight, net[0].linear.bias, ctx, True)
+    x = LinearFn.apply(x, net[2].linear.weight, net[2].linear.bias, ctx, False)
+    return GeMFn.apply(x, model.global_pooling.pooling.p, ctx, lvl)
+
+
+# ----------------------------------------------------------------------------- sharded step plumbing
+def all_reduce_gradients(params: List[torch.nn.Parameter], group=None, world_size: Optional[int] = None):
+    """Sum the gradients of all ranks in ONE flat RCCL all-reduce (4.71 M values = 18.8 MB for EgoNN; with the loss
+    evaluated on the all-gathered embeddings each rank holds the contribution of its own scans, so the sum is the
+    gradient of the whole batch — no averaging)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    ps = [p for p in params if p.grad is not None]
+    if not ps:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    o = 0
+    for p in ps:
+        n = p.grad.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        o += n

@@ -138,6 +138,56 @@ int egonn_triplet_loss(const float* embeddings, int n, int d, const uint8_t* pos
                        const uint8_t* negatives_mask, float margin, float* out_stats, int32_t* out_triplets,
                        float* out_grad, float* scratch, void* stream);
 
+/* ------------------------------------------------------------------ training-mode operators (configs[3])
+ * The reference trains through MinkowskiEngine's autograd (training/trainer.py:160-175: model.train(); y = model(batch);
+ * loss.backward()).  Backward of a sparse convolution w.r.t. its input is again a sparse convolution on the cached
+ * map (k=3: same table with kernel[26-k]^T; k=2,s=2 <-> transposed) and is composed from egonn_conv /
+ * egonn_conv_transpose by the host side (egonn_amd/train.py); the entry points below are what has no forward twin.
+ * `scratch`: device floats owned by the caller (partial sums of the deterministic two-stage reductions).            */
+enum { EGONN_ACT_NONE = 0, EGONN_ACT_RELU = 1, EGONN_ACT_TANH = 2, EGONN_ACT_SOFTPLUS = 3, EGONN_ACT_SIGMOID = 4 };
+/* Row-wise dense layer out = act(x @ Wmat + bias): weight_out_in = 0: weight (cin,cout) (ME 1x1 kernel);
+ * 1: weight (cout,cin) (nn.Linear / MinkowskiLinear, models/minkgl.py:175-225).  Also the input gradient of either
+ * layout (swap the flag). */
+int egonn_dense(const float* x, int64_t n, int cin, const float* weight, int weight_out_in, const float* bias, int cout,
+                int act, float* out, void* stream);
+/* out (ca,cb) = a^T b over n rows: weight gradient of a dense layer (a = input, b = grad_out for the (cin,cout) layout). */
+int egonn_dense_backward_weight(const float* a, int ca, const float* b, int cb, int64_t n, float* out, float* scratch,
+                                int64_t scratch_floats, void* stream);
+/* Weight gradient of MinkowskiConvolution / MinkowskiConvolutionTranspose on the current plan: grad_kernel
+ * (K,cin,cout).  kernel_size 5: the 1->32 input layer (in == NULL: all-ones features); 3; 2 (transposed = 0: level
+ * l -> l+1, 1: l -> l-1); 1. */
+int egonn_conv_backward_weight(egonn_ctx* ctx, int level_in, int level_out, int kernel_size, int transposed,
+                               const float* in, int cin, const float* grad_out, int cout, float* grad_kernel,
+                               float* scratch, int64_t scratch_floats, void* stream);
+/* Per-channel reductions over (n,c) rows -> out (2,c).  MinkowskiBatchNorm in train mode = nn.BatchNorm1d over all
+ * rows (models/minkgl.py:102,107):  mode 0: sum a, sum a^2;  mode 1: sum (a-mean)^2, 0;
+ * mode 2 (backward): g = a*[mask>0] (mask nullable): sum g, sum g*(b-mean).  scratch >= 2*c*ceil(n/2048) floats. */
+int egonn_col_stats(int mode, const float* a, const float* b, const float* mask, const float* mean, int64_t n, int c,
+                    float* out, float* scratch, int64_t scratch_floats, void* stream);
+/* out = relu?(x*scale[c] + shift[c]) — BatchNorm application with batch statistics folded by the caller. */
+int egonn_affine_act(const float* x, const float* scale, const float* shift, int64_t n, int c, int relu, float* out,
+                     void* stream);
+/* out = A[c]*(g*[mask>0]) + B[c]*x + C[c] — BatchNorm input gradient (mask = the ReLU output, nullable). */
+int egonn_affine3(const float* g, const float* mask, const float* x, const float* A, const float* B, const float* C,
+                  int64_t n, int c, float* out, void* stream);
+int egonn_relu_backward(const float* grad_out, const float* out, int64_t n, int c, float* grad_in, void* stream);
+/* out = relu?(x * gate[sample] + residual): MinkowskiBroadcastMultiplication + residual add + MinkowskiReLU
+ * (layers/eca_block.py:69-73) with an explicit (B,c) gate (nullable = 1); backward: d = grad_out*[out>0],
+ * grad_residual = d (nullable), grad_x = d*gate. */
+int egonn_gate_residual(egonn_ctx* ctx, int level, const float* x, const float* gate, const float* residual, int channels,
+                        int relu, float* out, void* stream);
+int egonn_gate_residual_backward(egonn_ctx* ctx, int level, const float* grad_out, const float* out, const float* gate,
+                                 int channels, float* grad_x, float* grad_residual, void* stream);
+/* Per-sample column sums -> out (B,c).  mode 0: a*b;  mode 1: t^p ln t, t = max(a,1e-6) (GeM d/dp);
+ * mode 2: (a*[b>0])*x2 (gate gradient).  scratch >= 32*B*c floats. */
+int egonn_segment_sums(egonn_ctx* ctx, int level, int mode, const float* a, const float* b, const float* x2,
+                       const float* p, int channels, float* out, float* scratch, int64_t scratch_floats, void* stream);
+/* out[r] = v[sample(r)] (* 1/n_sample when mean): backward of MinkowskiGlobalPooling (layers/eca_block.py:16). */
+int egonn_segment_broadcast(egonn_ctx* ctx, int level, const float* v, int channels, int mean, float* out, void* stream);
+/* GeM input gradient: grad_x[r] = coef[sample(r)] * x^(p-1) * [x >= 1e-6] (layers/pooling.py:82-86). */
+int egonn_gem_backward(egonn_ctx* ctx, int level, const float* x, const float* coef, const float* p, int channels,
+                       float* grad_x, void* stream);
+
 /* ------------------------------------------------------------------ launch timing (bench.py roofline leg)
  * mode 0: off; 1: time every tagged sparse-conv launch; 2: only launches whose tag contains `filter`.
  * Timing = HIP events recorded on the caller's stream around the launch. */

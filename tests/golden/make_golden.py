@@ -189,5 +189,70 @@ def main():
         print(name, "voxels", bc.shape[0], "backbone rows", len(c), f"{os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def grad_digest(name, g):
+    """small, order-independent-enough summary of one gradient tensor (the full set is 4.7 M values)."""
+    import zlib
+    import numpy as np
+    g = np.asarray(g, dtype=np.float64).reshape(-1)
+    r = np.random.default_rng(zlib.crc32(name.encode())).standard_normal(g.size)
+    return np.concatenate([[np.linalg.norm(g), float(g @ r)], g[:64] if g.size > 4096 else g])
+
+
+TRAIN_CASES = [
+    # name,               coordinates, step,  scans,                                   weight seed, projection seed
+    ("egonn_train_cart03", "cartesian", "0.3", [(31, 9000), (32, 7000), (33, 8000)], 41, 42),
+]
+
+
+def main_train():
+    """train-mode step of the REFERENCE graph (models/minkgl.py in .train(): batch-statistics BatchNorm) on the
+    stand-in ME ops with torch autograd: global descriptors, a linear functional of them as the loss, gradients of
+    every parameter (digested) and the BatchNorm running statistics after the step."""
+    bootstrap_reference()
+    import numpy as np
+    import torch
+    import MinkowskiEngine as ME
+    from models.model_factory import model_factory
+    from egonn_amd.synth import lidar_scan, seeded_state_dict
+
+    for name, coordinates, step, scans, wseed, pseed in TRAIN_CASES:
+        mp = model_params(coordinates, step)
+        model = model_factory(mp)
+        shapes = {k: [int(s) for s in v.shape] for k, v in model.state_dict().items()}
+        new = seeded_state_dict(wseed, {k: tuple(v) for k, v in shapes.items()})
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()})
+        model.train()
+        coords_list = []
+        out = {"weight_seed": np.int64(wseed), "proj_seed": np.int64(pseed), "coordinates": np.array(coordinates),
+               "quantization_step": np.array([float(step)]), "n_scans": np.int64(len(scans))}
+        for b, (seed, n) in enumerate(scans):
+            pc = kitti_like_filter(lidar_scan(seed, n_points=n))
+            coords, _ = mp.quantizer(torch.from_numpy(pc))
+            coords_list.append(coords)
+        bc = ME.utils.batched_coordinates(coords_list)
+        feats = torch.ones((bc.shape[0], 1), dtype=torch.float32)
+        y = model({"coords": bc, "features": feats})                    # REFERENCE forward, train mode
+        g = y["global"]
+        R = torch.from_numpy(np.random.default_rng(pseed).standard_normal(tuple(g.shape)).astype(np.float32))
+        loss = (g * R).sum()
+        loss.backward()
+        out["coords"] = bc.numpy().astype(np.int32)
+        out["global"] = g.detach().numpy()
+        out["loss"] = np.float64(loss.item())
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                out["grad/" + k] = grad_digest(k, p.grad.numpy())
+        for k, v in model.state_dict().items():
+            if k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"):
+                out["buf/" + k] = v.numpy()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        n_grad = sum(1 for k in out if k.startswith("grad/"))
+        print(name, "voxels", bc.shape[0], "params with grad", n_grad, f"{os.path.getsize(path) / 1e6:.2f} MB")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        main_train()
+        sys.exit(0)
     main()

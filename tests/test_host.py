@@ -69,10 +69,10 @@ def test_no_cpu_fallback(built):
         m.quantizer(torch.zeros((4, 3)))
 
 
-def test_training_mode_is_refused_loudly(built):
+def test_training_mode_has_no_cpu_path_either(built):
     from egonn_amd import ModelParams, model_factory
     m = model_factory(ModelParams(model="egonn", coordinates="cartesian", quantization_step=0.1)).train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         m({"coords": torch.zeros((1, 4), dtype=torch.int32), "features": torch.ones((1, 1))})
 
 
