@@ -29,6 +29,36 @@ def _world() -> Tuple[int, int]:
     return 0, 1
 
 
+def _staged(t: torch.Tensor) -> bool:
+    """gloo has no device collectives on this build: stage HIP tensors through the host (tests only — on the GPU
+    box the backend is "nccl" = RCCL and tensors stay on the device)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """in-place SUM all-reduce (RCCL; host-staged under gloo)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    if _staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def _all_gather_list(t: torch.Tensor, world: int) -> List[torch.Tensor]:
+    if _staged(t):
+        h = t.cpu()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h)
+        return [p.to(t.device) for p in parts]
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return parts
+
+
 def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """Concatenate the ranks' row blocks (contiguous `shard_bounds` partition of n_total rows) on every rank.
     One collective: blocks are padded to the largest shard so that a single all_gather_into_tensor
@@ -102,15 +132,12 @@ class _AllGatherEmbeddings(torch.autograd.Function):
             ctx.lo = 0
             return local.clone()
         counts = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-        all_counts = [torch.zeros_like(counts) for _ in range(world)]
-        dist.all_gather(all_counts, counts)
-        sizes = [int(c.item()) for c in all_counts]
+        sizes = [int(c.item()) for c in _all_gather_list(counts, world)]
         ctx.lo = sum(sizes[:rank])
         mx = max(sizes)
         pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         pad[: local.shape[0]] = local
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad)
+        parts = _all_gather_list(pad, world)
         return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
 
     @staticmethod

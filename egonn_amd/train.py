@@ -77,8 +77,8 @@ def sparse_conv(ctx, x, conv_module, level_in, level_out):
 # ----------------------------------------------------------------------------- batch norm (batch statistics)
 def _all_reduce(t: torch.Tensor, group):
     if group is not None:
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        from .distributed import all_reduce_sum
+        all_reduce_sum(t, group)
     return t
 
 
@@ -304,10 +304,50 @@ def all_reduce_gradients(params: List[torch.nn.Parameter], group=None, world_siz
     ps = [p for p in params if p.grad is not None]
     if not ps:
         return
+    from .distributed import all_reduce_sum
     flat = torch.cat([p.grad.reshape(-1) for p in ps])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_sum(flat, group)
     o = 0
     for p in ps:
         n = p.grad.numel()
         p.grad.copy_(flat[o:o + n].view_as(p.grad))
         o += n
+
+
+class TrainStep:
+    """One optimisation step of the reference's global phase (training/trainer.py:157-175,193), sharded over the
+    ranks of the default process group (BASELINE configs[3]: batch 256 = 32 scans per GPU on 8 GPUs):
+
+        forward of this rank's scans (SyncBN statistics over the whole batch: one all-reduce of C+1 and one of C
+        values per BatchNorm layer and direction)
+        -> RCCL all-gather of the (b_local, 256) global descriptors (differentiable, distributed.py)
+        -> batch-hard triplet loss on the gathered (B, 256) matrix with the (B, B) masks every rank holds
+        -> backward (each rank back-propagates the rows it produced)
+        -> ONE flat SUM all-reduce of the parameter gradients -> optimizer.step()
+
+    With a single process it is exactly the reference's step."""
+
+    def __init__(self, model, optimizer, margin: float = 0.2):
+        from .loss import BatchHardTripletLossWithMasks
+        self.model, self.optimizer = model, optimizer
+        self.loss_fn = BatchHardTripletLossWithMasks(margin)
+
+    def __call__(self, batch: Dict[str, torch.Tensor], positives_mask: torch.Tensor, negatives_mask: torch.Tensor,
+                 step_optimizer: bool = True):
+        import torch.distributed as dist
+        from .distributed import all_gather_embeddings
+        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        model = self.model
+        model.train()
+        model.sync_bn_group = dist.group.WORLD if sharded else None
+        self.optimizer.zero_grad(set_to_none=True)
+        y = model(batch, disable_local_head=True)
+        emb = all_gather_embeddings(y['global'])
+        dev = emb.device
+        loss, stats, _ = self.loss_fn(emb, positives_mask.to(dev), negatives_mask.to(dev))
+        loss.backward()
+        if sharded:
+            all_reduce_gradients(list(model.parameters()))
+        if step_optimizer:
+            self.optimizer.step()
+        return loss.detach(), stats

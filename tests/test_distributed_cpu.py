@@ -113,3 +113,43 @@ def test_all_gather_embeddings_autograd_world2_gloo():
     for rank, g, grad, want_grad, full in got:
         assert np.array_equal(g, full)                 # every rank sees the whole batch, rank order
         assert np.array_equal(grad, want_grad)         # and back-propagates exactly its own rows
+
+
+# ----------------------------------------------------------------------------- sharded training step: host logic
+def _stats_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from egonn_amd.train import combine_batch_stats, all_reduce_gradients
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn((101, 7), generator=g) * 2 + 3
+        lo, hi = (0, 40) if rank == 0 else (40, 101)                     # uneven shards
+        mean, total = combine_batch_stats(x[lo:hi].sum(0), torch.tensor(float(hi - lo)), dist.group.WORLD)
+        # a "parameter" whose per-rank gradient is the contribution of the rank's rows
+        p = torch.nn.Parameter(torch.zeros(7))
+        p.grad = x[lo:hi].sum(0)
+        q2 = torch.nn.Parameter(torch.zeros(3))                           # no gradient on any rank: must be skipped
+        all_reduce_gradients([p, q2])
+        q.put((rank, mean.numpy(), float(total), p.grad.numpy(), q2.grad is None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_syncbn_statistics_and_gradient_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stats_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((101, 7), generator=g) * 2 + 3
+    for rank, mean, total, grad, skipped in got:
+        assert total == 101.0 and skipped
+        assert np.allclose(mean, x.mean(0).numpy(), rtol=1e-6, atol=1e-6)          # whole-batch mean on every rank
+        assert np.allclose(grad, x.sum(0).numpy(), rtol=1e-6, atol=1e-5)           # SUM, not average

@@ -215,3 +215,98 @@ def test_train_step_matches_reference_fixture():
         if not k.startswith(("trunk", "global")):
             continue
         assert np.allclose(sd[k].cpu().numpy(), ref, rtol=1e-3, atol=1e-5), k
+
+
+# ----------------------------------------------------------------------------- sharded step == single-process step
+def _make_model(dev, wseed):
+    import egonn_amd
+    mp_ = egonn_amd.ModelParams(model="egonn", coordinates="cartesian", quantization_step=0.3)
+    model = egonn_amd.model_factory(mp_)
+    w = H.seeded_weights(wseed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    return model.to(dev)
+
+
+def _scan_batch(dev, coords, scan_ids):
+    """sub-batch of the fixture's scans, batch index renumbered from 0"""
+    parts = []
+    for new_b, b in enumerate(scan_ids):
+        c = coords[coords[:, 0] == b].clone()
+        c[:, 0] = new_b
+        parts.append(c)
+    c = torch.cat(parts).to(dev)
+    return {"coords": c, "features": torch.ones((len(c), 1), device=dev), "batch_size": len(scan_ids)}
+
+
+def _masks():
+    pos = torch.zeros((3, 3), dtype=torch.bool)
+    pos[0, 1] = pos[1, 0] = True
+    neg = torch.zeros((3, 3), dtype=torch.bool)
+    neg[0, 2] = neg[2, 0] = neg[1, 2] = neg[2, 1] = True
+    return pos, neg
+
+
+def _sharded_worker(rank, world, port, out_path):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # 2 ranks sharing the one GPU of the box:
+    try:                                                               # RCCL needs one GPU per rank, gloo is host-staged
+        from egonn_amd.train import TrainStep
+        dev = torch.device("cuda", 0)
+        case = H.load_case("egonn_train_cart03")
+        coords = torch.from_numpy(case["coords"])
+        model = _make_model(dev, int(case["weight_seed"]))
+        step = TrainStep(model, torch.optim.SGD(model.parameters(), lr=0.0), margin=0.2)
+        pos, neg = _masks()
+        mine = [0, 1] if rank == 0 else [2]                            # uneven shards
+        loss, stats = step(_scan_batch(dev, coords, mine), pos, neg, step_optimizer=False)
+        grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}
+        bufs = {k: v.detach().cpu() for k, v in model.state_dict().items() if "running" in k}
+        torch.save({"loss": float(loss), "stats": stats, "grads": grads, "bufs": bufs}, f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_step_equals_single_process_step(tmp_path):
+    """2 ranks (scans [0,1] | [2]) with SyncBN + embedding all-gather + gradient all-reduce reproduce the gradients,
+    the loss and the BatchNorm running statistics of one process stepping the whole batch."""
+    import socket
+    import torch.multiprocessing as tmp_mp
+    import __graft_entry__ as ge
+    ge.build()
+    from egonn_amd import _lib
+    from egonn_amd.train import TrainStep
+    dev = _lib.require_gpu()
+    case = H.load_case("egonn_train_cart03")
+    coords = torch.from_numpy(case["coords"])
+    model = _make_model(dev, int(case["weight_seed"]))
+    step = TrainStep(model, torch.optim.SGD(model.parameters(), lr=0.0), margin=0.2)
+    pos, neg = _masks()
+    loss, stats = step(_scan_batch(dev, coords, [0, 1, 2]), pos, neg, step_optimizer=False)
+    assert stats["num_triplets"] == 2 and np.isfinite(float(loss))
+    want = {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    want_buf = {k: v.detach().cpu() for k, v in model.state_dict().items() if "running" in k}
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "res")
+    ctx = tmp_mp.get_context("spawn")
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    for r in range(2):
+        got = torch.load(f"{out}.{r}")
+        assert abs(got["loss"] - float(loss)) <= 1e-4 * max(1.0, abs(float(loss)))
+        assert set(got["grads"]) == set(want)
+        for k, g in got["grads"].items():
+            scale = float(want[k].abs().max())
+            assert torch.allclose(g, want[k], rtol=2e-3, atol=2e-4 * scale + 1e-10), (r, k)
+        for k, v in got["bufs"].items():
+            if k.startswith(("trunk", "global")):
+                assert torch.allclose(v, want_buf[k], rtol=1e-4, atol=1e-6), (r, k)
