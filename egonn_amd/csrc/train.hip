@@ -239,7 +239,7 @@ int conv0_wgrad(Ctx* ctx, const float* feat, const float* dout, float* dW, float
 // mode 1: s0 = sum (a - m)^2    s1 = 0                                  (second pass of the batch variance)
 // mode 2: g = a * [mask > 0] (mask nullable);  s0 = sum g,  s1 = sum g * (b - m)     (BatchNorm backward)
 // block = 256 threads = (256/CP) row lanes x CP channel lanes (CP = channels padded to a power of two <= 256)
-static constexpr int CS_ROWS = 2048;   // rows per block
+static constexpr int CS_ROWS = 512;   // rows per block
 __global__ __launch_bounds__(256) void col_stats_kernel(int mode, const float* __restrict__ a, const float* __restrict__ b,
                                                        const float* __restrict__ mask, const float* __restrict__ m,
                                                        int64_t n, int c, int cp, float* __restrict__ partial) {
@@ -250,16 +250,30 @@ __global__ __launch_bounds__(256) void col_stats_kernel(int mode, const float* _
   float s0 = 0.f, s1 = 0.f;
   if (ci < c) {
     const float mu = (mode != 0 && m) ? m[ci] : 0.f;
-    for (int64_t r = r0 + rl; r < r1; r += nrl) {
-      const float av = a[r * c + ci];
-      if (mode == 0) {
+    if (mode == 0) {
+#pragma unroll 4
+      for (int64_t r = r0 + rl; r < r1; r += nrl) {
+        const float av = a[r * c + ci];
         s0 += av;
         s1 = fmaf(av, av, s1);
-      } else if (mode == 1) {
-        const float d = av - mu;
+      }
+    } else if (mode == 1) {
+#pragma unroll 4
+      for (int64_t r = r0 + rl; r < r1; r += nrl) {
+        const float d = a[r * c + ci] - mu;
         s0 = fmaf(d, d, s0);
-      } else {
-        const float gq = (mask && !(mask[r * c + ci] > 0.f)) ? 0.f : av;
+      }
+    } else if (mask) {
+#pragma unroll 4
+      for (int64_t r = r0 + rl; r < r1; r += nrl) {
+        const float gq = (mask[r * c + ci] > 0.f) ? a[r * c + ci] : 0.f;
+        s0 += gq;
+        s1 = fmaf(gq, b[r * c + ci] - mu, s1);
+      }
+    } else {
+#pragma unroll 4
+      for (int64_t r = r0 + rl; r < r1; r += nrl) {
+        const float gq = a[r * c + ci];
         s0 += gq;
         s1 = fmaf(gq, b[r * c + ci] - mu, s1);
       }
@@ -279,6 +293,17 @@ __global__ __launch_bounds__(256) void col_stats_kernel(int mode, const float* _
   }
 }
 
+// out[i] = sum over chunks of partial[ch][i]: one wave per output value (few values, many chunks), fp64, fixed order
+__global__ __launch_bounds__(64) void sum_partials_wave_kernel(const float* __restrict__ partial, int chunks, int64_t size,
+                                                              float* __restrict__ out) {
+  const int64_t i = blockIdx.x;
+  double s = 0.0;
+  for (int ch = threadIdx.x; ch < chunks; ch += 64) s += (double)partial[(int64_t)ch * size + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (threadIdx.x == 0) out[i] = (float)s;
+}
+
 int col_stats(int mode, const float* a, const float* b, const float* mask, const float* m, int64_t n, int c, float* out2c,
               float* scratch, size_t scratch_floats, hipStream_t stream) {
   EGONN_REQUIRE(c >= 1 && c <= 256, EGONN_ERR_INVALID, "col_stats: %d channels unsupported (1..256)", c);
@@ -294,7 +319,7 @@ int col_stats(int mode, const float* a, const float* b, const float* mask, const
                 "col_stats: scratch too small (%zu < %lld floats)", scratch_floats, (long long)(blocks * 2 * c));
   hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, mode, a, b, mask, m, n, c, cp,
                      scratch);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(2 * c, 256)), dim3(256), 0, stream, scratch, (int)blocks,
+  hipLaunchKernelGGL(sum_partials_wave_kernel, dim3((unsigned)(2 * c)), dim3(64), 0, stream, scratch, (int)blocks,
                      (int64_t)2 * c, out2c);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;

@@ -161,7 +161,7 @@ int egonn_conv_backward_weight(egonn_ctx* ctx, int level_in, int level_out, int 
                                float* scratch, int64_t scratch_floats, void* stream);
 /* Per-channel reductions over (n,c) rows -> out (2,c).  MinkowskiBatchNorm in train mode = nn.BatchNorm1d over all
  * rows (models/minkgl.py:102,107):  mode 0: sum a, sum a^2;  mode 1: sum (a-mean)^2, 0;
- * mode 2 (backward): g = a*[mask>0] (mask nullable): sum g, sum g*(b-mean).  scratch >= 2*c*ceil(n/2048) floats. */
+ * mode 2 (backward): g = a*[mask>0] (mask nullable): sum g, sum g*(b-mean).  scratch >= 2*c*ceil(n/512) floats. */
 int egonn_col_stats(int mode, const float* a, const float* b, const float* mask, const float* mean, int64_t n, int c,
                     float* out, float* scratch, int64_t scratch_floats, void* stream);
 /* out = relu?(x*scale[c] + shift[c]) — BatchNorm application with batch statistics folded by the caller. */
