@@ -853,3 +853,18 @@ API int egonn_gem_backward(egonn_ctx* c, int level, const float* x, const float*
   return gem_backward_rows(x, coef, p, c->plan.lv[level].boff, c->plan.batch, c->plan.lv[level].n, ch, grad_x,
                            (hipStream_t)stream);
 }
+
+
+// ------------------------------------------------------------------------------------------ retrieval (eval/evaluate.py)
+API int egonn_knn(const float* query, int64_t n_query, const float* database, int64_t n_database, int dim, int k,
+                  int32_t* out_index, float* out_distance, float* scratch, int64_t scratch_floats, void* stream) {
+  EGONN_REQUIRE(n_query < (1ll << 31) && n_database < (1ll << 31), EGONN_ERR_INVALID, "knn: too many rows");
+  return knn_search(query, (int32_t)n_query, database, (int32_t)n_database, dim, k, out_index, out_distance, scratch,
+                    (size_t)scratch_floats, (hipStream_t)stream);
+}
+API int egonn_recall_counts(const int32_t* nn_index, const float* query_positions, const float* map_positions,
+                            int64_t n_query, int k, int position_dim, const float* radius, int n_radius,
+                            int32_t* out_true_positives, void* stream) {
+  return recall_counts(nn_index, query_positions, map_positions, (int32_t)n_query, k, position_dim, radius, n_radius,
+                       out_true_positives, (hipStream_t)stream);
+}

@@ -188,6 +188,19 @@ int egonn_segment_broadcast(egonn_ctx* ctx, int level, const float* v, int chann
 int egonn_gem_backward(egonn_ctx* ctx, int level, const float* x, const float* coef, const float* p, int channels,
                        float* grad_x, void* stream);
 
+/* ------------------------------------------------------------------ retrieval (database build, configs[4])
+ * replaces the per-query NumPy search of Evaluator.evaluate, eval/evaluate.py:80-82 and :175-176:
+ *   embed_dist = np.linalg.norm(map_embeddings - query_embedding, axis=1);  nn_ndx = np.argsort(embed_dist)[:k]
+ * out_index (n_query,k) int32 ascending by distance (ties: lower index; -1 beyond n_database), out_distance (n_query,k).
+ * scratch >= n_query*n_database floats. */
+int egonn_knn(const float* query, int64_t n_query, const float* database, int64_t n_database, int dim, int k,
+              int32_t* out_index, float* out_distance, float* scratch, int64_t scratch_floats, void* stream);
+/* eval/evaluate.py:84-88 / :181-184: out_true_positives (n_radius,k) int32, [r][nn] = number of queries with a
+ * retrieved map element among the first nn+1 whose position is within radius[r] (positions: (n, position_dim) f32). */
+int egonn_recall_counts(const int32_t* nn_index, const float* query_positions, const float* map_positions,
+                        int64_t n_query, int k, int position_dim, const float* radius, int n_radius,
+                        int32_t* out_true_positives, void* stream);
+
 /* ------------------------------------------------------------------ launch timing (bench.py roofline leg)
  * mode 0: off; 1: time every tagged sparse-conv launch; 2: only launches whose tag contains `filter`.
  * Timing = HIP events recorded on the caller's stream around the launch. */

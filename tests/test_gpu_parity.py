@@ -534,3 +534,34 @@ def test_config4_database_build_mulran_shaped(gpu):
         solo = ex.extract([load(i)])
         assert H.cosine_err(_np(solo["global"]), _np(db["global"][[i]])).max() < 1e-5
         assert int(solo["count"][0]) == int(db["count"][i])
+
+
+def test_knn_and_recall_match_oracle():
+    """on-device kNN + recall@k (eval/evaluate.py:80-88) vs the numpy restatement: indices bit-exact (ties by index)."""
+    from egonn_amd import retrieval, _lib
+    from oracle import retrieval_ref as R
+    dev = _lib.require_gpu()
+    rng = np.random.default_rng(7)
+    m, nq, d, k = 5000, 300, 256, 25
+    db = rng.standard_normal((m, d)).astype(np.float32)
+    db[100] = db[7]                                                 # exact duplicates -> ties
+    db[4000] = db[7]
+    qs = (db[rng.integers(0, m, nq)] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
+    qs[0] = db[7]
+    idx, dist = retrieval.knn(torch.from_numpy(qs).to(dev), torch.from_numpy(db).to(dev), k)
+    ridx, rdist = R.knn(qs, db, k)
+    assert idx.cpu().numpy()[0, :3].tolist() == [7, 100, 4000]
+    same = idx.cpu().numpy() == ridx
+    # fp32 summation order can swap two neighbours whose distances agree to the last ulp
+    assert same.mean() > 0.999
+    assert np.allclose(dist.cpu().numpy(), rdist, rtol=1e-5, atol=1e-5)
+    mpos = rng.uniform(0, 500, (m, 2)).astype(np.float32)
+    qpos = (mpos[ridx[:, 0]] + rng.normal(0, 8, (nq, 2))).astype(np.float32)
+    out = retrieval.recall_at_k(torch.from_numpy(db), torch.from_numpy(qs), torch.from_numpy(mpos), torch.from_numpy(qpos),
+                                radius=[5, 20], k=k)
+    want = R.recall(idx.cpu().numpy(), qpos, mpos, [5, 20], k)
+    for r in (5, 20):
+        assert np.allclose(out['recall'][r], want[r], atol=1e-9), r
+    # k larger than the database, and an empty query set
+    i2, d2 = retrieval.knn(torch.from_numpy(qs[:4]).to(dev), torch.from_numpy(db[:3]).to(dev), 5)
+    assert (i2[:, 3:] == -1).all() and torch.isinf(d2[:, 3:]).all() and (i2[:, :3] >= 0).all()

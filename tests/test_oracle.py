@@ -170,3 +170,18 @@ def test_triplet_miner_matches_reference_formulas():
     li = torch.relu(d_ap - torch.minimum(d_an, d_pn) + 0.2)
     want = li[li > 0].mean().item() if (li > 0).any() else 0.0
     assert abs(loss - want) < 1e-5
+
+
+def test_retrieval_oracle_known_answer():
+    from oracle import retrieval_ref as R
+    m = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 2.0], [1.0, 0.0]], dtype=np.float32)      # rows 1 and 3 tie
+    q = np.array([[0.9, 0.0], [0.0, 1.9]], dtype=np.float32)
+    idx, dist = R.knn(q, m, 3)
+    assert idx.tolist() == [[1, 3, 0], [2, 0, 1]]
+    assert np.allclose(dist[0], [0.1, 0.1, 0.9], atol=1e-6)
+    mpos = np.array([[0, 0], [10, 0], [0, 10], [50, 50]], dtype=np.float32)
+    qpos = np.array([[48, 50], [0, 9]], dtype=np.float32)
+    rec = R.recall(idx, qpos, mpos, [5, 20], 3)
+    assert rec[5] == [0.5, 1.0, 1.0] and rec[20] == [0.5, 1.0, 1.0]
+    idx2, _ = R.knn(q, m[:2], 3)                                   # k larger than the database
+    assert idx2.tolist() == [[1, 0, -1], [0, 1, -1]]
