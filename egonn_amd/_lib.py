@@ -60,6 +60,9 @@ _SIGS = [
     ("egonn_segment_sums", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, C.c_int64, _P]),
     ("egonn_segment_broadcast", C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     ("egonn_gem_backward", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P]),
+    ("egonn_filter_points_scratch_ints", C.c_int64, [C.c_int64]),
+    ("egonn_filter_points", C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P,
+                                      C.c_int64, _P]),
     ("egonn_knn", C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P, C.c_int64, _P]),
     ("egonn_recall_counts", C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     ("egonn_profile_enable", C.c_int, [_P, C.c_int, C.c_char_p]),

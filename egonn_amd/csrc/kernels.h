@@ -83,4 +83,10 @@ int knn_search(const float* query, int32_t nq, const float* db, int32_t m, int d
 int recall_counts(const int32_t* nn_idx, const float* qpos, const float* mpos, int32_t nq, int k, int pd,
                   const float* radius, int nr, int32_t* tp, hipStream_t stream);
 
+// ingest.hip -------------------------------------------------------------------------------------
+size_t ingest_scratch_ints(int64_t n);
+int ingest_filter(const float* raw, int64_t n, int stride, const int64_t* raw_off_dev, int batch, int remove_zero,
+                  int remove_ground, float ground, float* out_xyz, int64_t* new_off_dev, int32_t* scratch,
+                  size_t scratch_ints, hipStream_t stream);
+
 }  // namespace egonn

@@ -868,3 +868,14 @@ API int egonn_recall_counts(const int32_t* nn_index, const float* query_position
   return recall_counts(nn_index, query_positions, map_positions, (int32_t)n_query, k, position_dim, radius, n_radius,
                        out_true_positives, (hipStream_t)stream);
 }
+
+
+// ------------------------------------------------------------------------------------------ scan ingest
+API int64_t egonn_filter_points_scratch_ints(int64_t n) { return (int64_t)ingest_scratch_ints(n); }
+API int egonn_filter_points(const float* raw, int64_t n, int floats_per_point, const int64_t* scan_offsets, int batch_size,
+                            int remove_zero_points, int remove_ground_plane, float ground_plane_level, float* out_points,
+                            int64_t* out_scan_offsets, int32_t* scratch, int64_t scratch_ints, void* stream) {
+  return ingest_filter(raw, n, floats_per_point, scan_offsets, batch_size, remove_zero_points, remove_ground_plane,
+                       ground_plane_level, out_points, out_scan_offsets, scratch, (size_t)scratch_ints,
+                       (hipStream_t)stream);
+}

@@ -188,6 +188,18 @@ int egonn_segment_broadcast(egonn_ctx* ctx, int level, const float* v, int chann
 int egonn_gem_backward(egonn_ctx* ctx, int level, const float* x, const float* coef, const float* p, int channels,
                        float* grad_x, void* stream);
 
+/* ------------------------------------------------------------------ scan ingest (the step before the path)
+ * replaces PointCloudLoader.__call__ (misc/point_clouds.py:95-111) after read_pc (datasets/mulran/mulran_raw.py:19-25,
+ * datasets/kitti/kitti_raw.py:16-22): raw (n, floats_per_point = 4 | 3) f32 returns of a whole batch (scan b = rows
+ * [scan_offsets[b], scan_offsets[b+1]), DEVICE int64, batch_size+1 entries); drops all-zero points (|v| <= 1e-8) and
+ * points with z <= ground_plane_level; survivors keep their order.  out_points (n,3) f32 (first out_scan_offsets[B]
+ * rows valid), out_scan_offsets (batch_size+1) DEVICE int64.  scratch: egonn_filter_points_scratch_ints(n) int32.
+ * No host sync (the caller copies the B+1 offsets back before egonn_voxelize). */
+int64_t egonn_filter_points_scratch_ints(int64_t n);
+int egonn_filter_points(const float* raw, int64_t n, int floats_per_point, const int64_t* scan_offsets, int batch_size,
+                        int remove_zero_points, int remove_ground_plane, float ground_plane_level, float* out_points,
+                        int64_t* out_scan_offsets, int32_t* scratch, int64_t scratch_ints, void* stream);
+
 /* ------------------------------------------------------------------ retrieval (database build, configs[4])
  * replaces the per-query NumPy search of Evaluator.evaluate, eval/evaluate.py:80-82 and :175-176:
  *   embed_dist = np.linalg.norm(map_embeddings - query_embedding, axis=1);  nn_ndx = np.argsort(embed_dist)[:k]

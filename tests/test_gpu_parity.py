@@ -565,3 +565,46 @@ def test_knn_and_recall_match_oracle():
     # k larger than the database, and an empty query set
     i2, d2 = retrieval.knn(torch.from_numpy(qs[:4]).to(dev), torch.from_numpy(db[:3]).to(dev), 5)
     assert (i2[:, 3:] == -1).all() and torch.isinf(d2[:, 3:]).all() and (i2[:, :3] >= 0).all()
+
+
+def _raw_scans(seeds, n):
+    from egonn_amd.synth import lidar_scan
+    raws = []
+    for s in seeds:
+        rng = np.random.default_rng(100 + s)
+        pc = lidar_scan(s, n_points=n)
+        raw = np.concatenate([pc, rng.uniform(0, 255, (len(pc), 1)).astype(np.float32)], axis=1)
+        raw[rng.integers(0, len(raw), 200), :3] = 0.0                 # dropped returns are stored as all-zero points
+        raw[rng.integers(0, len(raw), 5), 2] = np.nan
+        raws.append(np.ascontiguousarray(raw))
+    return raws
+
+
+def test_ingest_filter_matches_loader_semantics():
+    """device zero-point / ground-plane filter == PointCloudLoader.__call__ (misc/point_clouds.py:95-111), bit-exact
+    and order-preserving, per scan of a batch; then ingest -> extract == host-filtered -> extract."""
+    import egonn_amd
+    from egonn_amd import _lib
+    from egonn_amd.ingest import ScanIngest
+    from oracle import ingest_ref as I
+    dev = _lib.require_gpu()
+    raws = _raw_scans([3, 4, 5], 30000) + [np.zeros((0, 4), dtype=np.float32)] + _raw_scans([6], 1500)
+    for ds in ("mulran", "kitti"):
+        pts, off = ScanIngest(ds, dev)(raws)
+        assert len(off) == len(raws) + 1 and off[0] == 0
+        got = pts.cpu().numpy()
+        for b, raw in enumerate(raws):
+            want = I.preprocess(I.read_pc(raw), ds)
+            assert off[b + 1] - off[b] == len(want), (ds, b)
+            assert np.array_equal(got[off[b]:off[b + 1]], want, equal_nan=True), (ds, b)
+    # end to end: the descriptors of the ingested batch equal those of the host-filtered clouds
+    mp = egonn_amd.ModelParams(model="egonn", coordinates="cartesian", quantization_step=0.3)
+    model = egonn_amd.model_factory(mp)
+    w = H.seeded_weights(11)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    ex = egonn_amd.DescriptorExtractor(model.to(dev).eval(), n_k=128)
+    raws = _raw_scans([7, 8], 30000)
+    pts, off = ScanIngest("mulran", dev)(raws)
+    a = ex.extract_packed(pts, off)
+    b = ex.extract([torch.from_numpy(I.preprocess(I.read_pc(r), "mulran")) for r in raws])
+    assert torch.equal(a["global"], b["global"]) and torch.equal(a["keypoints"], b["keypoints"])

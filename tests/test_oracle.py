@@ -185,3 +185,11 @@ def test_retrieval_oracle_known_answer():
     assert rec[5] == [0.5, 1.0, 1.0] and rec[20] == [0.5, 1.0, 1.0]
     idx2, _ = R.knn(q, m[:2], 3)                                   # k larger than the database
     assert idx2.tolist() == [[1, 0, -1], [0, 1, -1]]
+
+
+def test_ingest_oracle_known_answer():
+    from oracle import ingest_ref as I
+    raw = np.array([[0, 0, 0, 5], [1, 2, -0.9, 1], [1, 2, -0.8999, 1], [0, 0, 1e-9, 0], [3, 4, np.nan, 0], [5, 6, 7, 8]],
+                   dtype=np.float32)
+    pc = I.preprocess(I.read_pc(raw), "mulran")
+    assert pc.tolist() == [[1.0, 2.0, np.float32(-0.8999)], [5.0, 6.0, 7.0]]
