@@ -100,20 +100,24 @@ __global__ __launch_bounds__(256) void ingest_scatter_kernel(const float* __rest
   }
 }
 
-// survivors with raw index < raw_off[b]  (raw_off on the device, B+1 entries)
-__global__ void ingest_offsets_kernel(const float* __restrict__ raw, int64_t n, int stride, int remove_zero,
-                                      int remove_ground, float ground, const int32_t* __restrict__ block_pre,
-                                      const int64_t* __restrict__ raw_off, int nb1, int64_t* __restrict__ new_off) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// survivors with raw index < raw_off[b]  (raw_off on the device, B+1 entries); one wave per entry
+__global__ __launch_bounds__(64) void ingest_offsets_kernel(const float* __restrict__ raw, int64_t n, int stride,
+                                                           int remove_zero, int remove_ground, float ground,
+                                                           const int32_t* __restrict__ block_pre,
+                                                           const int64_t* __restrict__ raw_off, int nb1,
+                                                           int64_t* __restrict__ new_off) {
+  const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= nb1) return;
   const int64_t e = raw_off[b];
   const int64_t blk = e / ING_BLOCK;
-  int64_t c = block_pre[blk];
-  for (int64_t i = blk * ING_BLOCK; i < e; ++i) {
+  int c = 0;
+  for (int64_t i0 = blk * ING_BLOCK; i0 < e; i0 += 64) {
+    const int64_t i = i0 + lane;
     float x, y, z;
-    c += keep_point(raw, i, stride, remove_zero, remove_ground, ground, x, y, z) ? 1 : 0;
+    const bool k = i < e && keep_point(raw, i, stride, remove_zero, remove_ground, ground, x, y, z);
+    c += __popcll(__ballot(k));
   }
-  new_off[b] = c;
+  if (lane == 0) new_off[b] = (int64_t)block_pre[blk] + c;
 }
 
 size_t ingest_scratch_ints(int64_t n) { return (size_t)cdiv(n, ING_BLOCK) + 2; }
@@ -134,7 +138,7 @@ int ingest_filter(const float* raw, int64_t n, int stride, const int64_t* raw_of
   if (nblk > 0)
     hipLaunchKernelGGL(ingest_scatter_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, raw, n, stride, remove_zero,
                        remove_ground, ground, scratch, out_xyz);
-  hipLaunchKernelGGL(ingest_offsets_kernel, dim3((unsigned)cdiv(batch + 1, 64)), dim3(64), 0, stream, raw, n, stride,
+  hipLaunchKernelGGL(ingest_offsets_kernel, dim3((unsigned)(batch + 1)), dim3(64), 0, stream, raw, n, stride,
                      remove_zero, remove_ground, ground, scratch, raw_off_dev, batch + 1, new_off_dev);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;

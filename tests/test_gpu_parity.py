@@ -6,6 +6,8 @@
 Bars: integer voxel coordinates / indices / keypoint selection bit-exact; fp32 descriptors within 1e-4
 cosine (BASELINE.json north_star); other fp32 tensors within the rtol/atol written in each test.
 Row order differs between implementations, so everything joins on the (b,x,y,z) coordinate."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -597,6 +599,15 @@ def test_ingest_filter_matches_loader_semantics():
             want = I.preprocess(I.read_pc(raw), ds)
             assert off[b + 1] - off[b] == len(want), (ds, b)
             assert np.array_equal(got[off[b]:off[b + 1]], want, equal_nan=True), (ds, b)
+    # files: .bin payloads read straight into the pinned staging buffer
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        paths = []
+        for i, raw in enumerate(raws):
+            paths.append(os.path.join(d, f"{i:06d}.bin"))
+            raw.tofile(paths[-1])
+        p2, o2 = ScanIngest("kitti", dev).load(paths)
+        assert o2 == off and torch.equal(torch.nan_to_num(p2), torch.nan_to_num(pts))
     # end to end: the descriptors of the ingested batch equal those of the host-filtered clouds
     mp = egonn_amd.ModelParams(model="egonn", coordinates="cartesian", quantization_step=0.3)
     model = egonn_amd.model_factory(mp)
