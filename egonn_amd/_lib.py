@@ -55,6 +55,8 @@ _SIGS = [
     ("egonn_affine_act", C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P]),
     ("egonn_affine3", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, _P, _P]),
     ("egonn_relu_backward", C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P]),
+    ("egonn_act_backward", C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P]),
+    ("egonn_l2_normalize", C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P]),
     ("egonn_gate_residual", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     ("egonn_gate_residual_backward", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P]),
     ("egonn_segment_sums", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, C.c_int64, _P]),
@@ -338,6 +340,19 @@ class Context:
         dx = torch.empty_like(g)
         self._call(self.lib.egonn_relu_backward, g.data_ptr(), out.data_ptr(), g.shape[0], g.shape[1], dx.data_ptr())
         return dx
+
+    def act_backward(self, act: int, grad_out, out):
+        g = _dev_f32(grad_out, self.device)
+        dx = torch.empty_like(g)
+        self._call(self.lib.egonn_act_backward, act, g.data_ptr(), out.data_ptr(), g.shape[0], g.shape[1], dx.data_ptr())
+        return dx
+
+    def l2_normalize(self, x, grad_out=None):
+        x = _dev_f32(x, self.device)
+        g = None if grad_out is None else _dev_f32(grad_out, self.device)
+        out = torch.empty_like(x)
+        self._call(self.lib.egonn_l2_normalize, x.data_ptr(), _ptr(g), x.shape[0], x.shape[1], out.data_ptr())
+        return out
 
     def gate_residual(self, level, x, gate, residual, relu: bool = True):
         x = _dev_f32(x, self.device)

@@ -103,6 +103,17 @@ __global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ in
   }
 }
 
+__global__ void dense_any_kernel(const float* __restrict__ in, int64_t total, int cin, const float* __restrict__ W,
+                                 int w_out_in, int cout, const float* __restrict__ bias, int act, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t r = i / cout;
+  const int co = (int)(i - r * cout);
+  float s = bias ? bias[co] : 0.f;
+  for (int ci = 0; ci < cin; ++ci) s = fmaf(in[r * cin + ci], w_out_in ? W[(int64_t)co * cin + ci] : W[(int64_t)ci * cout + co], s);
+  out[i] = apply_act(s, act);
+}
+
 int dense_forward(const float* in, int64_t n, int cin, const float* W, int w_out_in, int cout, const float* bias,
                   const float* scale, const float* shift, int act, const float* residual, float* out,
                   hipStream_t stream) {
@@ -126,8 +137,13 @@ int dense_forward(const float* in, int64_t n, int cin, const float* W, int w_out
   EGONN_DENSE_CASE(192)
   EGONN_DENSE_CASE(256)
 #undef EGONN_DENSE_CASE
-  set_error("dense: cin=%d not supported (32, 64, 96, 128, 192, 256)", cin);
-  return EGONN_ERR_INVALID;
+  // any other width (the 3- and 1-channel gradients of the keypoint / sigma regressors): plain kernel, thread per output
+  EGONN_REQUIRE(!scale && !shift && !residual, EGONN_ERR_INVALID, "dense: cin=%d has no fused epilogue", cin);
+  const int64_t total = n * cout;
+  hipLaunchKernelGGL(dense_any_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, in, total, cin, W, w_out_in,
+                     cout, bias, act, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
 }
 
 // ------------------------------------------------------------------ BatchNorm folding (eval mode)

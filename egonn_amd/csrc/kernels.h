@@ -77,6 +77,10 @@ int seg_sums2(int mode, const float* a, const float* b, const float* x2, const f
 int gem_backward_rows(const float* x, const float* coef, const float* p, const int32_t* boff, int B, int64_t n, int c,
                       float* dx, hipStream_t stream);
 
+int act_backward(int act, const float* g, const float* y, int64_t n, int c, float* out, hipStream_t stream);
+// g == nullptr: out = normalize(x) ; else out = d normalize / dx applied to g
+int l2norm_rows(const float* x, const float* g, int64_t n, int c, float* out, hipStream_t stream);
+
 // retrieval.hip ----------------------------------------------------------------------------------
 int knn_search(const float* query, int32_t nq, const float* db, int32_t m, int d, int k, int32_t* out_idx, float* out_dist,
                float* scratch, size_t scratch_floats, hipStream_t stream);

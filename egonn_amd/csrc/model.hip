@@ -819,6 +819,14 @@ API int egonn_relu_backward(const float* grad_out, const float* out, int64_t n, 
   EGONN_REQUIRE(grad_out && out && grad_in, EGONN_ERR_INVALID, "relu_backward: null argument");
   return gate_residual_backward(grad_out, out, nullptr, nullptr, 0, n, c, grad_in, nullptr, (hipStream_t)stream);
 }
+API int egonn_act_backward(int act, const float* grad_out, const float* out, int64_t n, int c, float* grad_in, void* stream) {
+  EGONN_REQUIRE(grad_out && out && grad_in && act >= 0 && act <= 4, EGONN_ERR_INVALID, "act_backward: bad arguments");
+  return act_backward(act, grad_out, out, n, c, grad_in, (hipStream_t)stream);
+}
+API int egonn_l2_normalize(const float* x, const float* grad_out, int64_t n, int c, float* out, void* stream) {
+  EGONN_REQUIRE(x && out && c >= 1, EGONN_ERR_INVALID, "l2_normalize: bad arguments");
+  return l2norm_rows(x, grad_out, n, c, out, (hipStream_t)stream);
+}
 API int egonn_gate_residual(egonn_ctx* c, int level, const float* x, const float* gate, const float* residual, int ch,
                             int relu, float* out, void* stream) {
   REQUIRE_LEVEL(c, level);

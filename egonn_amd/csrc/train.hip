@@ -513,4 +513,59 @@ int gem_backward_rows(const float* x, const float* coef, const float* p, const i
   return EGONN_OK;
 }
 
+// ------------------------------------------------------------------------------------------ activations / L2 normalisation
+// grad_in = grad_out * act'(.) expressed through the activation's OUTPUT y:
+//   relu: [y > 0]   tanh: 1 - y^2   softplus: 1 - exp(-y)  (= sigmoid(x))   sigmoid: y (1 - y)
+__global__ void act_bwd_kernel(int act, const float* __restrict__ g, const float* __restrict__ y, int64_t total,
+                               float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float yv = y[i];
+  float d = 1.f;
+  if (act == ACT_RELU) d = yv > 0.f ? 1.f : 0.f;
+  else if (act == ACT_TANH) d = 1.f - yv * yv;
+  else if (act == ACT_SOFTPLUS) d = 1.f - expf(-yv);
+  else if (act == ACT_SIGMOID) d = yv * (1.f - yv);
+  out[i] = g[i] * d;
+}
+int act_backward(int act, const float* g, const float* y, int64_t n, int c, float* out, hipStream_t stream) {
+  const int64_t total = n * c;
+  if (total == 0) return EGONN_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, act, g, y, total, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// F.normalize(x, p=2, dim=1, eps=1e-12): y = x / max(|x|, eps).  One wave per row.
+// backward (|x| > eps): dx = (g - y (g . y)) / |x| ;  (|x| <= eps): dx = g / eps
+__global__ __launch_bounds__(256) void l2norm_fwd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            int64_t n, int c, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* p = x + row * c;
+  float ss = 0.f, gy = 0.f;
+  for (int i = lane; i < c; i += 64) ss = fmaf(p[i], p[i], ss);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float nrm = sqrtf(ss);
+  const float inv = 1.f / fmaxf(nrm, 1e-12f);
+  if (!g) {
+    for (int i = lane; i < c; i += 64) out[row * c + i] = p[i] * inv;
+    return;
+  }
+  const float* q = g + row * c;
+  for (int i = lane; i < c; i += 64) gy = fmaf(q[i], p[i] * inv, gy);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gy += __shfl_xor(gy, o, 64);
+  const bool clamped = !(nrm > 1e-12f);
+  for (int i = lane; i < c; i += 64) out[row * c + i] = clamped ? q[i] * inv : (q[i] - p[i] * inv * gy) * inv;
+}
+int l2norm_rows(const float* x, const float* g, int64_t n, int c, float* out, hipStream_t stream) {
+  if (n == 0) return EGONN_OK;
+  hipLaunchKernelGGL(l2norm_fwd_bwd_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream, x, g, n, c, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
 }  // namespace egonn

@@ -270,24 +270,37 @@ class MinkGL(nn.Module):
             bs = int(coords[:, 0].max().item()) + 1
         ctx.coords_set(coords, bs)
         if self.training:
-            return self._forward_train(ctx, feats, disable_global_head)
+            return self._forward_train(ctx, feats, disable_global_head, disable_local_head)
         return self._forward_on_plan(ctx, feats, disable_global_head, disable_local_head)
 
     # process group for SyncBN statistics in train mode (None = this process only); set by the sharded step
     sync_bn_group = None
 
-    def _forward_train(self, ctx: _lib.Context, feats: torch.Tensor, disable_global_head: bool):
-        """train mode (reference training/trainer.py:160-175): batch-statistics BatchNorm, autograd through the HIP
-        operators (egonn_amd/train.py).  Only the global branch is differentiable so far; the local-head outputs
-        (and the losses of models/loss_utils.py that train them) are not produced in train mode."""
+    def _forward_train(self, ctx: _lib.Context, feats: torch.Tensor, disable_global_head: bool,
+                       disable_local_head: bool = False):
+        """train mode (reference training/trainer.py:160-175,183-192): batch-statistics BatchNorm, autograd through the
+        HIP operators (egonn_amd/train.py).  Output dict as in eval mode; every tensor carries a grad_fn."""
         from . import train
         if not bool((feats == 1).all()):
             raise NotImplementedError("train mode supports the reference's all-ones input features only")
         y = {}
+        levels = train.trunk_forward(self, ctx, self.sync_bn_group)
         if not disable_global_head:
-            g = train.global_branch(self, ctx, self.sync_bn_group)
+            g = train.global_branch(self, ctx, self.sync_bn_group, levels)
             assert g.dim() == 2 and g.shape[1] == self.global_descriptor_size
             y['global'] = g
+        if self.local_head is not None and not disable_local_head:
+            lvl, desc, kp_off, sigma = train.local_branch(self, ctx, levels)
+            coords = ctx.level_coords(lvl)                                    # (n,4) int32 [b,x,y,z]
+            stride = [2 ** lvl] * 3
+            if self.ignore_keypoint_regressor:
+                kp_off = torch.zeros_like(kp_off)
+            kp_pos = self.quantizer.keypoint_position(coords[:, 1:], stride, kp_off)      # minkgl.py:296-302
+            off = ctx.level_batch_offsets(lvl)
+            B = ctx.batch_size
+            y['descriptors'] = [desc[off[b]:off[b + 1]] for b in range(B)]
+            y['keypoints'] = [kp_pos[off[b]:off[b + 1]] for b in range(B)]
+            y['sigma'] = [sigma[off[b]:off[b + 1]] for b in range(B)]
         return y
 
     def _forward_on_plan(self, ctx: _lib.Context, feats: torch.Tensor, disable_global_head=False,

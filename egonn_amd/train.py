@@ -11,8 +11,10 @@ BatchNorm uses the statistics of ALL rows of the batch (`nn.BatchNorm1d` on Spar
 the per-channel sums are all-reduced (SyncBN) so that a sharded batch reproduces the single-GPU
 statistics.  There is no CPU path: every Function needs the HIP library.
 
-Scope: the global branch (trunk + global head + decoder + GeM), which is what the batch-hard triplet loss of
-models/loss.py back-propagates through.  The local-head losses (models/loss_utils.py) are not built.
+Both branches are differentiable: the global one (trunk + global head + decoder + GeM) for the batch-hard triplet
+loss of models/loss.py, the local one (local head, descriptor decoder + L2 norm, keypoint regressor + tanh + the
+quantiser's keypoint_position, sigma regressor + softplus) so that the reference's own local losses
+(models/loss_utils.py, plain torch code on the output lists) can back-propagate into it.
 """
 from __future__ import annotations
 
@@ -24,7 +26,7 @@ from torch.autograd import Function
 
 from . import _lib
 
-ACT_NONE, ACT_RELU = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2, 3
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -195,27 +197,43 @@ class AddFn(Function):
 
 # ----------------------------------------------------------------------------- dense layers / GeM
 class LinearFn(Function):
-    """ME.MinkowskiLinear (+ fused MinkowskiReLU): rows @ W^T + b, W (out, in)."""
+    """ME.MinkowskiLinear (+ fused MinkowskiReLU / Tanh / Softplus): act(rows @ W^T + b), W (out, in).
+    `act`: True/False (ReLU or none) or an ACT_* code."""
 
     @staticmethod
-    def forward(fctx, x, weight, bias, ctx: _lib.Context, relu: bool):
-        y = ctx.dense(x, _c(weight.detach()), out_in=True, bias=None if bias is None else _c(bias.detach()),
-                      act=ACT_RELU if relu else ACT_NONE)
-        fctx.save_for_backward(x, weight, y if relu else None)
-        fctx.meta = (ctx, relu, bias is not None)
+    def forward(fctx, x, weight, bias, ctx: _lib.Context, act):
+        act = int(act)
+        y = ctx.dense(x, _c(weight.detach()), out_in=True, bias=None if bias is None else _c(bias.detach()), act=act)
+        fctx.save_for_backward(x, weight, y if act else None)
+        fctx.meta = (ctx, act, bias is not None)
         return y
 
     @staticmethod
     def backward(fctx, g):
         x, weight, y = fctx.saved_tensors
-        ctx, relu, has_bias = fctx.meta
+        ctx, act, has_bias = fctx.meta
         g = _c(g)
-        if relu:
-            g = ctx.relu_backward(g, y)
+        if act:
+            g = ctx.act_backward(act, g, y)
         dx = ctx.dense(g, _c(weight.detach()), out_in=False) if fctx.needs_input_grad[0] else None
         dw = ctx.dense_backward_weight(g, x) if fctx.needs_input_grad[1] else None
         db = ctx.col_stats(0, g)[0].clone() if has_bias and fctx.needs_input_grad[2] else None
         return dx, dw, db, None, None
+
+
+class L2NormalizeFn(Function):
+    """ME.MinkowskiFunctional.normalize (F.normalize over the channels of every row)."""
+
+    @staticmethod
+    def forward(fctx, x, ctx: _lib.Context):
+        fctx.save_for_backward(x)
+        fctx.meta = ctx
+        return ctx.l2_normalize(x)
+
+    @staticmethod
+    def backward(fctx, g):
+        (x,) = fctx.saved_tensors
+        return fctx.meta.l2_normalize(x, _c(g)), None
 
 
 class GeMFn(Function):
@@ -283,14 +301,33 @@ def head_forward(head, ctx, levels: Dict[int, torch.Tensor]):
     return head.min_level, y
 
 
-def global_branch(model, ctx, group=None) -> torch.Tensor:
+def global_branch(model, ctx, group=None, levels=None) -> torch.Tensor:
     """trunk -> global head -> descriptor decoder -> GeM  (reference models/minkgl.py:269-287)."""
-    levels = trunk_forward(model, ctx, group)
+    if levels is None:
+        levels = trunk_forward(model, ctx, group)
     lvl, x = head_forward(model.global_head, ctx, levels)
     net = model.global_descriptor_decoder.net
     x = LinearFn.apply(x, net[0].linear.weight, net[0].linear.bias, ctx, True)
     x = LinearFn.apply(x, net[2].linear.weight, net[2].linear.bias, ctx, False)
     return GeMFn.apply(x, model.global_pooling.pooling.p, ctx, lvl)
+
+
+def local_branch(model, ctx, levels: Dict[int, torch.Tensor]):
+    """local head -> descriptor decoder (+L2 norm), keypoint regressor (+tanh), sigma regressor (+softplus)
+    (reference models/minkgl.py:289-308).  Returns (level, descriptors, keypoint offsets, sigma), rows of `level`."""
+    lvl, x = head_forward(model.local_head, ctx, levels)
+    d = model.local_descriptor_decoder.net
+    desc = LinearFn.apply(x, d[0].linear.weight, d[0].linear.bias, ctx, ACT_RELU)
+    desc = LinearFn.apply(desc, d[2].linear.weight, d[2].linear.bias, ctx, ACT_NONE)
+    if model.local_descriptor_decoder.normalize:
+        desc = L2NormalizeFn.apply(desc, ctx)
+    k = model.local_keypoint_regressor.net
+    kp = LinearFn.apply(x, k[0].linear.weight, k[0].linear.bias, ctx, ACT_RELU)
+    kp = LinearFn.apply(kp, k[2].linear.weight, k[2].linear.bias, ctx, ACT_TANH)
+    g = model.local_sigma_regressor.net
+    sg = LinearFn.apply(x, g[0].linear.weight, g[0].linear.bias, ctx, ACT_RELU)
+    sg = LinearFn.apply(sg, g[2].linear.weight, g[2].linear.bias, ctx, ACT_SOFTPLUS)
+    return lvl, desc, kp, sg
 
 
 # ----------------------------------------------------------------------------- sharded step plumbing

@@ -171,6 +171,12 @@ int egonn_affine_act(const float* x, const float* scale, const float* shift, int
 int egonn_affine3(const float* g, const float* mask, const float* x, const float* A, const float* B, const float* C,
                   int64_t n, int c, float* out, void* stream);
 int egonn_relu_backward(const float* grad_out, const float* out, int64_t n, int c, float* grad_in, void* stream);
+/* grad_in = grad_out * act'(.) from the activation's output (MinkowskiReLU / Tanh / Softplus / Sigmoid,
+ * models/minkgl.py:181-183,198-200). */
+int egonn_act_backward(int act, const float* grad_out, const float* out, int64_t n, int c, float* grad_in, void* stream);
+/* MinkowskiFunctional.normalize = F.normalize(x, p=2, dim=1, eps=1e-12) (models/minkgl.py:222-223): grad_out == NULL:
+ * out = normalised rows; else out = the input gradient for grad_out. */
+int egonn_l2_normalize(const float* x, const float* grad_out, int64_t n, int c, float* out, void* stream);
 /* out = relu?(x * gate[sample] + residual): MinkowskiBroadcastMultiplication + residual add + MinkowskiReLU
  * (layers/eca_block.py:69-73) with an explicit (B,c) gate (nullable = 1); backward: d = grad_out*[out>0],
  * grad_residual = d (nullable), grad_x = d*gate. */

@@ -11,7 +11,8 @@ What it does (SURVEY.md §8c "Oracle plan", Appendix D recipe):
 
 No reference source text is stored — only arrays the reference code computed.
 
-    python tests/golden/make_golden.py            # rewrite all fixtures
+    python tests/golden/make_golden.py            # rewrite the inference fixtures
+    python tests/golden/make_golden.py train      # rewrite the train-step fixtures
 """
 from __future__ import annotations
 
@@ -201,7 +202,17 @@ def grad_digest(name, g):
 TRAIN_CASES = [
     # name,               coordinates, step,  scans,                                   weight seed, projection seed
     ("egonn_train_cart03", "cartesian", "0.3", [(31, 9000), (32, 7000), (33, 8000)], 41, 42),
+    ("egonn_train_polar", "polar", "1., 0.3, 0.2", [(34, 9000), (35, 8000)], 43, 44),
 ]
+
+
+def row_weights(coords, width, salt):
+    """deterministic per-row projection weights as a function of the row's (b,x,y,z) coordinate, so that both sides
+    can evaluate the same linear functional of the local outputs whatever their row order is."""
+    import numpy as np
+    c = np.asarray(coords, dtype=np.float64)
+    phase = 2.1 * c[:, 0] + 0.37 * c[:, 1] + 0.73 * c[:, 2] + 1.13 * c[:, 3] + salt
+    return np.cos(phase[:, None] + 0.05 * np.arange(width)[None, :]).astype(np.float32)
 
 
 def main_train():
@@ -224,17 +235,32 @@ def main_train():
         model.train()
         coords_list = []
         out = {"weight_seed": np.int64(wseed), "proj_seed": np.int64(pseed), "coordinates": np.array(coordinates),
-               "quantization_step": np.array([float(step)]), "n_scans": np.int64(len(scans))}
+               "quantization_step": np.array([float(s_) for s_ in step.split(",")]), "n_scans": np.int64(len(scans))}
         for b, (seed, n) in enumerate(scans):
             pc = kitti_like_filter(lidar_scan(seed, n_points=n))
             coords, _ = mp.quantizer(torch.from_numpy(pc))
             coords_list.append(coords)
         bc = ME.utils.batched_coordinates(coords_list)
         feats = torch.ones((bc.shape[0], 1), dtype=torch.float32)
+        captured = {}
+        hook = model.local_head.register_forward_hook(lambda m, i, o: captured.setdefault("xl", o))
         y = model({"coords": bc, "features": feats})                    # REFERENCE forward, train mode
+        hook.remove()
         g = y["global"]
         R = torch.from_numpy(np.random.default_rng(pseed).standard_normal(tuple(g.shape)).astype(np.float32))
         loss = (g * R).sum()
+        # local outputs: a linear functional with coordinate-keyed weights (row order is implementation defined)
+        xl = captured["xl"]
+        kc = xl.C.numpy().astype(np.int32)
+        for b, rows in enumerate(xl._batchwise_row_indices):
+            cb = kc[rows.numpy()]
+            out[f"kp_coords_{b}"] = cb
+            out[f"descriptors_{b}"] = y["descriptors"][b].detach().numpy()
+            out[f"keypoints_{b}"] = y["keypoints"][b].detach().numpy()
+            out[f"sigma_{b}"] = y["sigma"][b].detach().numpy()
+            loss = loss + (y["descriptors"][b] * torch.from_numpy(row_weights(cb, 128, 0.1))).sum() \
+                        + (y["keypoints"][b] * torch.from_numpy(row_weights(cb, 3, 0.2))).sum() \
+                        + (y["sigma"][b] * torch.from_numpy(row_weights(cb, 1, 0.3))).sum()
         loss.backward()
         out["coords"] = bc.numpy().astype(np.int32)
         out["global"] = g.detach().numpy()

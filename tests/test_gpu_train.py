@@ -169,15 +169,26 @@ def _digest(name, g):
     return np.concatenate([[np.linalg.norm(g), float(g @ r)], g[:64] if g.size > 4096 else g])
 
 
-def test_train_step_matches_reference_fixture():
-    """forward (batch-statistics BN), backward and running-stat update of one step vs the reference graph's autograd."""
+def _row_weights(coords, width, salt):
+    c = np.asarray(coords, dtype=np.float64)
+    phase = 2.1 * c[:, 0] + 0.37 * c[:, 1] + 0.73 * c[:, 2] + 1.13 * c[:, 3] + salt
+    return np.cos(phase[:, None] + 0.05 * np.arange(width)[None, :]).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["egonn_train_cart03", "egonn_train_polar"])
+def test_train_step_matches_reference_fixture(name):
+    """forward (batch-statistics BN, all four outputs), backward into all 104 parameters and the running-stat update
+    of one step vs the autograd of the reference's own graph (tests/golden/make_golden.py train)."""
     import __graft_entry__ as ge
     ge.build()
     import egonn_amd
     from egonn_amd import _lib
     dev = _lib.require_gpu()
-    case = H.load_case("egonn_train_cart03")
-    mp = egonn_amd.ModelParams(model="egonn", coordinates="cartesian", quantization_step=float(case["quantization_step"][0]))
+    case = H.load_case(name)
+    polar = str(case["coordinates"]) == "polar"
+    step = [float(v) for v in case["quantization_step"]]
+    mp = egonn_amd.ModelParams(model="egonn", coordinates="polar" if polar else "cartesian",
+                               quantization_step=step if polar else step[0])
     model = egonn_amd.model_factory(mp)
     w = H.seeded_weights(int(case["weight_seed"]))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
@@ -191,11 +202,22 @@ def test_train_step_matches_reference_fixture():
     assert np.allclose(g.detach().cpu().numpy(), ref_g, rtol=2e-3, atol=2e-4 * np.abs(ref_g).max())
     R = torch.from_numpy(np.random.default_rng(int(case["proj_seed"])).standard_normal(ref_g.shape).astype(np.float32)).to(dev)
     loss = (g * R).sum()
+    kcs = model.keypoint_coords()
+    for b in range(int(case["n_scans"])):
+        kc = kcs[b].cpu().numpy()
+        perm = H.join_perm(kc, case[f"kp_coords_{b}"])              # fixture row -> my row
+        d, k, sg = y["descriptors"][b], y["keypoints"][b], y["sigma"][b]
+        assert H.cosine_err(d.detach().cpu().numpy()[perm], case[f"descriptors_{b}"]).max() <= 1e-4
+        assert np.allclose(k.detach().cpu().numpy()[perm], case[f"keypoints_{b}"], atol=2e-3)
+        assert np.allclose(sg.detach().cpu().numpy()[perm], case[f"sigma_{b}"], rtol=2e-3, atol=1e-5)
+        loss = loss + (d * torch.from_numpy(_row_weights(kc, 128, 0.1)).to(dev)).sum() \
+                    + (k * torch.from_numpy(_row_weights(kc, 3, 0.2)).to(dev)).sum() \
+                    + (sg * torch.from_numpy(_row_weights(kc, 1, 0.3)).to(dev)).sum()
     assert abs(loss.item() - float(case["loss"])) <= 2e-3 * max(1.0, abs(float(case["loss"])))
     loss.backward()
     grads = {k: p.grad for k, p in model.named_parameters()}
     keys = [k[5:] for k in case if k.startswith("grad/")]
-    assert len(keys) == 89
+    assert len(keys) == 104 == len(grads)
     bad = []
     for k in keys:
         assert grads[k] is not None, k
@@ -206,15 +228,9 @@ def test_train_step_matches_reference_fixture():
         if err > 5e-3:
             bad.append((k, err))
     assert not bad, bad
-    for k, p in grads.items():
-        if k not in keys:
-            assert p is None or float(p.abs().max()) == 0.0, k          # local head: untouched by the global loss
     sd = model.state_dict()
     for k in [k[4:] for k in case if k.startswith("buf/")]:
-        ref = case["buf/" + k]
-        if not k.startswith(("trunk", "global")):
-            continue
-        assert np.allclose(sd[k].cpu().numpy(), ref, rtol=1e-3, atol=1e-5), k
+        assert np.allclose(sd[k].cpu().numpy(), case["buf/" + k], rtol=1e-3, atol=1e-5), k
 
 
 # ----------------------------------------------------------------------------- sharded step == single-process step
