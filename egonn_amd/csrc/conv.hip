@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int relu,
                                                           float* __restrict__ out, int32_t n_out, int K, int T,
-                                                          uint32_t in_bytes) {
+                                                          uint32_t in_bytes, uint32_t w_bytes) {
   using C = SconvCfg<CIN, COUT>;
   // gather prefetch depth (chunks in flight per wave): the A rows come from L2/HBM at random-access latency
   constexpr int SLOT_F4 = C::KSTEPS * (1 + C::NT);             // float4 registers per ring slot (A + W)
@@ -213,17 +213,20 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
   // (row -1 -> offset beyond num_records): no predicate, no branch, counted waits.
   const __amdgpu_buffer_rsrc_t a_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, (int)w_bytes, 0x00020000);
   f32x4 aring[DDEPTH][C::KSTEPS];
   f32x4 wring[DDEPTH][C::NT][C::KSTEPS];
   auto slot_load = [&](int32_t j, int k, auto RS) {
     constexpr int rs = decltype(RS)::value;
     // W is pre-packed in fragment order (pack_sconv_weights): one coalesced float4 per lane per (nt, t)
-    const f32x4* wk = reinterpret_cast<const f32x4*>(W + (size_t)k * CIN * COUT) +
-                      (size_t)(nsl * C::NT) * C::KSTEPS * 64 + lane;
+    const uint32_t woff = ((uint32_t)k * (uint32_t)(CIN * COUT) + (uint32_t)(nsl * C::NT * C::KSTEPS * 64 + lane) * 4u) * 4u;
 #pragma unroll
     for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
-      for (int t = 0; t < C::KSTEPS; ++t) wring[rs][nt][t] = wk[(nt * C::KSTEPS + t) * 64];
+      for (int t = 0; t < C::KSTEPS; ++t)
+        wring[rs][nt][t] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(woff + (uint32_t)((nt * C::KSTEPS + t) * 64 * 16)), 0, 0));
     const uint32_t off = (uint32_t)j * (uint32_t)(CIN * 4) + (uint32_t)(16 * g4);   // j = -1 -> >= 2^32 - CIN*4
 #pragma unroll
     for (int t = 0; t < C::KSTEPS; ++t)
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
   // are the all-padding chunk: zero A rows, +0 on the dummy accumulator row) and made provably wave-uniform, so
   // there is no branch between the loads and their waits — with per-chunk bounds checks hipcc emitted
   // s_waitcnt vmcnt(0) at the head of every group and the ring never overlapped anything.
-  const int n_groups = __builtin_amdgcn_readfirstlane((my_chunks + DDEPTH - 1) / DDEPTH);
+  const int n_groups = (relu & 2) ? 0 : __builtin_amdgcn_readfirstlane((my_chunks + DDEPTH - 1) / DDEPTH);   // bit 1: measurement hook
   for (int g = 0; g < n_groups; ++g) {
     [&]<int... Is>(std::integer_sequence<int, Is...>) {
       (body(g * DDEPTH + Is, std::integral_constant<int, Is>{}), ...);
@@ -364,6 +367,8 @@ int pack_sconv_weights(const float* W, int K, int cin, int cout, float* out, hip
 
 static int g_sconv_tile = 0;   // tuning hook: 0 = auto, else forced tile rows (64 / 128)
 static int g_sconv_abl = 0;
+static int g_sconv_skip = 0;   // measurement only: 1 = weight loads return zeros (no traffic), 2 = gathers return zeros
+void sconv_set_skip(int m) { g_sconv_skip = m; }
 static int g_sconv_split_target = 128;   // workgroups wanted per launch before kernel offsets are split
 void sconv_set_variant(int v) { g_sconv_abl = v & 7; g_sconv_split_target = (v & 4) ? 1 : ((v & 2) ? 512 : 128); g_sconv_tile = ((v >> 8) & 3) == 1 ? 64 : ((v >> 8) & 3) == 2 ? 128 : ((v >> 8) & 3) == 3 ? 32 : 0; }
 
@@ -374,6 +379,7 @@ static int launch_sconv(const float* in, int64_t n_in, const int32_t* nbr, const
   EGONN_REQUIRE((uint64_t)n_in * CIN * 4 < (1ull << 32) - 4096, EGONN_ERR_INVALID,
                 "sconv: input feature map of %lld rows exceeds the 4 GiB buffer-resource range", (long long)n_in);
   const uint32_t in_bytes = (uint32_t)((uint64_t)n_in * CIN * 4);
+  const uint32_t w_bytes = (g_sconv_skip & 1) ? 0u : (uint32_t)((size_t)K * CIN * COUT * 4);
   // 64-row tiles: the kernel is latency bound, more resident workgroups beat better chunk fill (tools/bench_sconv.py)
   const int T = g_sconv_tile ? g_sconv_tile : 64;
   const int tiles = (int)cdiv(n_out, T);
@@ -394,12 +400,13 @@ static int launch_sconv(const float* in, int64_t n_in, const int32_t* nbr, const
   hipEvent_t* pev = prof_kernel_events();
   if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
     hipExtLaunchKernelGGL((sconv_mfma_kernel<CIN, COUT>), dim3((unsigned)tiles, (unsigned)nsplit), dim3(256), lds,
-                          stream, pev[0], pev[1], 0, in, nbr, W, scale, shift, (relu ? 1 : 0), dst, n_out, K, T,
-                          in_bytes);
+                          stream, pev[0], pev[1], 0, in, nbr, W, scale, shift, ((relu ? 1 : 0) | ((g_sconv_skip & 4) ? 2 : 0)), dst, n_out, K, T,
+                          (g_sconv_skip & 2) ? 0u : in_bytes, w_bytes);
     pev[0] = pev[1] = nullptr;
   } else {
     hipLaunchKernelGGL((sconv_mfma_kernel<CIN, COUT>), dim3((unsigned)tiles, (unsigned)nsplit), dim3(256), lds,
-                       stream, in, nbr, W, scale, shift, (relu ? 1 : 0), dst, n_out, K, T, in_bytes);
+                       stream, in, nbr, W, scale, shift, ((relu ? 1 : 0) | ((g_sconv_skip & 4) ? 2 : 0)), dst, n_out, K, T,
+                       (g_sconv_skip & 2) ? 0u : in_bytes, w_bytes);
   }
   if (nsplit > 1) {
     const int64_t n4 = (int64_t)n_out * COUT / 4;

@@ -17,6 +17,7 @@ int pack_sconv_weights(const float* W, int K, int cin, int cout, float* out, hip
 static constexpr size_t SCONV_SCRATCH_FLOATS = (size_t)8 << 20;   // 32 MB: >= 512 tiles x 64 rows x 128 ch
 void sconv_set_naive(bool on);
 void sconv_set_variant(int v);
+void sconv_set_skip(int m);
 int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, const float* scale,
                      const float* shift, int relu, float* out, hipStream_t stream);
 

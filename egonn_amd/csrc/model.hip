@@ -76,6 +76,7 @@ API const char* egonn_last_error(void) { return last_error(); }
 
 API int egonn_debug_set_naive_conv(int on) {
   sconv_set_naive((on & 1) != 0);
+  sconv_set_skip((on >> 16) & 7);   // measurement hook: operand loads that return zeros without traffic
   if (on & 0x100) sconv_set_variant(((on >> 4) & 7) | (((on >> 12) & 3) << 8));   // tuning hook: variant, tile
   return EGONN_OK;
 }

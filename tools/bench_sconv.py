@@ -17,7 +17,7 @@ lib = _lib.load()
 cfgs = [(1, 32, 32, 3)] if os.environ.get("ONLY32") else [(1, 32, 32, 3), (2, 32, 64, 3), (2, 64, 64, 3), (3, 64, 64, 3), (4, 128, 128, 3), (6, 128, 128, 3), (1, 32, 32, 2)]
 res = {}
 for var in map(int, os.environ.get("VARS", "0,7,16,23").split(",")):
-    lib.egonn_debug_set_naive_conv(0x100 | ((var & 7) << 4) | ((var >> 4) << 12))
+    lib.egonn_debug_set_naive_conv(0x100 | ((var & 7) << 4) | (((var >> 4) & 3) << 12) | ((var >> 8) << 16))   # var bits 8-9: skip W / skip A loads
     for (lvl, ci, co, ks) in cfgs:
         lin = lvl if ks == 3 else lvl - 1
         x = torch.randn(ctx.level_count(lin), ci, device="cuda")
