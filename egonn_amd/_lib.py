@@ -52,6 +52,8 @@ _SIGS = [
     ("egonn_conv_backward_weight", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P,
                                              C.c_int64, _P]),
     ("egonn_col_stats", C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int, _P, _P, C.c_int64, _P]),
+    ("egonn_bn_train_finalize", C.c_int, [_P, _P, C.c_double, C.c_int, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P]),
+    ("egonn_bn_backward_finalize", C.c_int, [_P, _P, C.c_double, C.c_int, _P, _P, _P, _P, _P]),
     ("egonn_affine_act", C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P]),
     ("egonn_affine3", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, _P, _P]),
     ("egonn_relu_backward", C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P]),
@@ -278,8 +280,14 @@ class Context:
         return buf
 
     def _call(self, fn, *args):
-        with torch.cuda.device(self.device):
-            check(fn(*args, _stream()))
+        idx = self.device.index
+        if idx is None or torch.cuda.current_device() == idx:       # common case: no device switch needed
+            rc = fn(*args, torch.cuda.current_stream().cuda_stream)
+        else:
+            with torch.cuda.device(self.device):
+                rc = fn(*args, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            check(rc)
 
     def dense(self, x, weight, out_in: bool, bias=None, act: int = 0):
         x, weight = _dev_f32(x, self.device), _dev_f32(weight, self.device)

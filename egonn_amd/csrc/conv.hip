@@ -370,7 +370,7 @@ static int g_sconv_abl = 0;
 static int g_sconv_skip = 0;   // measurement only: 1 = weight loads return zeros (no traffic), 2 = gathers return zeros
 void sconv_set_skip(int m) { g_sconv_skip = m; }
 static int g_sconv_split_target = 128;   // workgroups wanted per launch before kernel offsets are split
-void sconv_set_variant(int v) { g_sconv_abl = v & 7; g_sconv_split_target = (v & 4) ? 1 : ((v & 2) ? 512 : 128); g_sconv_tile = ((v >> 8) & 3) == 1 ? 64 : ((v >> 8) & 3) == 2 ? 128 : ((v >> 8) & 3) == 3 ? 32 : 0; }
+void sconv_set_variant(int v) { g_sconv_abl = v & 7; g_sconv_split_target = (v & 4) ? 1 : ((v & 2) ? 512 : ((v & 1) ? 256 : 128)); g_sconv_tile = ((v >> 8) & 3) == 1 ? 64 : ((v >> 8) & 3) == 2 ? 128 : ((v >> 8) & 3) == 3 ? 32 : 0; }
 
 template <int CIN, int COUT>
 static int launch_sconv(const float* in, int64_t n_in, const int32_t* nbr, const float* W, const float* scale,

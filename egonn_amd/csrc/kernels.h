@@ -65,6 +65,10 @@ int conv0_wgrad(Ctx* ctx, const float* feat, const float* dout, float* dW, float
                 hipStream_t stream);
 int col_stats(int mode, const float* a, const float* b, const float* mask, const float* m, int64_t n, int c, float* out2c,
               float* scratch, size_t scratch_floats, hipStream_t stream);
+int bn_fwd_finalize(const float* sums, const float* m, double n, int c, const float* w, const float* b, float eps,
+                    float momentum, float* running_mean, float* running_var, float* out4, hipStream_t stream);
+int bn_bwd_finalize(const float* local, const float* global, double n, int c, const float* w, const float* mean,
+                    const float* invstd, float* out5, hipStream_t stream);
 int affine_act(const float* x, const float* A, const float* B, int64_t n, int c, int relu, float* out, hipStream_t stream);
 int affine3(const float* g, const float* mask, const float* x, const float* A, const float* B, const float* C, int64_t n,
             int c, float* out, hipStream_t stream);

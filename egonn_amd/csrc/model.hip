@@ -806,6 +806,21 @@ API int egonn_col_stats(int mode, const float* a, const float* b, const float* m
                         float* out, float* scratch, int64_t scratch_floats, void* stream) {
   return col_stats(mode, a, b, mask, mean, n, c, out, scratch, (size_t)scratch_floats, (hipStream_t)stream);
 }
+API int egonn_bn_train_finalize(const float* sums, const float* shift_point, double count, int c, const float* weight,
+                                const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                                float* out_mean_invstd_scale_shift, void* stream) {
+  EGONN_REQUIRE(sums && shift_point && weight && bias && out_mean_invstd_scale_shift && count >= 1.0 && c >= 1,
+                EGONN_ERR_INVALID, "bn_train_finalize: bad arguments");
+  return bn_fwd_finalize(sums, shift_point, count, c, weight, bias, eps, momentum, running_mean, running_var,
+                         out_mean_invstd_scale_shift, (hipStream_t)stream);
+}
+API int egonn_bn_backward_finalize(const float* local_sums, const float* global_sums, double count, int c,
+                                   const float* weight, const float* mean, const float* invstd, float* out_abc_dgamma_dbeta,
+                                   void* stream) {
+  EGONN_REQUIRE(local_sums && global_sums && weight && mean && invstd && out_abc_dgamma_dbeta && count >= 1.0,
+                EGONN_ERR_INVALID, "bn_backward_finalize: bad arguments");
+  return bn_bwd_finalize(local_sums, global_sums, count, c, weight, mean, invstd, out_abc_dgamma_dbeta, (hipStream_t)stream);
+}
 API int egonn_affine_act(const float* x, const float* scale, const float* shift, int64_t n, int c, int relu, float* out,
                          void* stream) {
   EGONN_REQUIRE(x && scale && shift && out, EGONN_ERR_INVALID, "affine_act: null argument");

@@ -103,6 +103,93 @@ __global__ __launch_bounds__((TCI / 4) * (TCO / 4)) void wgrad_kernel(
   }
 }
 
+// MFMA version for the sparse-conv channel plans: dW[k] (CIN x COUT) = A^T B with A = gathered input rows (pairs x CIN),
+// B = grad_out rows (pairs x COUT); v_mfma_f32_16x16x4_f32 with M = ci, N = co, K = 4 pairs per instruction.  Four
+// waves tile the CIN x COUT output (WM x WN waves, each (TM/WM) x (TN/WN) tiles of 16 x 16, accumulators in registers);
+// pairs are compacted like in wgrad_kernel and staged 32 at a time in LDS (row stride +16 floats: the four
+// lane groups of a fragment read four consecutive rows -> bank offsets 0/16, conflict free).
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                        const int32_t* __restrict__ nbr, int32_t n_out, int K,
+                                                        int32_t rows_per_chunk, float* __restrict__ partial) {
+  constexpr int TM = CIN / 16, TN = COUT / 16;
+  constexpr int WN = 2, WM = 2;
+  constexpr int TMW = TM / WM, TNW = TN / WN;
+  constexpr int PB = 32, LDA = CIN + 16, LDB = COUT + 16;
+  static_assert(TM % WM == 0 && TN % WN == 0, "bad wgrad tiling");
+  __shared__ int2 s_pair[256];
+  __shared__ __attribute__((aligned(16))) float s_a[PB * LDA];
+  __shared__ __attribute__((aligned(16))) float s_b[PB * LDB];
+  __shared__ int s_wcnt[4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, k = blockIdx.y, chunk = blockIdx.x;
+  const int wm = w / WN, wn = w % WN;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  wg_f32x4 acc[TMW][TNW];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) acc[i][j] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+  const int32_t r0 = chunk * rows_per_chunk;
+  const int32_t r1 = (int32_t)min((int64_t)n_out, (int64_t)r0 + rows_per_chunk);
+  for (int32_t base = r0; base < r1; base += 256) {
+    const int32_t o = base + t;
+    int32_t j = -1;
+    if (o < r1) j = nbr ? nbr[(int64_t)o * K + k] : o;
+    const bool v = j >= 0;
+    const uint64_t bal = __ballot(v);
+    if (lane == 0) s_wcnt[w] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < w) woff += s_wcnt[i];
+      cnt += s_wcnt[i];
+    }
+    if (v) s_pair[woff + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(j, o);
+    __syncthreads();
+    for (int p0 = 0; p0 < cnt; p0 += PB) {
+      for (int e = t; e < PB * (CIN / 4); e += 256) {
+        const int pr = e / (CIN / 4), c4 = e % (CIN / 4);
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p0 + pr < cnt) val = *reinterpret_cast<const float4*>(in + (int64_t)s_pair[p0 + pr].x * CIN + c4 * 4);
+        *reinterpret_cast<float4*>(&s_a[pr * LDA + c4 * 4]) = val;
+      }
+      for (int e = t; e < PB * (COUT / 4); e += 256) {
+        const int pr = e / (COUT / 4), c4 = e % (COUT / 4);
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p0 + pr < cnt) val = *reinterpret_cast<const float4*>(dout + (int64_t)s_pair[p0 + pr].y * COUT + c4 * 4);
+        *reinterpret_cast<float4*>(&s_b[pr * LDB + c4 * 4]) = val;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int sst = 0; sst < PB / 4; ++sst) {
+        float a[TMW], b[TNW];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) a[i] = s_a[(4 * sst + g4) * LDA + (wm * TMW + i) * 16 + l15];
+#pragma unroll
+        for (int jn = 0; jn < TNW; ++jn) b[jn] = s_b[(4 * sst + g4) * LDB + (wn * TNW + jn) * 16 + l15];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TNW; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[jn], acc[i][jn], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  float* dst = partial + ((int64_t)chunk * K + k) * CIN * COUT;
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TNW; ++jn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = (wm * TMW + i) * 16 + 4 * g4 + r, co = (wn * TNW + jn) * 16 + l15;
+        dst[(int64_t)ci * COUT + co] = acc[i][jn][r];
+      }
+}
+
 __global__ void sum_partials_kernel(const float* __restrict__ partial, int chunks, int64_t size, float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= size) return;
@@ -120,6 +207,30 @@ int conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int64_t n
   }
   EGONN_REQUIRE(scratch && scratch_floats >= (size_t)size, EGONN_ERR_INVALID,
                 "wgrad: scratch of %zu floats is smaller than one kernel (%lld)", scratch_floats, (long long)size);
+  const bool mfma = (cin == 32 && (cout == 32 || cout == 64)) || (cin == 64 && (cout == 64 || cout == 128)) ||
+                    (cin == 128 && cout == 128);
+  if (mfma) {
+    int64_t chunks = std::max<int64_t>(1, 2048 / (int64_t)K);
+    chunks = std::min<int64_t>(chunks, cdiv(n_out, 512));
+    chunks = std::max<int64_t>(1, std::min<int64_t>(chunks, (int64_t)(scratch_floats / (size_t)size)));
+    const int32_t rpc = (int32_t)cdiv(n_out, chunks);
+    chunks = cdiv(n_out, rpc);
+    const dim3 grid((unsigned)chunks, (unsigned)K);
+#define EGONN_WGRAD_CASE(CI, CO)                                                                                 \
+  if (cin == CI && cout == CO)                                                                                   \
+    hipLaunchKernelGGL((wgrad_mfma_kernel<CI, CO>), grid, dim3(256), 0, stream, in, dout, nbr, (int32_t)n_out, K, rpc, \
+                       scratch);
+    EGONN_WGRAD_CASE(32, 32)
+    EGONN_WGRAD_CASE(32, 64)
+    EGONN_WGRAD_CASE(64, 64)
+    EGONN_WGRAD_CASE(64, 128)
+    EGONN_WGRAD_CASE(128, 128)
+#undef EGONN_WGRAD_CASE
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(size, 256)), dim3(256), 0, stream, scratch, (int)chunks,
+                       size, dW);
+    HIP_CHECK(hipGetLastError());
+    return EGONN_OK;
+  }
   const bool small = cin <= 32 && cout <= 32;
   const int T = small ? 32 : 64, NT = small ? 64 : 256;
   const int tiles = (int)(cdiv(cin, T) * cdiv(cout, T));
@@ -238,6 +349,7 @@ int conv0_wgrad(Ctx* ctx, const float* feat, const float* dout, float* dW, float
 // mode 0: s0 = sum a            s1 = sum a^2
 // mode 1: s0 = sum (a - m)^2    s1 = 0                                  (second pass of the batch variance)
 // mode 2: g = a * [mask > 0] (mask nullable);  s0 = sum g,  s1 = sum g * (b - m)     (BatchNorm backward)
+// mode 3: d = a - m;  s0 = sum d,  s1 = sum d^2     (single-pass batch statistics around the shift m, additive over ranks)
 // block = 256 threads = (256/CP) row lanes x CP channel lanes (CP = channels padded to a power of two <= 256)
 static constexpr int CS_ROWS = 512;   // rows per block
 __global__ __launch_bounds__(256) void col_stats_kernel(int mode, const float* __restrict__ a, const float* __restrict__ b,
@@ -262,6 +374,13 @@ __global__ __launch_bounds__(256) void col_stats_kernel(int mode, const float* _
       for (int64_t r = r0 + rl; r < r1; r += nrl) {
         const float d = a[r * c + ci] - mu;
         s0 = fmaf(d, d, s0);
+      }
+    } else if (mode == 3) {
+#pragma unroll 4
+      for (int64_t r = r0 + rl; r < r1; r += nrl) {
+        const float d = a[r * c + ci] - mu;
+        s0 += d;
+        s1 = fmaf(d, d, s1);
       }
     } else if (mask) {
 #pragma unroll 4
@@ -307,7 +426,7 @@ __global__ __launch_bounds__(64) void sum_partials_wave_kernel(const float* __re
 int col_stats(int mode, const float* a, const float* b, const float* mask, const float* m, int64_t n, int c, float* out2c,
               float* scratch, size_t scratch_floats, hipStream_t stream) {
   EGONN_REQUIRE(c >= 1 && c <= 256, EGONN_ERR_INVALID, "col_stats: %d channels unsupported (1..256)", c);
-  EGONN_REQUIRE(mode >= 0 && mode <= 2 && a && (mode != 2 || b), EGONN_ERR_INVALID, "col_stats: bad arguments");
+  EGONN_REQUIRE(mode >= 0 && mode <= 3 && a && (mode != 2 || b), EGONN_ERR_INVALID, "col_stats: bad arguments");
   if (n == 0) {
     HIP_CHECK(hipMemsetAsync(out2c, 0, (size_t)2 * c * 4, stream));
     return EGONN_OK;
@@ -321,6 +440,65 @@ int col_stats(int mode, const float* a, const float* b, const float* mask, const
                      scratch);
   hipLaunchKernelGGL(sum_partials_wave_kernel, dim3((unsigned)(2 * c)), dim3(64), 0, stream, scratch, (int)blocks,
                      (int64_t)2 * c, out2c);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------------------------------- BatchNorm vector math
+// forward: sums (2,c) = [sum d, sum d^2] around shift m (whole batch, after the SyncBN all-reduce), count n ->
+//   mean, invstd, scale = w * invstd, shift = b - mean * scale (out4: 4 x c), running statistics updated in place
+//   (momentum; unbiased variance), exactly nn.BatchNorm1d's bookkeeping.
+__global__ void bn_fwd_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ m, double n, int c,
+                                       const float* __restrict__ w, const float* __restrict__ b, float eps, float momentum,
+                                       float* __restrict__ running_mean, float* __restrict__ running_var,
+                                       float* __restrict__ out4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const double sd = sums[i], sq = sums[c + i];
+  const double dm = sd / n;
+  const double mean = (double)m[i] + dm;
+  double var = sq / n - dm * dm;
+  var = var > 0.0 ? var : 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float scale = w[i] * invstd;
+  out4[i] = (float)mean;
+  out4[c + i] = invstd;
+  out4[2 * c + i] = scale;
+  out4[3 * c + i] = b[i] - (float)mean * scale;
+  if (running_mean) {
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * (float)mean;
+    running_var[i] = (1.f - momentum) * running_var[i] + momentum * (float)unbiased;
+  }
+}
+// backward: local sums (2,c) = [sum g', sum g'(x - mean)] of this rank, global sums (after the all-reduce), count n ->
+//   out5: A = w invstd, B = -w invstd^3 S2/n, C = -B mean - A S1/n, dgamma = S2_local invstd, dbeta = S1_local
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ local, const float* __restrict__ global, double n, int c,
+                                       const float* __restrict__ w, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* __restrict__ out5) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const double inv = invstd[i], wi = w[i];
+  const double A = wi * inv;
+  const double Bc = -wi * inv * inv * inv * (double)global[c + i] / n;
+  const double Cc = -Bc * (double)mean[i] - A * (double)global[i] / n;
+  out5[i] = (float)A;
+  out5[c + i] = (float)Bc;
+  out5[2 * c + i] = (float)Cc;
+  out5[3 * c + i] = (float)((double)local[c + i] * inv);
+  out5[4 * c + i] = local[i];
+}
+int bn_fwd_finalize(const float* sums, const float* m, double n, int c, const float* w, const float* b, float eps,
+                    float momentum, float* running_mean, float* running_var, float* out4, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((unsigned)cdiv(c, 64)), dim3(64), 0, stream, sums, m, n, c, w, b, eps,
+                     momentum, running_mean, running_var, out4);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+int bn_bwd_finalize(const float* local, const float* global, double n, int c, const float* w, const float* mean,
+                    const float* invstd, float* out5, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(c, 64)), dim3(64), 0, stream, local, global, n, c, w, mean,
+                     invstd, out5);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }

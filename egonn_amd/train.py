@@ -92,54 +92,68 @@ def combine_batch_stats(sum_x: torch.Tensor, count: torch.Tensor, group=None):
     return (buf[:-1] / total).float(), total
 
 
+def level_totals(ctx: _lib.Context, group=None) -> List[float]:
+    """rows of every level summed over the ranks of `group` (the N of the whole-batch BatchNorm statistics):
+    one all-reduce of 8 values per step."""
+    counts = [float(ctx.level_count(l)) for l in range(8)]
+    if group is None:
+        return counts
+    t = torch.tensor(counts, dtype=torch.float64, device=ctx.device)
+    _all_reduce(t, group)
+    return t.tolist()
+
+
 class BatchNormFn(Function):
-    """nn.BatchNorm1d over all rows in train mode (MinkowskiBatchNorm), optional fused ReLU, optional SyncBN."""
+    """nn.BatchNorm1d over all rows in train mode (MinkowskiBatchNorm), optional fused ReLU, optional SyncBN.
+    Statistics: ONE pass of shifted sums (sum d, sum d^2 with d = x - running_mean: additive over ranks, robust
+    against cancellation because the shift is close to the mean), all-reduced when `group` is given; the per-channel
+    bookkeeping (mean, invstd, folded scale/shift, running statistics; A/B/C, dgamma, dbeta in backward) runs in one
+    small kernel each."""
 
     @staticmethod
-    def forward(fctx, x, weight, bias, ctx: _lib.Context, bn: torch.nn.BatchNorm1d, relu: bool, group):
+    def forward(fctx, x, weight, bias, ctx: _lib.Context, bn: torch.nn.BatchNorm1d, relu: bool, group, total):
         n, c = x.shape
-        dev = x.device
-        s = ctx.col_stats(0, x)
-        mean, total = combine_batch_stats(s[0], torch.tensor(float(n), device=dev), group)
-        m2 = ctx.col_stats(1, x, mean=mean)[0].double()
-        _all_reduce(m2, group)
-        var = m2 / total                                            # biased, used for normalisation
-        invstd = torch.rsqrt(var + bn.eps).float()
-        scale = weight.detach() * invstd
-        shift = bias.detach() - mean * scale
-        y = ctx.affine_act(x, _c(scale), _c(shift), relu)
-        if bn.track_running_stats and bn.running_mean is not None:
-            with torch.no_grad():
-                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                unbiased = (m2 / torch.clamp(total - 1, min=1)).float()
-                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(unbiased, alpha=mom)
-                bn.num_batches_tracked += 1
-        fctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
-        fctx.meta = (ctx, relu, group, total)
+        lib = ctx.lib
+        track = bn.track_running_stats and bn.running_mean is not None
+        shift_pt = bn.running_mean if track else torch.zeros(c, dtype=torch.float32, device=x.device)
+        s = ctx.col_stats(3, x, mean=shift_pt)
+        _all_reduce(s, group)
+        total = float(total if total is not None else n)
+        out4 = torch.empty((4, c), dtype=torch.float32, device=x.device)
+        if track:
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+        else:
+            mom = 0.0
+        ctx._call(lib.egonn_bn_train_finalize, s.data_ptr(), shift_pt.data_ptr(), total, c, weight.data_ptr(),
+                  bias.data_ptr(), float(bn.eps), float(mom), _lib._ptr(bn.running_mean if track else None),
+                  _lib._ptr(bn.running_var if track else None), out4.data_ptr())
+        if track:
+            bn.num_batches_tracked += 1
+        y = ctx.affine_act(x, out4[2], out4[3], relu)
+        fctx.save_for_backward(x, y if relu else None, out4, weight)
+        fctx.meta = (ctx, group, total)
         return y
 
     @staticmethod
     def backward(fctx, g):
-        x, y, mean, invstd, weight = fctx.saved_tensors
-        ctx, relu, group, total = fctx.meta
+        x, y, out4, weight = fctx.saved_tensors
+        ctx, group, total = fctx.meta
+        c = x.shape[1]
         g = _c(g)
-        s = ctx.col_stats(2, g, b=x, mask=y, mean=mean)             # sum g', sum g' (x - mean)   (this rank's rows)
-        dbeta = s[0].clone()
-        dgamma = s[1] * invstd
-        sg = _all_reduce(s.double(), group)                         # whole-batch sums for the input gradient
-        w = weight.detach().double()
-        inv = invstd.double()
-        A = w * inv
-        Bc = -w * inv ** 3 * sg[1] / total
-        Cc = -Bc * mean.double() - A * sg[0] / total
-        dx = ctx.affine3(g, y, x, _c(A.float()), _c(Bc.float()), _c(Cc.float()))
-        return dx, dgamma, dbeta, None, None, None, None
+        s = ctx.col_stats(2, g, b=x, mask=y, mean=out4[0])          # sum g', sum g' (x - mean)   (this rank's rows)
+        sg = s
+        if group is not None:
+            sg = _all_reduce(s.clone(), group)                      # whole-batch sums for the input gradient
+        out5 = torch.empty((5, c), dtype=torch.float32, device=x.device)
+        ctx._call(ctx.lib.egonn_bn_backward_finalize, s.data_ptr(), sg.data_ptr(), total, c, weight.data_ptr(),
+                  out4[0].data_ptr(), out4[1].data_ptr(), out5.data_ptr())
+        dx = ctx.affine3(g, y, x, out5[0], out5[1], out5[2])
+        return dx, out5[3], out5[4], None, None, None, None, None
 
 
-def batch_norm(ctx, x, bn_module, relu: bool, group=None):
+def batch_norm(ctx, x, bn_module, relu: bool, group=None, total=None):
     bn = bn_module.bn
-    return BatchNormFn.apply(x, bn.weight, bn.bias, ctx, bn, relu, group)
+    return BatchNormFn.apply(x, bn.weight, bn.bias, ctx, bn, relu, group, total)
 
 
 # ----------------------------------------------------------------------------- per-sample pooling / ECA tail
@@ -181,7 +195,16 @@ def eca_tail(ctx, level, x, residual, eca_module):
     """layers/eca_block.py:21-36,66-73: gate = sigmoid(Conv1d_k(mean_b(x))), out = relu(x * gate + residual)."""
     m = SegmentMeanFn.apply(x, ctx, level)                                       # (B, C)
     conv = eca_module.conv
-    z = F.conv1d(m.unsqueeze(1), conv.weight, padding=conv.padding[0]).squeeze(1)   # (B, C): Conv1d over channels
+    # Conv1d(1, 1, k, padding=(k-1)/2, bias=False) over the channel axis of the (B, C) means, written as k shifted
+    # multiply-adds: F.conv1d's weight gradient uses atomics on this backend (run-to-run differences in the last bit),
+    # this form is deterministic
+    w = conv.weight.reshape(-1)
+    pad = int(conv.padding[0])
+    mp = F.pad(m, (pad, pad))
+    c = m.shape[1]
+    z = mp[:, 0:c] * w[0]
+    for t in range(1, w.shape[0]):
+        z = z + mp[:, t:t + c] * w[t]
     return GateResidualFn.apply(x, torch.sigmoid(z), residual, ctx, level)
 
 
@@ -271,21 +294,22 @@ class GeMFn(Function):
 def trunk_forward(model, ctx, group=None) -> Dict[int, torch.Tensor]:
     """MinkTrunk.forward (reference models/minkgl.py:136-153) with all-ones input features."""
     t = model.trunk
+    tot = level_totals(ctx, group)
     x = SparseConvFn.apply(None, t.convs['0'].kernel, ctx, 0, 0, t.convs['0'].kernel_size, False)
-    x = batch_norm(ctx, x, t.bn['0'], True, group)
+    x = batch_norm(ctx, x, t.bn['0'], True, group, tot[0])
     levels = {}
     for i in range(1, len(t.planes) + 1):
         x = sparse_conv(ctx, x, t.convs[str(i)], i - 1, i)
-        x = batch_norm(ctx, x, t.bn[str(i)], True, group)
+        x = batch_norm(ctx, x, t.bn[str(i)], True, group, tot[i])
         for blk in t.blocks[str(i)]:
             y = sparse_conv(ctx, x, blk.conv1, i, i)
-            y = batch_norm(ctx, y, blk.norm1, True, group)
+            y = batch_norm(ctx, y, blk.norm1, True, group, tot[i])
             y = sparse_conv(ctx, y, blk.conv2, i, i)
-            y = batch_norm(ctx, y, blk.norm2, False, group)
+            y = batch_norm(ctx, y, blk.norm2, False, group, tot[i])
             res = x
             if blk.downsample is not None:
                 res = sparse_conv(ctx, x, blk.downsample[0], i, i)
-                res = batch_norm(ctx, res, blk.downsample[1], False, group)
+                res = batch_norm(ctx, res, blk.downsample[1], False, group, tot[i])
             x = eca_tail(ctx, i, y, res, blk.eca)
         levels[i] = x
     return levels

@@ -161,9 +161,19 @@ int egonn_conv_backward_weight(egonn_ctx* ctx, int level_in, int level_out, int 
                                float* scratch, int64_t scratch_floats, void* stream);
 /* Per-channel reductions over (n,c) rows -> out (2,c).  MinkowskiBatchNorm in train mode = nn.BatchNorm1d over all
  * rows (models/minkgl.py:102,107):  mode 0: sum a, sum a^2;  mode 1: sum (a-mean)^2, 0;
- * mode 2 (backward): g = a*[mask>0] (mask nullable): sum g, sum g*(b-mean).  scratch >= 2*c*ceil(n/512) floats. */
+ * mode 2 (backward): g = a*[mask>0] (mask nullable): sum g, sum g*(b-mean);  mode 3: d = a-mean: sum d, sum d^2 (one-pass
+ * statistics around a shift point, additive over ranks for SyncBN).  scratch >= 2*c*ceil(n/512) floats. */
 int egonn_col_stats(int mode, const float* a, const float* b, const float* mask, const float* mean, int64_t n, int c,
                     float* out, float* scratch, int64_t scratch_floats, void* stream);
+/* Per-channel BatchNorm bookkeeping of nn.BatchNorm1d in train mode, on the device:
+ * forward: sums (2,c) from mode 3 around shift_point (c) over `count` rows (whole batch) -> out (4,c) = mean, invstd,
+ * scale = weight*invstd, shift = bias - mean*scale; running_mean/var (nullable) updated with `momentum` (unbiased var).
+ * backward: local/global (2,c) sums from mode 2 -> out (5,c) = A, B, C of egonn_affine3, dgamma, dbeta. */
+int egonn_bn_train_finalize(const float* sums, const float* shift_point, double count, int c, const float* weight,
+                            const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                            float* out_mean_invstd_scale_shift, void* stream);
+int egonn_bn_backward_finalize(const float* local_sums, const float* global_sums, double count, int c, const float* weight,
+                               const float* mean, const float* invstd, float* out_abc_dgamma_dbeta, void* stream);
 /* out = relu?(x*scale[c] + shift[c]) — BatchNorm application with batch statistics folded by the caller. */
 int egonn_affine_act(const float* x, const float* scale, const float* shift, int64_t n, int c, int relu, float* out,
                      void* stream);

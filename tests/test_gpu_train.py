@@ -102,7 +102,7 @@ def test_batch_norm_train_matches_torch(plan, relu):
         bn.weight.copy_(rnd((c,), 9, dev) * 0.2 + 1.0)
         bn.bias.copy_(rnd((c,), 10, dev) * 0.1)
     G = rnd((n, c), 11, dev)
-    y = BatchNormFn.apply(x, bn.weight, bn.bias, ctx, bn, relu, None)
+    y = BatchNormFn.apply(x, bn.weight, bn.bias, ctx, bn, relu, None, None)
     (y * G).sum().backward()
     ref = torch.nn.BatchNorm1d(c)
     with torch.no_grad():
@@ -326,3 +326,25 @@ def test_sharded_step_equals_single_process_step(tmp_path):
         for k, v in got["bufs"].items():
             if k.startswith(("trunk", "global")):
                 assert torch.allclose(v, want_buf[k], rtol=1e-4, atol=1e-6), (r, k)
+
+
+def test_train_step_is_bitwise_deterministic():
+    """two steps from the same state give bitwise identical loss and gradients (fixed-order reductions everywhere; the
+    ECA Conv1d is written as shifted multiply-adds because F.conv1d's weight gradient uses atomics on this backend)."""
+    import __graft_entry__ as ge
+    ge.build()
+    from egonn_amd import _lib
+    from egonn_amd.train import TrainStep
+    dev = _lib.require_gpu()
+    case = H.load_case("egonn_train_cart03")
+    coords = torch.from_numpy(case["coords"])
+    pos, neg = _masks()
+    runs = []
+    for _ in range(2):
+        model = _make_model(dev, int(case["weight_seed"]))
+        step = TrainStep(model, torch.optim.SGD(model.parameters(), lr=0.0), margin=0.2)
+        loss, _ = step(_scan_batch(dev, coords, [0, 1, 2]), pos, neg, step_optimizer=False)
+        runs.append((float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert runs[0][0] == runs[1][0]
+    for k, g in runs[0][1].items():
+        assert torch.equal(g, runs[1][1][k]), k
