@@ -193,3 +193,24 @@ def test_ingest_oracle_known_answer():
                    dtype=np.float32)
     pc = I.preprocess(I.read_pc(raw), "mulran")
     assert pc.tolist() == [[1.0, 2.0, np.float32(-0.8999)], [5.0, 6.0, 7.0]]
+
+
+def test_c_openmp_oracle_matches_numpy_oracle_and_fixture():
+    """oracle/egonn_cpu.c (the CPU baseline bench.py times) vs the numpy oracle and the reference-graph fixture."""
+    from oracle import egonn_cpu, egonn_ref as ref
+    case = H.load_case("egonn_cart01_b1")
+    w = H.seeded_weights(int(case["weight_seed"]))
+    pc = case["points_0"]
+    co = egonn_cpu.CpuOracle(w, 0.1)
+    g, kp, desc, coords, sigma, counts = co.compute_embedding(pc, 128)
+    # fixture produced by the reference's own graph code
+    assert H.cosine_err(g, case["global"]).max() <= 1e-4
+    assert counts[0] == len(case["quant_coords_0"]) and counts[3] == len(case["kp_coords_0"])
+    assert np.array_equal(coords, case["topk_coords_0"][:, 1:])                 # the 128 selected super-voxels, in order
+    assert np.allclose(sigma, case["topk_sigma_0"], rtol=1e-3, atol=1e-6)
+    # numpy oracle: same selection, same keypoints / descriptors
+    orc = ref.EgoNNOracle(w, ref.CartesianQuantizer(0.1))
+    g2, kp2, desc2, c2 = ref.compute_embedding(orc, pc, 128)
+    assert np.array_equal(coords, c2[:, 1:])
+    assert np.allclose(kp, kp2, atol=2e-4) and H.cosine_err(desc, desc2).max() <= 1e-5
+    assert H.cosine_err(g, g2).max() <= 1e-6
