@@ -17,6 +17,6 @@ timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_pf -o pf --
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_pw -o pw -- $BENCH > $OUT/${TAG}_pw.log 2>&1
 cd $REPO
 KT=$(find $OUT/${TAG}_kt -name '*.db' | head -1); PF=$(find $OUT/${TAG}_pf -name '*.db' | head -1); PW=$(find $OUT/${TAG}_pw -name '*.db' | head -1)
-python tools/rocpd_summary.py $KT $OUT/${TAG}_kernel_stats.csv 26
+python tools/rocpd_summary.py $KT $OUT/${TAG}_kernel_stats.csv 34
 python tools/pmc_traffic.py $PF $PW $OUT/${TAG}_traffic.json
 rm -rf $OUT/${TAG}_kt $OUT/${TAG}_pf $OUT/${TAG}_pw
