@@ -514,6 +514,48 @@ __global__ void nbrT_kernel(const int32_t* __restrict__ parent, const uint64_t* 
   o[1] = make_int4(r[4], r[5], r[6], r[7]);
 }
 
+// both tables of every level 1..7 in ONE launch (the 14 per-level launches were ~5 us of dispatch each)
+struct Nbr8TArgs {
+  const int32_t* cstart[EGONN_NUM_LEVELS];
+  const uint64_t* ckeys[EGONN_NUM_LEVELS];    // keys of level l-1
+  const int32_t* parent[EGONN_NUM_LEVELS];
+  const uint64_t* keys[EGONN_NUM_LEVELS];
+  int32_t* nbr8[EGONN_NUM_LEVELS];
+  int32_t* nbrT[EGONN_NUM_LEVELS];
+  int32_t prefix[EGONN_NUM_LEVELS + 1];       // prefix over levels 1..7 of their row counts; [0] unused
+};
+__global__ void nbr8T_all_kernel(Nbr8TArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.prefix[EGONN_NUM_LEVELS]) return;
+  int l = 1;
+  while (l < EGONN_NUM_LEVELS - 1 && t >= a.prefix[l + 1]) ++l;
+  const int32_t p = (int32_t)(t - a.prefix[l]);
+  {
+    int32_t r[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    const int32_t s = a.cstart[l][p], e = a.cstart[l][p + 1];
+    const uint64_t* ck = a.ckeys[l];
+    for (int32_t c = s; c < e; ++c) {
+      const int slot = (int)(ck[c] & 7);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (q == slot) r[q] = c;
+    }
+    int4* o = reinterpret_cast<int4*>(a.nbr8[l] + (int64_t)p * 8);
+    o[0] = make_int4(r[0], r[1], r[2], r[3]);
+    o[1] = make_int4(r[4], r[5], r[6], r[7]);
+  }
+  {
+    const int slot = (int)(a.keys[l][p] & 7);
+    const int32_t par = a.parent[l][p];
+    int32_t r[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[q] = (q == slot) ? par : -1;
+    int4* o = reinterpret_cast<int4*>(a.nbrT[l] + (int64_t)p * 8);
+    o[0] = make_int4(r[0], r[1], r[2], r[3]);
+    o[1] = make_int4(r[4], r[5], r[6], r[7]);
+  }
+}
+
 __global__ void decode_coords_kernel(const uint64_t* __restrict__ keys, int32_t n, int level, int cb,
                                      int32_t* __restrict__ out) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -639,17 +681,28 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
                          P.lv[2].mask, P.lv[2].bstart, n2 * 27, P.t2m, P.t2s);
     }
   }
-  for (int l = 1; l < EGONN_NUM_LEVELS; ++l) {
-    Level& V = P.lv[l];
-    const int32_t nv = (int32_t)V.n;
-    V.nbr8 = A.alloc<int32_t>((size_t)nv * 8);
-    V.nbrT = A.alloc<int32_t>((size_t)nv * 8);
-    EGONN_REQUIRE(V.nbr8 && V.nbrT, EGONN_ERR_STATE, "plan arena too small");
-    if (nv == 0) continue;
-    hipLaunchKernelGGL(nbr8_kernel, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, stream, V.cstart, P.lv[l - 1].keys,
-                       nv, V.nbr8);
-    hipLaunchKernelGGL(nbrT_kernel, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, stream, V.parent, V.keys, nv,
-                       V.nbrT);
+  {
+    Nbr8TArgs na;
+    na.prefix[0] = na.prefix[1] = 0;
+    for (int l = 1; l < EGONN_NUM_LEVELS; ++l) {
+      Level& V = P.lv[l];
+      const int32_t nv = (int32_t)V.n;
+      V.nbr8 = A.alloc<int32_t>((size_t)nv * 8);
+      V.nbrT = A.alloc<int32_t>((size_t)nv * 8);
+      EGONN_REQUIRE(V.nbr8 && V.nbrT, EGONN_ERR_STATE, "plan arena too small");
+      na.cstart[l] = V.cstart;
+      na.ckeys[l] = P.lv[l - 1].keys;
+      na.parent[l] = V.parent;
+      na.keys[l] = V.keys;
+      na.nbr8[l] = V.nbr8;
+      na.nbrT[l] = V.nbrT;
+      na.prefix[l + 1] = na.prefix[l] + nv;
+    }
+    na.cstart[0] = nullptr; na.ckeys[0] = nullptr; na.parent[0] = nullptr; na.keys[0] = nullptr;
+    na.nbr8[0] = nullptr; na.nbrT[0] = nullptr;
+    const int64_t tot = na.prefix[EGONN_NUM_LEVELS];
+    if (tot > 0)
+      hipLaunchKernelGGL(nbr8T_all_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, stream, na);
   }
   HIP_CHECK(hipGetLastError());
   P.valid = true;
