@@ -45,6 +45,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--layer-table", type=str, default="", help="write a per-layer timing table (json) here")
     p.add_argument("--tune", type=int, default=-1, help="library tuning hook value (debug)")
+    p.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                   help="f32 = BASELINE configs[1] (default, the headline metric); bf16 = configs[2] arithmetic "
+                        "(sparse-conv MFMA operands rounded to bf16, fp32 accumulate, fp32 feature maps)")
     p.add_argument("--streams", type=int, default=3, help="batches in flight (HIP streams, one egonn_ctx each)")
     return p.parse_args()
 
@@ -85,6 +88,7 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.to(dev).eval()
     model.coord_bits = 12                                  # +-204.8 m at 0.1 m voxels: fewer radix passes
+    model.precision = "bf16" if args.dtype == "bf16" else "fp32"
     ex = DescriptorExtractor(model, n_k=128)
 
     scans = make_scans(rank, args.batch, args.points)
@@ -247,11 +251,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.dtype == "f32" else "bf16 (MFMA operands; f32 accumulate and feature maps)",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: EgoNN (minkgl) inference, synthetic 50k-pt LiDAR-like clouds, "
-                                   "Cartesian 0.1 m voxels, batch 16 per GPU, fp32; step = voxelise + forward + "
-                                   "top-128 keypoints; random-init weights",
+            "config": {"workload": ("configs[1]" if args.dtype == "f32" and args.batch == 16 else "configs[1] variant") +
+                                   ": EgoNN (minkgl) inference, synthetic 50k-pt LiDAR-like clouds, "
+                                   f"Cartesian 0.1 m voxels, batch {args.batch} per GPU, {args.dtype}; step = voxelise + "
+                                   "forward + top-128 keypoints; random-init weights",
                        "batch_per_gpu": args.batch, "points_per_scan": args.points, "voxel_m": args.voxel,
                        "voxels_per_level": n_levels, "parallelism": f"scan-sharded x{world} (no collective)", "batches_in_flight": args.streams},
             "roofline": roofline,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libegonn_hip.so")
 
 QUANT_CARTESIAN, QUANT_POLAR = 0, 1
-FLAG_DISABLE_GLOBAL, FLAG_DISABLE_LOCAL, FLAG_IGNORE_KP_REGRESSOR = 1, 2, 4
+FLAG_DISABLE_GLOBAL, FLAG_DISABLE_LOCAL, FLAG_IGNORE_KP_REGRESSOR, FLAG_BF16 = 1, 2, 4, 8
 
 # every symbol include/egonn_hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p

@@ -97,7 +97,18 @@ static size_t sconv_lds_bytes(int K, int T) {
 //   epilogue: group copies are summed, folded BatchNorm (+ReLU) applied, one coalesced float4 store per element.
 // History (profiles/r01*): an LDS-staged variant with a barrier per step spent its time serialised (ablation:
 // gather / W / accumulate / barrier / MFMA each 10-17 %); ds_add_f32 LDS atomics were 3.3x slower than the RMW.
-template <int CIN, int COUT>
+// BF16 = true: the MFMA operands are rounded to bf16 (A fragments converted in registers after the fp32 gather, W
+// pre-packed as bf16 in the same fragment order), products accumulate in fp32 on v_mfma_f32_16x16x32_bf16 — BASELINE
+// configs[2]; feature maps stay fp32 in HBM.  One instruction covers two of the 16-wide K slabs of the fp32 path: the
+// K index is a reduction index, so lane g simply owns columns {32s+4g..+3} and {32s+16+4g..+3} of both operands.
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ static inline uint32_t pack_bf16x2(float a, float b) {       // round to nearest even, a in the low half
+  uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua += 0x7FFFu + ((ua >> 16) & 1u);
+  ub += 0x7FFFu + ((ub >> 16) & 1u);
+  return (ua >> 16) | (ub & 0xFFFF0000u);
+}
+template <int CIN, int COUT, bool BF16>
 __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict__ in,
                                                           const int32_t* __restrict__ nbr,
                                                           const float* __restrict__ W,
@@ -107,7 +118,9 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
                                                           uint32_t in_bytes, uint32_t w_bytes) {
   using C = SconvCfg<CIN, COUT>;
   // gather prefetch depth (chunks in flight per wave): the A rows come from L2/HBM at random-access latency
-  constexpr int SLOT_F4 = C::KSTEPS * (1 + C::NT);             // float4 registers per ring slot (A + W)
+  constexpr int SLOT_F4 = BF16 ? (C::KSTEPS * (2 + C::NT) + 1) / 2 : C::KSTEPS * (1 + C::NT);   // float4 regs per ring slot (A + W)
+  // (deeper rings were measured: 6 / 8 slots for the <32,32> plan run 4 % / 15 % slower — registers cost more waves
+  //  than the extra lookahead hides)
   constexpr int DDEPTH = (SLOT_F4 <= 4) ? 4 : ((SLOT_F4 <= 12) ? 3 : 2);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* accL = reinterpret_cast<float*>(smem);                               // [WAVES_M][T+1][LDC]
@@ -215,18 +228,24 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, (int)w_bytes, 0x00020000);
+  using wfrag_t = std::conditional_t<BF16, uint2, f32x4>;      // one W fragment: 4 values per lane
   f32x4 aring[DDEPTH][C::KSTEPS];
-  f32x4 wring[DDEPTH][C::NT][C::KSTEPS];
+  wfrag_t wring[DDEPTH][C::NT][C::KSTEPS];
   auto slot_load = [&](int32_t j, int k, auto RS) {
     constexpr int rs = decltype(RS)::value;
     // W is pre-packed in fragment order (pack_sconv_weights): one coalesced float4 per lane per (nt, t)
-    const uint32_t woff = ((uint32_t)k * (uint32_t)(CIN * COUT) + (uint32_t)(nsl * C::NT * C::KSTEPS * 64 + lane) * 4u) * 4u;
+    constexpr uint32_t EB = BF16 ? 2u : 4u;                    // bytes per packed weight
+    const uint32_t woff = ((uint32_t)k * (uint32_t)(CIN * COUT) + (uint32_t)(nsl * C::NT * C::KSTEPS * 64 + lane) * 4u) * EB;
 #pragma unroll
     for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
-      for (int t = 0; t < C::KSTEPS; ++t)
-        wring[rs][nt][t] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(woff + (uint32_t)((nt * C::KSTEPS + t) * 64 * 16)), 0, 0));
+      for (int t = 0; t < C::KSTEPS; ++t) {
+        const int o = (int)(woff + (uint32_t)((nt * C::KSTEPS + t) * 64 * 4) * EB);
+        if constexpr (BF16)
+          wring[rs][nt][t] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, o, 0, 0));
+        else
+          wring[rs][nt][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, o, 0, 0));
+      }
     const uint32_t off = (uint32_t)j * (uint32_t)(CIN * 4) + (uint32_t)(16 * g4);   // j = -1 -> >= 2^32 - CIN*4
 #pragma unroll
     for (int t = 0; t < C::KSTEPS; ++t)
@@ -258,14 +277,30 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
     f32x4 acc[C::NT];
 #pragma unroll
     for (int nt = 0; nt < C::NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF16) {
 #pragma unroll
-    for (int t = 0; t < C::KSTEPS; ++t) {
-      const f32x4 a4 = aring[rs][t];
+      for (int t2 = 0; t2 < C::KSTEPS / 2; ++t2) {
+        const f32x4 a0 = aring[rs][2 * t2], a1 = aring[rs][2 * t2 + 1];
+        const uint4 ap = make_uint4(pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]),
+                                    pack_bf16x2(a1[2], a1[3]));
+        const bf16x8_t av = __builtin_bit_cast(bf16x8_t, ap);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+        for (int nt = 0; nt < C::NT; ++nt) {
+          const uint2 w0 = wring[rs][nt][2 * t2], w1 = wring[rs][nt][2 * t2 + 1];
+          const bf16x8_t bv = __builtin_bit_cast(bf16x8_t, make_uint4(w0.x, w0.y, w1.x, w1.y));
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[nt], 0, 0, 0);
+        }
+      }
+    } else {
 #pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u], wring[rs][nt][t][u], acc[nt], 0, 0, 0);
+      for (int t = 0; t < C::KSTEPS; ++t) {
+        const f32x4 a4 = aring[rs][t];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u], wring[rs][nt][t][u], acc[nt], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -357,6 +392,33 @@ __global__ void pack_sconv_weights_kernel(const float* __restrict__ W, int K, in
   const int co = nsl * nw + nt * 16 + (lane & 15);
   out[e] = W[(int64_t)k * per_k + (int64_t)ci * cout + co];
 }
+// same fragment order, values rounded to bf16 (round to nearest even): 2 bytes per weight
+__global__ void pack_sconv_weights_bf16_kernel(const float* __restrict__ W, int K, int cin, int cout,
+                                               uint16_t* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per_k = (int64_t)cin * cout;
+  if (e >= K * per_k) return;
+  const int k = (int)(e / per_k);
+  int64_t r = e - k * per_k;
+  const int nw = cout <= 32 ? 16 : 32, ntn = nw / 16, ksteps = cin / 16;
+  const int u = (int)(r & 3); r >>= 2;
+  const int lane = (int)(r & 63); r >>= 6;
+  const int t = (int)(r % ksteps); r /= ksteps;
+  const int nt = (int)(r % ntn); r /= ntn;
+  const int nsl = (int)r;
+  const int ci = 16 * t + 4 * (lane >> 4) + u;
+  const int co = nsl * nw + nt * 16 + (lane & 15);
+  uint32_t v = __float_as_uint(W[(int64_t)k * per_k + (int64_t)ci * cout + co]);
+  v += 0x7FFFu + ((v >> 16) & 1u);
+  out[e] = (uint16_t)(v >> 16);
+}
+int pack_sconv_weights_bf16(const float* W, int K, int cin, int cout, void* out, hipStream_t stream) {
+  const int64_t n = (int64_t)K * cin * cout;
+  hipLaunchKernelGGL(pack_sconv_weights_bf16_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, W, K, cin, cout,
+                     reinterpret_cast<uint16_t*>(out));
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
 int pack_sconv_weights(const float* W, int K, int cin, int cout, float* out, hipStream_t stream) {
   const int64_t n = (int64_t)K * cin * cout;
   hipLaunchKernelGGL(pack_sconv_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, W, K, cin, cout,
@@ -372,14 +434,14 @@ void sconv_set_skip(int m) { g_sconv_skip = m; }
 static int g_sconv_split_target = 128;   // workgroups wanted per launch before kernel offsets are split
 void sconv_set_variant(int v) { g_sconv_abl = v & 7; g_sconv_split_target = (v & 4) ? 1 : ((v & 2) ? 512 : ((v & 1) ? 256 : 128)); g_sconv_tile = ((v >> 8) & 3) == 1 ? 64 : ((v >> 8) & 3) == 2 ? 128 : ((v >> 8) & 3) == 3 ? 32 : 0; }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool BF16>
 static int launch_sconv(const float* in, int64_t n_in, const int32_t* nbr, const float* W, const float* scale,
                         const float* shift, int relu, float* out, int32_t n_out, int K, float* scratch,
                         size_t scratch_floats, hipStream_t stream) {
   EGONN_REQUIRE((uint64_t)n_in * CIN * 4 < (1ull << 32) - 4096, EGONN_ERR_INVALID,
                 "sconv: input feature map of %lld rows exceeds the 4 GiB buffer-resource range", (long long)n_in);
   const uint32_t in_bytes = (uint32_t)((uint64_t)n_in * CIN * 4);
-  const uint32_t w_bytes = (g_sconv_skip & 1) ? 0u : (uint32_t)((size_t)K * CIN * COUT * 4);
+  const uint32_t w_bytes = (g_sconv_skip & 1) ? 0u : (uint32_t)((size_t)K * CIN * COUT * (BF16 ? 2 : 4));
   // 64-row tiles: the kernel is latency bound, more resident workgroups beat better chunk fill (tools/bench_sconv.py)
   const int T = g_sconv_tile ? g_sconv_tile : 64;
   const int tiles = (int)cdiv(n_out, T);
@@ -392,19 +454,19 @@ static int launch_sconv(const float* in, int64_t n_in, const int32_t* nbr, const
   const size_t lds = sconv_lds_bytes<CIN, COUT>(K, T);
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_mfma_kernel<CIN, COUT>),
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_mfma_kernel<CIN, COUT, BF16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   float* dst = nsplit > 1 ? scratch : out;
   hipEvent_t* pev = prof_kernel_events();
   if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
-    hipExtLaunchKernelGGL((sconv_mfma_kernel<CIN, COUT>), dim3((unsigned)tiles, (unsigned)nsplit), dim3(256), lds,
+    hipExtLaunchKernelGGL((sconv_mfma_kernel<CIN, COUT, BF16>), dim3((unsigned)tiles, (unsigned)nsplit), dim3(256), lds,
                           stream, pev[0], pev[1], 0, in, nbr, W, scale, shift, ((relu ? 1 : 0) | ((g_sconv_skip & 4) ? 2 : 0)), dst, n_out, K, T,
                           (g_sconv_skip & 2) ? 0u : in_bytes, w_bytes);
     pev[0] = pev[1] = nullptr;
   } else {
-    hipLaunchKernelGGL((sconv_mfma_kernel<CIN, COUT>), dim3((unsigned)tiles, (unsigned)nsplit), dim3(256), lds,
+    hipLaunchKernelGGL((sconv_mfma_kernel<CIN, COUT, BF16>), dim3((unsigned)tiles, (unsigned)nsplit), dim3(256), lds,
                        stream, in, nbr, W, scale, shift, ((relu ? 1 : 0) | ((g_sconv_skip & 4) ? 2 : 0)), dst, n_out, K, T,
                        (g_sconv_skip & 2) ? 0u : in_bytes, w_bytes);
   }
@@ -422,7 +484,7 @@ void sconv_set_naive(bool on) { g_force_naive = on; }
 
 int sconv_forward(const float* in, int64_t n_in, const int32_t* nbr, const float* W, const float* Wp, const float* scale,
                   const float* shift, int relu, float* out, int32_t n_out, int K, int cin, int cout, float* scratch,
-                  size_t scratch_floats, hipStream_t stream) {
+                  size_t scratch_floats, hipStream_t stream, int bf16) {
   if (n_out == 0) return EGONN_OK;
   EGONN_REQUIRE(K == 27 || K == 8, EGONN_ERR_INVALID, "sconv: kernel volume %d not supported", K);
   const bool mfma_shape = (cin == 32 && (cout == 32 || cout == 64)) || (cin == 64 && (cout == 64 || cout == 128)) ||
@@ -432,14 +494,20 @@ int sconv_forward(const float* in, int64_t n_in, const int32_t* nbr, const float
       const size_t wn = (size_t)K * cin * cout;
       EGONN_REQUIRE(scratch && scratch_floats > wn, EGONN_ERR_STATE, "sconv: no scratch to pack the kernel into");
       float* packed = scratch + (scratch_floats - wn);
-      EGONN_TRY(pack_sconv_weights(W, K, cin, cout, packed, stream));
+      if (bf16)
+        EGONN_TRY(pack_sconv_weights_bf16(W, K, cin, cout, packed, stream));
+      else
+        EGONN_TRY(pack_sconv_weights(W, K, cin, cout, packed, stream));
       Wp = packed;
       scratch_floats -= wn;
     }
     W = Wp;
-#define EGONN_SCONV_CASE(CI, CO)  \
-  if (cin == CI && cout == CO)    \
-    return launch_sconv<CI, CO>(in, n_in, nbr, W, scale, shift, relu, out, n_out, K, scratch, scratch_floats, stream);
+#define EGONN_SCONV_CASE(CI, CO)                                                                                         \
+  if (cin == CI && cout == CO)                                                                                           \
+    return bf16 ? launch_sconv<CI, CO, true>(in, n_in, nbr, W, scale, shift, relu, out, n_out, K, scratch, scratch_floats,   \
+                                             stream)                                                                     \
+                : launch_sconv<CI, CO, false>(in, n_in, nbr, W, scale, shift, relu, out, n_out, K, scratch, scratch_floats,  \
+                                              stream);
     EGONN_SCONV_CASE(32, 32)
     EGONN_SCONV_CASE(32, 64)
     EGONN_SCONV_CASE(64, 64)
@@ -449,6 +517,7 @@ int sconv_forward(const float* in, int64_t n_in, const int32_t* nbr, const float
     EGONN_SCONV_CASE(128, 64)
 #undef EGONN_SCONV_CASE
   }
+  EGONN_REQUIRE(!bf16, EGONN_ERR_INVALID, "sconv: the bf16 operand path exists for the MFMA channel plans only (%d->%d)", cin, cout);
   const int64_t total = (int64_t)n_out * cout;
   hipLaunchKernelGGL(sconv_naive_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, in, nbr, W, scale,
                      shift, relu, out, n_out, K, cin, cout);

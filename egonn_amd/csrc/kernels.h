@@ -12,8 +12,9 @@ const char* last_error();
 // in: [n_in][cin] rows gathered through nbr; W: reference layout [K][cin][cout]; Wp: the same kernel in MFMA fragment order (pack_sconv_weights), or null
 int sconv_forward(const float* in, int64_t n_in, const int32_t* nbr, const float* W, const float* Wp, const float* scale,
                   const float* shift, int relu, float* out, int32_t n_out, int K, int cin, int cout, float* scratch,
-                  size_t scratch_floats, hipStream_t stream);
+                  size_t scratch_floats, hipStream_t stream, int bf16 = 0);   // bf16: Wp (if given) is the bf16 packing
 int pack_sconv_weights(const float* W, int K, int cin, int cout, float* out, hipStream_t stream);
+int pack_sconv_weights_bf16(const float* W, int K, int cin, int cout, void* out, hipStream_t stream);
 static constexpr size_t SCONV_SCRATCH_FLOATS = (size_t)8 << 20;   // 32 MB: >= 512 tiles x 64 rows x 128 ch
 void sconv_set_naive(bool on);
 void sconv_set_variant(int v);

@@ -69,6 +69,8 @@ struct egonn_model {
   float* packed = nullptr;
   size_t packed_cap = 0;
   const float *p_convs[8] = {}, *p_c1[8] = {}, *p_c2[8] = {}, *p_gt[8] = {}, *p_lt[8] = {};
+  // the same kernels packed as bf16 (EGONN_FLAG_BF16): [0] = fp32 set, [1] = bf16 set
+  const float *q_convs[8] = {}, *q_c1[8] = {}, *q_c2[8] = {}, *q_gt[8] = {}, *q_lt[8] = {};
 };
 
 // ------------------------------------------------------------------------------------------ lifecycle
@@ -477,10 +479,17 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
     need_p += (size_t)2 * 8 * GLOBAL_CH * GLOBAL_CH + (size_t)8 * LOCAL_CH * LOCAL_CH;
     if (m->packed_cap < need_p) {
       if (m->packed) HIP_CHECK(hipFree(m->packed));
-      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->packed), need_p * sizeof(float)));
+      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->packed), (need_p + need_p / 2 + 64) * sizeof(float)));
       m->packed_cap = need_p;
     }
     float* pc = m->packed;
+    uint16_t* qc = reinterpret_cast<uint16_t*>(m->packed + need_p);      // bf16 copies behind the fp32 ones
+    auto pack16 = [&](const float* w, int K, int ci, int co, const float** dst) -> int {
+      EGONN_TRY(pack_sconv_weights_bf16(w, K, ci, co, qc, st));
+      *dst = reinterpret_cast<const float*>(qc);
+      qc += (size_t)K * ci * co;
+      return EGONN_OK;
+    };
     auto pack = [&](const float* w, int K, int ci, int co, const float** dst) -> int {
       EGONN_TRY(pack_sconv_weights(w, K, ci, co, pc, st));
       *dst = pc;
@@ -492,10 +501,16 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
       EGONN_TRY(pack(m->convs[i], 8, b.cin, b.cin, &m->p_convs[i]));
       EGONN_TRY(pack(b.conv1, 27, b.cin, b.cout, &m->p_c1[i]));
       EGONN_TRY(pack(b.conv2, 27, b.cout, b.cout, &m->p_c2[i]));
+      EGONN_TRY(pack16(m->convs[i], 8, b.cin, b.cin, &m->q_convs[i]));
+      EGONN_TRY(pack16(b.conv1, 27, b.cin, b.cout, &m->q_c1[i]));
+      EGONN_TRY(pack16(b.conv2, 27, b.cout, b.cout, &m->q_c2[i]));
     }
     EGONN_TRY(pack(m->gt[6], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[6]));
     EGONN_TRY(pack(m->gt[7], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[7]));
     EGONN_TRY(pack(m->lt[4], 8, LOCAL_CH, LOCAL_CH, &m->p_lt[4]));
+    EGONN_TRY(pack16(m->gt[6], 8, GLOBAL_CH, GLOBAL_CH, &m->q_gt[6]));
+    EGONN_TRY(pack16(m->gt[7], 8, GLOBAL_CH, GLOBAL_CH, &m->q_gt[7]));
+    EGONN_TRY(pack16(m->lt[4], 8, LOCAL_CH, LOCAL_CH, &m->q_lt[4]));
   }
   EGONN_TRY(fold(m->bn[0], st));
   for (int i = 1; i <= 7; ++i) {
@@ -527,6 +542,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   hipStream_t st = (hipStream_t)stream;
   const Plan& P = c->plan;
   const int B = P.batch;
+  const int bf16 = (flags & EGONN_FLAG_BF16) ? 1 : 0;          // bf16 MFMA operands for the sparse convolutions
   const bool do_global = !(flags & EGONN_FLAG_DISABLE_GLOBAL);
   const bool do_local = !(flags & EGONN_FLAG_DISABLE_LOCAL);
   EGONN_REQUIRE(!do_global || out_global, EGONN_ERR_INVALID, "forward: out_global is null");
@@ -571,21 +587,21 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     {
       snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k2s2", b.cin, b.cin, i);
       ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, P.lv[i - 1].n, n);
-      EGONN_TRY(sconv_forward(x[i - 1], P.lv[i - 1].n, L.nbr8, m->convs[i], m->p_convs[i], m->bn[i].scale, m->bn[i].shift, 1, y, (int32_t)n, 8,
-                              b.cin, b.cin, scr, SCONV_SCRATCH_FLOATS, st));
+      EGONN_TRY(sconv_forward(x[i - 1], P.lv[i - 1].n, L.nbr8, m->convs[i], bf16 ? m->q_convs[i] : m->p_convs[i], m->bn[i].scale, m->bn[i].shift, 1, y, (int32_t)n, 8,
+                              b.cin, b.cin, scr, SCONV_SCRATCH_FLOATS, st, bf16));
     }
     // ECABasicBlock (layers/eca_block.py:56-73)
     WALLOC(t1, n * b.cout);
     {
       snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k3.conv1", b.cin, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cin, b.cout, n, n);
-      EGONN_TRY(sconv_forward(y, n, L.nbr27, b.conv1, m->p_c1[i], b.n1.scale, b.n1.shift, 1, t1, (int32_t)n, 27, b.cin, b.cout, scr, SCONV_SCRATCH_FLOATS, st));
+      EGONN_TRY(sconv_forward(y, n, L.nbr27, b.conv1, bf16 ? m->q_c1[i] : m->p_c1[i], b.n1.scale, b.n1.shift, 1, t1, (int32_t)n, 27, b.cin, b.cout, scr, SCONV_SCRATCH_FLOATS, st, bf16));
     }
     WALLOC(t2, n * b.cout);
     {
       snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k3.conv2", b.cout, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cout, b.cout, n, n);
-      EGONN_TRY(sconv_forward(t1, n, L.nbr27, b.conv2, m->p_c2[i], b.n2.scale, b.n2.shift, 0, t2, (int32_t)n, 27, b.cout, b.cout, scr, SCONV_SCRATCH_FLOATS, st));
+      EGONN_TRY(sconv_forward(t1, n, L.nbr27, b.conv2, bf16 ? m->q_c2[i] : m->p_c2[i], b.n2.scale, b.n2.shift, 0, t2, (int32_t)n, 27, b.cout, b.cout, scr, SCONV_SCRATCH_FLOATS, st, bf16));
     }
     WALLOC(partial, (size_t)B * SEG_CHUNKS * b.cout + (size_t)B * b.cout);
     EGONN_TRY(segment_partial_sums(t2, L.boff, B, b.cout, 0, nullptr, partial, st));
@@ -607,11 +623,11 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     WALLOC(g7, P.lv[7].n * GLOBAL_CH);
     EGONN_TRY(dense_forward(x[7], P.lv[7].n, 128, m->g1x1[7], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, g7, st));
     WALLOC(u6, P.lv[6].n * GLOBAL_CH);
-    EGONN_TRY(sconv_forward(g7, P.lv[7].n, P.lv[6].nbrT, m->gt[7], m->p_gt[7], nullptr, nullptr, 0, u6, (int32_t)P.lv[6].n, 8, GLOBAL_CH, GLOBAL_CH, scr, SCONV_SCRATCH_FLOATS, st));
+    EGONN_TRY(sconv_forward(g7, P.lv[7].n, P.lv[6].nbrT, m->gt[7], bf16 ? m->q_gt[7] : m->p_gt[7], nullptr, nullptr, 0, u6, (int32_t)P.lv[6].n, 8, GLOBAL_CH, GLOBAL_CH, scr, SCONV_SCRATCH_FLOATS, st, bf16));
     WALLOC(g6, P.lv[6].n * GLOBAL_CH);
     EGONN_TRY(dense_forward(x[6], P.lv[6].n, 128, m->g1x1[6], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u6, g6, st));
     WALLOC(u5, P.lv[5].n * GLOBAL_CH);
-    EGONN_TRY(sconv_forward(g6, P.lv[6].n, P.lv[5].nbrT, m->gt[6], m->p_gt[6], nullptr, nullptr, 0, u5, (int32_t)P.lv[5].n, 8, GLOBAL_CH, GLOBAL_CH, scr, SCONV_SCRATCH_FLOATS, st));
+    EGONN_TRY(sconv_forward(g6, P.lv[6].n, P.lv[5].nbrT, m->gt[6], bf16 ? m->q_gt[6] : m->p_gt[6], nullptr, nullptr, 0, u5, (int32_t)P.lv[5].n, 8, GLOBAL_CH, GLOBAL_CH, scr, SCONV_SCRATCH_FLOATS, st, bf16));
     WALLOC(g5, P.lv[5].n * GLOBAL_CH);
     EGONN_TRY(dense_forward(x[5], P.lv[5].n, 128, m->g1x1[5], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u5, g5, st));
     WALLOC(gh, P.lv[5].n * m->gdec.mid);
@@ -628,7 +644,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     WALLOC(l4, n4 * LOCAL_CH);
     EGONN_TRY(dense_forward(x[4], n4, 128, m->l1x1[4], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, l4, st));
     WALLOC(u3, n3 * LOCAL_CH);
-    EGONN_TRY(sconv_forward(l4, n4, P.lv[3].nbrT, m->lt[4], m->p_lt[4], nullptr, nullptr, 0, u3, (int32_t)n3, 8, LOCAL_CH, LOCAL_CH, scr, SCONV_SCRATCH_FLOATS, st));
+    EGONN_TRY(sconv_forward(l4, n4, P.lv[3].nbrT, m->lt[4], bf16 ? m->q_lt[4] : m->p_lt[4], nullptr, nullptr, 0, u3, (int32_t)n3, 8, LOCAL_CH, LOCAL_CH, scr, SCONV_SCRATCH_FLOATS, st, bf16));
     WALLOC(l3, n3 * LOCAL_CH);
     EGONN_TRY(dense_forward(x[3], n3, 64, m->l1x1[3], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u3, l3, st));
     WALLOC(dh, n3 * m->ldec.mid);

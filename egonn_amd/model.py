@@ -273,6 +273,10 @@ class MinkGL(nn.Module):
             return self._forward_train(ctx, feats, disable_global_head, disable_local_head)
         return self._forward_on_plan(ctx, feats, disable_global_head, disable_local_head)
 
+    # eval-mode arithmetic of the sparse convolutions: 'fp32' (exact-fp32 MFMA, the default and what parity is stated
+    # for) or 'bf16' (BASELINE configs[2]: MFMA operands rounded to bf16, fp32 accumulate, feature maps fp32)
+    precision = 'fp32'
+
     # process group for SyncBN statistics in train mode (None = this process only); set by the sharded step
     sync_bn_group = None
 
@@ -324,6 +328,10 @@ class MinkGL(nn.Module):
             out_s = torch.empty((n3, 1), dtype=torch.float32, device=dev)
         if self.ignore_keypoint_regressor:
             flags |= _lib.FLAG_IGNORE_KP_REGRESSOR
+        if self.precision == 'bf16':
+            flags |= _lib.FLAG_BF16
+        elif self.precision != 'fp32':
+            raise ValueError(f"precision {self.precision!r}: 'fp32' or 'bf16'")
         q = self.quantizer
         step = (_lib.C.c_float * 3)(*([float(s) for s in q.step] + [0.0, 0.0])[:3])
         with torch.cuda.device(dev):

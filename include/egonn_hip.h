@@ -30,7 +30,9 @@ typedef struct egonn_ctx egonn_ctx;       /* one per (device, stream user); owns
 typedef struct egonn_model egonn_model;   /* EgoNN weights registered by state_dict key */
 
 enum { EGONN_QUANT_CARTESIAN = 0, EGONN_QUANT_POLAR = 1 };
-enum { EGONN_FLAG_DISABLE_GLOBAL = 1, EGONN_FLAG_DISABLE_LOCAL = 2, EGONN_FLAG_IGNORE_KP_REGRESSOR = 4 };
+enum { EGONN_FLAG_DISABLE_GLOBAL = 1, EGONN_FLAG_DISABLE_LOCAL = 2, EGONN_FLAG_IGNORE_KP_REGRESSOR = 4,
+       /* BASELINE configs[2]: sparse-conv MFMA operands rounded to bf16, fp32 accumulate, feature maps fp32 in HBM */
+       EGONN_FLAG_BF16 = 8 };
 
 /* ------------------------------------------------------------------ lifecycle / errors */
 /* coord_bits in [10,16]: voxel coordinates must lie in [-2^(coord_bits-1), 2^(coord_bits-1)). */

@@ -619,3 +619,43 @@ def test_ingest_filter_matches_loader_semantics():
     a = ex.extract_packed(pts, off)
     b = ex.extract([torch.from_numpy(I.preprocess(I.read_pc(r), "mulran")) for r in raws])
     assert torch.equal(a["global"], b["global"]) and torch.equal(a["keypoints"], b["keypoints"])
+
+
+@pytest.mark.parametrize("name", ["egonn_cart01_b2", "egonn_polar_b1"])
+def test_bf16_operand_mode_config2(name):
+    """BASELINE configs[2] arithmetic: sparse-conv MFMA operands rounded to bf16 (fp32 accumulate, fp32 feature maps).
+    Stated tolerance vs the reference-graph fixture: global descriptor 1-cos <= 1e-5, local descriptors 1-cos <= 2e-4,
+    keypoints <= 5 cm, sigma rtol 2e-2, >= 120 of the 128 selected keypoints in common with the fp32 path."""
+    import egonn_amd
+    from egonn_amd import _lib
+    dev = _lib.require_gpu()
+    case = H.load_case(name)
+    polar = str(case["coordinates"]) == "polar"
+    step = [float(v) for v in case["quantization_step"]]
+    mp = egonn_amd.ModelParams(model="egonn", coordinates="polar" if polar else "cartesian",
+                               quantization_step=step if polar else step[0])
+    model = egonn_amd.model_factory(mp)
+    w = H.seeded_weights(int(case["weight_seed"]))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    model = model.to(dev).eval()
+    coords = torch.from_numpy(case["coords"]).to(dev)
+    batch = {"coords": coords, "features": torch.ones((len(coords), 1), device=dev)}
+    y32 = model(batch)
+    s32 = [t.clone() for t in y32["sigma"]]
+    model.precision = "bf16"
+    y = model(batch)
+    assert H.cosine_err(y["global"].cpu().numpy(), case["global"]).max() <= 1e-5
+    kcs = model.keypoint_coords()
+    for b in range(int(case["n_scans"])):
+        perm = H.join_perm(kcs[b].cpu().numpy(), case[f"kp_coords_{b}"])
+        assert H.cosine_err(y["descriptors"][b].cpu().numpy()[perm], case[f"descriptors_{b}"]).max() <= 2e-4
+        assert np.allclose(y["keypoints"][b].cpu().numpy()[perm], case[f"keypoints_{b}"], atol=5e-2)
+        assert np.allclose(y["sigma"][b].cpu().numpy()[perm], case[f"sigma_{b}"], rtol=2e-2, atol=1e-5)
+        k = min(128, len(s32[b]))
+        a = set(torch.topk(s32[b].squeeze(1), k, largest=False).indices.tolist())
+        c = set(torch.topk(y["sigma"][b].squeeze(1), k, largest=False).indices.tolist())
+        assert len(a & c) >= k - 8
+    assert not torch.equal(y["global"], y32["global"])             # the flag really switched the arithmetic
+    model.precision = "fp16"
+    with pytest.raises(ValueError):
+        model(batch)
