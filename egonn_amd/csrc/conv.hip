@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
   const int n0 = nsl * C::NW;
   const int l15 = lane & 15, g4 = lane >> 4;
   const int my_chunks = (total_chunks - grp + C::WAVES_M - 1) / C::WAVES_M;   // chunks q = i*WAVES_M + grp
-  float* myacc = accL + (size_t)grp * (T + 1) * C::LDC + n0 + l15;
+  float* myacc = accL + (size_t)grp * (T + 1) * C::LDC + n0 + 4 * g4;
 
   // Per-chunk metadata (kernel offset, 4 output rows, gather row of the chunk DDEPTH-1 ahead) is read from LDS
   // one chunk early, and the accumulator rows are read BEFORE the MFMA chain, so that the whole body has a single
@@ -254,26 +254,26 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
   auto chunk_of = [&](int i) { return min(i * C::WAVES_M + grp, total_chunks); };   // total_chunks = padding chunk
 
   // metadata: output rows of the chunk the next body() works on; gather row + offset of the chunk it prefetches
-  uint32_t m_rows = *reinterpret_cast<const uint32_t*>(pr + chunk_of(0) * 16 + 4 * g4);
+  // (operands are fed to the MFMA swapped — D^T = W^T A^T — so that lane (pair = l15, g) ends up with FOUR CONSECUTIVE
+  //  COLUMNS 4g..4g+3 of its pair's output row: the accumulate is one 16-byte LDS read + one 16-byte write per column
+  //  tile and the lane needs the row of one pair only; with the natural order it was four scattered 4-byte
+  //  read-modify-writes plus the decode of four row indices — a third of the loop's instruction stream)
+  int m_row = pr[chunk_of(0) * 16 + l15];
   int32_t m_j = pj[chunk_of(DDEPTH - 1) * 16 + l15];
   int m_k = ck[chunk_of(DDEPTH - 1)];
 
   auto body = [&](int i, auto RS) {
     constexpr int rs = decltype(RS)::value;
-    const uint32_t orows = m_rows;
+    float* const arow = myacc + m_row * C::LDC;
     slot_load(m_j, m_k, std::integral_constant<int, (rs + DDEPTH - 1) % DDEPTH>{});
-    // LDS reads issued ahead of the MFMA chain: next chunk's metadata + this chunk's accumulator rows
-    m_rows = *reinterpret_cast<const uint32_t*>(pr + chunk_of(i + 1) * 16 + 4 * g4);
+    // LDS reads issued ahead of the MFMA chain: next chunk's metadata + this chunk's accumulator row
+    m_row = pr[chunk_of(i + 1) * 16 + l15];
     const int qp = chunk_of(i + DDEPTH);
     m_j = pj[qp * 16 + l15];
     m_k = ck[qp];
-    float old[4][C::NT];
+    f32x4 old[C::NT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int orow = (orows >> (8 * r)) & 0xFF;
-#pragma unroll
-      for (int nt = 0; nt < C::NT; ++nt) old[r][nt] = myacc[orow * C::LDC + nt * 16];
-    }
+    for (int nt = 0; nt < C::NT; ++nt) old[nt] = *reinterpret_cast<const f32x4*>(arow + nt * 16);
     f32x4 acc[C::NT];
 #pragma unroll
     for (int nt = 0; nt < C::NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
         for (int nt = 0; nt < C::NT; ++nt) {
           const uint2 w0 = wring[rs][nt][2 * t2], w1 = wring[rs][nt][2 * t2 + 1];
           const bf16x8_t bv = __builtin_bit_cast(bf16x8_t, make_uint4(w0.x, w0.y, w1.x, w1.y));
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, av, acc[nt], 0, 0, 0);
         }
       }
     } else {
@@ -299,15 +299,11 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int nt = 0; nt < C::NT; ++nt)
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u], wring[rs][nt][t][u], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wring[rs][nt][t][u], a4[u], acc[nt], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int orow = (orows >> (8 * r)) & 0xFF;
-#pragma unroll
-      for (int nt = 0; nt < C::NT; ++nt) myacc[orow * C::LDC + nt * 16] = old[r][nt] + acc[nt][r];
-    }
+    for (int nt = 0; nt < C::NT; ++nt) *reinterpret_cast<f32x4*>(arow + nt * 16) = old[nt] + acc[nt];
   };
   // prologue: fill the ring; main loop unrolled DDEPTH x so that ring slots are compile-time constants
   [&]<int... Is>(std::integer_sequence<int, Is...>) {
