@@ -17,8 +17,8 @@ namespace egonn {
 
 static constexpr int SORT_BLOCK = 256;
 static constexpr int SORT_WAVES = SORT_BLOCK / 64;
-static constexpr int SORT_ROUNDS = 16;                       // keys per thread
-static constexpr int SORT_TILE = SORT_BLOCK * SORT_ROUNDS;   // 4096 keys per workgroup
+static constexpr int SORT_ROUNDS = 8;                        // keys per thread
+static constexpr int SORT_TILE = SORT_BLOCK * SORT_ROUNDS;   // 2048 keys per workgroup (391 tiles for the 800 k points of a batch; 4096 left CUs idle, 1024 is no better)
 static constexpr int SORT_SUPER = 32;                        // tiles per supertile
 
 __global__ __launch_bounds__(SORT_BLOCK) void sort_hist_kernel(const uint64_t* __restrict__ keys, int64_t n,
