@@ -117,10 +117,9 @@ class _MinkLocBase(nn.Module):
             self._ctx = _lib.Context(dev, coord_bits=self.coord_bits)
         return self._ctx
 
+    sync_bn_group = None          # process group of the SyncBN statistics in train mode (None = this process)
+
     def _forward(self, batch: Dict[str, torch.Tensor], gem_p: torch.Tensor):
-        if self.training:
-            raise NotImplementedError("training-mode forward is not part of the inference path built so far; "
-                                      "call model.eval()")
         dev = self._device()
         ctx = self.context()
         coords = batch['coords'].to(device=dev, dtype=torch.int32).contiguous()
@@ -130,6 +129,13 @@ class _MinkLocBase(nn.Module):
         if bs is None:
             bs = int(coords[:, 0].max().item()) + 1
         ctx.coords_set(coords, bs)
+        if self.training:     # batch-statistics BatchNorm + autograd through the HIP operators (egonn_amd/train.py)
+            from . import train
+            if not bool((feats == 1).all()):
+                raise NotImplementedError("train mode supports the reference's all-ones input features only")
+            level, x = train.minkfpn_forward(self.backbone, ctx, self.sync_bn_group)
+            assert x.shape[1] == self.feature_size
+            return {'global': train.GeMFn.apply(x, gem_p, ctx, level)}
         with torch.no_grad():
             level, x = self.backbone.run(ctx, ctx.gather_input(feats))
             assert x.shape[1] == self.feature_size

@@ -176,7 +176,8 @@ class GateResidualFn(Function):
 
     @staticmethod
     def forward(fctx, x, gate, residual, ctx: _lib.Context, level: int):
-        out = ctx.gate_residual(level, x, _c(gate.detach()), residual, relu=True)
+        """gate None: plain ME BasicBlock tail relu(x + residual)."""
+        out = ctx.gate_residual(level, x, None if gate is None else _c(gate.detach()), residual, relu=True)
         fctx.save_for_backward(x, gate, out)
         fctx.meta = (ctx, level)
         return out
@@ -186,8 +187,9 @@ class GateResidualFn(Function):
         x, gate, out = fctx.saved_tensors
         ctx, level = fctx.meta
         g = _c(g)
-        dx, dres = ctx.gate_residual_backward(level, g, out, _c(gate.detach()), want_residual=fctx.needs_input_grad[2])
-        dgate = ctx.segment_sums(level, 2, g, b=out, x2=x) if fctx.needs_input_grad[1] else None
+        dx, dres = ctx.gate_residual_backward(level, g, out, None if gate is None else _c(gate.detach()),
+                                              want_residual=fctx.needs_input_grad[2])
+        dgate = ctx.segment_sums(level, 2, g, b=out, x2=x) if gate is not None and fctx.needs_input_grad[1] else None
         return dx, dgate, dres, None, None
 
 
@@ -334,6 +336,49 @@ def global_branch(model, ctx, group=None, levels=None) -> torch.Tensor:
     x = LinearFn.apply(x, net[0].linear.weight, net[0].linear.bias, ctx, True)
     x = LinearFn.apply(x, net[2].linear.weight, net[2].linear.bias, ctx, False)
     return GeMFn.apply(x, model.global_pooling.pooling.p, ctx, lvl)
+
+
+def minkfpn_forward(fpn, ctx, group=None):
+    """MinkFPN.forward in train mode (reference models/minkfpn.py:65-93; BasicBlock / ECABasicBlock, all-ones input
+    features): the same graph as egonn_amd.minkloc.MinkFPN.run, on the differentiable operators."""
+    tot = level_totals(ctx, group)
+
+    def block(level, x, b):
+        y = sparse_conv(ctx, x, b.conv1, level, level)
+        y = batch_norm(ctx, y, b.norm1, True, group, tot[level])
+        y = sparse_conv(ctx, y, b.conv2, level, level)
+        y = batch_norm(ctx, y, b.norm2, False, group, tot[level])
+        res = x
+        if b.downsample is not None:
+            res = sparse_conv(ctx, x, b.downsample[0], level, level)
+            res = batch_norm(ctx, res, b.downsample[1], False, group, tot[level])
+        if hasattr(b, 'eca'):
+            return eca_tail(ctx, level, y, res, b.eca)
+        return GateResidualFn.apply(y, None, res, ctx, level)
+
+    assert fpn.conv0.kernel_size == 5 and fpn.conv0.kernel.shape[1] == 1, "train mode: k=5, 1-channel input layer"
+    x = SparseConvFn.apply(None, fpn.conv0.kernel, ctx, 0, 0, 5, False)
+    x = batch_norm(ctx, x, fpn.bn0, True, group, tot[0])
+    fmaps = []
+    if fpn.num_top_down == fpn.num_bottom_up:
+        fmaps.append((0, x))
+    level = 0
+    for ndx, (conv, bn, blocks) in enumerate(zip(fpn.convs, fpn.bn, fpn.blocks)):
+        x = sparse_conv(ctx, x, conv, level, level + 1)
+        level += 1
+        x = batch_norm(ctx, x, bn, True, group, tot[level])
+        for b in blocks:
+            x = block(level, x, b)
+        if fpn.num_bottom_up - 1 - fpn.num_top_down <= ndx < len(fpn.convs) - 1:
+            fmaps.append((level, x))
+    x = sparse_conv(ctx, x, fpn.conv1x1[0], level, level)
+    for ndx, tconv in enumerate(fpn.tconvs):
+        x = sparse_conv(ctx, x, tconv, level, level - 1)
+        level -= 1
+        flevel, f = fmaps[-ndx - 1]
+        assert flevel == level
+        x = AddFn.apply(x, sparse_conv(ctx, f, fpn.conv1x1[ndx + 1], level, level), ctx)
+    return level, x
 
 
 def local_branch(model, ctx, levels: Dict[int, torch.Tensor]):

@@ -277,8 +277,57 @@ def main_train():
         print(name, "voxels", bc.shape[0], "params with grad", n_grad, f"{os.path.getsize(path) / 1e6:.2f} MB")
 
 
+MINKLOC_TRAIN_CASES = [
+    ("minkloc3d_train_cart03", "MinkLoc3D", "BasicBlock", "0.3", [(36, 9000), (37, 8000)], 45, 46),
+    ("minkloc_eca_train_cart03", "MinkLoc", "ECABasicBlock", "0.3", [(38, 9000), (39, 7000)], 47, 48),
+]
+
+
+def main_train_minkloc():
+    """train-mode step of the reference MinkLoc3D / MinkLoc graphs (models/minkfpn.py + GeM) on the stand-in ME ops."""
+    bootstrap_reference()
+    import numpy as np
+    import torch
+    import MinkowskiEngine as ME
+    from models.model_factory import model_factory
+    from egonn_amd.synth import lidar_scan, seeded_state_dict
+
+    for name, mname, block, step, scans, wseed, pseed in MINKLOC_TRAIN_CASES:
+        mp = minkloc_params(mname, step, block)
+        model = model_factory(mp)
+        shapes = {k: [int(s) for s in v.shape] for k, v in model.state_dict().items()}
+        new = seeded_state_dict(wseed, {k: tuple(v) for k, v in shapes.items()})
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in new.items()})
+        model.train()
+        coords_list = []
+        for b, (seed, n) in enumerate(scans):
+            pc = kitti_like_filter(lidar_scan(seed, n_points=n))
+            coords, _ = mp.quantizer(torch.from_numpy(pc))
+            coords_list.append(coords)
+        bc = ME.utils.batched_coordinates(coords_list)
+        feats = torch.ones((bc.shape[0], 1), dtype=torch.float32)
+        g = model({"coords": bc, "features": feats})["global"]
+        R = torch.from_numpy(np.random.default_rng(pseed).standard_normal(tuple(g.shape)).astype(np.float32))
+        loss = (g * R).sum()
+        loss.backward()
+        out = {"weight_seed": np.int64(wseed), "proj_seed": np.int64(pseed), "model": np.array(mname),
+               "block": np.array(block), "quantization_step": np.array([float(step)]), "n_scans": np.int64(len(scans)),
+               "coords": bc.numpy().astype(np.int32), "global": g.detach().numpy(), "loss": np.float64(loss.item())}
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                out["grad/" + k] = grad_digest(k, p.grad.numpy())
+        for k, v in model.state_dict().items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                out["buf/" + k] = v.numpy()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(name, "voxels", bc.shape[0], "params with grad", sum(1 for k in out if k.startswith("grad/")),
+              f"{os.path.getsize(path) / 1e6:.2f} MB")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         main_train()
+        main_train_minkloc()
         sys.exit(0)
     main()

@@ -348,3 +348,46 @@ def test_train_step_is_bitwise_deterministic():
     assert runs[0][0] == runs[1][0]
     for k, g in runs[0][1].items():
         assert torch.equal(g, runs[1][1][k]), k
+
+
+@pytest.mark.parametrize("name,shapes", [("minkloc3d_train_cart03", "minkloc3d_cart03_b2"),
+                                         ("minkloc_eca_train_cart03", "minkloc_eca_cart03")])
+def test_minkloc_train_step_matches_reference_fixture(name, shapes):
+    """MinkLoc3D / MinkLoc (MinkFPN + GeM; BasicBlock and ECABasicBlock) in train mode vs the reference graph's autograd."""
+    import __graft_entry__ as ge
+    ge.build()
+    import egonn_amd
+    from egonn_amd import _lib
+    dev = _lib.require_gpu()
+    case = H.load_case(name)
+    if str(case["model"]) == "MinkLoc3D":
+        model = egonn_amd.model_factory(egonn_amd.ModelParams(model="MinkLoc3D", coordinates="cartesian", quantization_step=0.3))
+    else:
+        model = egonn_amd.model_factory(egonn_amd.ModelParams(model="MinkLoc", coordinates="cartesian", quantization_step=0.3,
+                                                             block="ECABasicBlock", planes="32,64,64", layers="1,1,1"))
+    w = H.seeded_weights(int(case["weight_seed"]), shapes)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    model = model.to(dev).train()
+    coords = torch.from_numpy(case["coords"]).to(dev)
+    g = model({"coords": coords, "features": torch.ones((len(coords), 1), device=dev)})["global"]
+    assert H.cosine_err(g.detach().cpu().numpy(), case["global"]).max() <= 1e-4
+    R = torch.from_numpy(np.random.default_rng(int(case["proj_seed"])).standard_normal(case["global"].shape).astype(np.float32)).to(dev)
+    loss = (g * R).sum()
+    assert abs(loss.item() - float(case["loss"])) <= 2e-3 * max(1.0, abs(float(case["loss"])))
+    loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    keys = [k[5:] for k in case if k.startswith("grad/")]
+    assert set(keys) == set(grads)
+    bad = []
+    for k in keys:
+        assert grads[k] is not None, k
+        mine, ref = _digest(k, grads[k].detach().cpu().numpy()), case["grad/" + k]
+        norm = max(ref[0], 1e-12)
+        err = max(abs(mine[0] - ref[0]) / norm, abs(mine[1] - ref[1]) / norm,
+                  float(np.abs(mine[2:] - ref[2:]).max()) / max(float(np.abs(ref[2:]).max()), 1e-12))
+        if err > 5e-3:
+            bad.append((k, err))
+    assert not bad, bad
+    sd = model.state_dict()
+    for k in [k[4:] for k in case if k.startswith("buf/")]:
+        assert np.allclose(sd[k].cpu().numpy(), case["buf/" + k], rtol=1e-3, atol=1e-5), k
