@@ -459,8 +459,8 @@ def test_minkloc_forward_matches_reference_graph(gpu, name):
     assert g.shape == case["global"].shape and set(y.keys()) == {"global"}
     assert H.cosine_err(g, case["global"]).max() < 1e-4
     np.testing.assert_allclose(g, case["global"], rtol=1e-3, atol=1e-4)
-    with pytest.raises(NotImplementedError):
-        m.train()(  {"coords": torch.from_numpy(c4), "features": torch.ones((len(c4), 1))})
+    yt = m.train()({"coords": torch.from_numpy(c4), "features": torch.ones((len(c4), 1))})     # train mode: tests/test_gpu_train.py
+    assert yt["global"].requires_grad and yt["global"].shape == y["global"].shape
 
 
 def test_triplet_loss_matches_oracle(gpu):
