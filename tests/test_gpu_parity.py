@@ -659,3 +659,53 @@ def test_bf16_operand_mode_config2(name):
     model.precision = "fp16"
     with pytest.raises(ValueError):
         model(batch)
+
+
+def _fuzz_cloud(rng, kind, n):
+    if kind == 0:
+        from egonn_amd.synth import lidar_scan
+        return lidar_scan(int(rng.integers(0, 10_000)), n_points=n)
+    if kind == 1:                                             # dense blob (many duplicates per voxel)
+        return (rng.standard_normal((n, 3)) * np.array([3.0, 3.0, 0.5])).astype(np.float32)
+    if kind == 2:                                             # a thin wall: 2-D structure, negative coordinates
+        p = rng.uniform(-40, 40, (n, 3)).astype(np.float32)
+        p[:, 0] = -7.3 + 0.02 * rng.standard_normal(n).astype(np.float32)
+        return p
+    p = np.zeros((n, 3), np.float32)                          # a line along x + a few far outliers
+    p[:, 0] = rng.uniform(-60, 60, n)
+    p[: max(1, n // 50)] = rng.uniform(-150, 150, (max(1, n // 50), 3))
+    return p
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_single_scan_vs_c_oracle(gpu, seed):
+    """randomised clouds / voxel sizes / sizes through compute_embedding vs the independent C/OpenMP restatement:
+    level sizes exact, global descriptor 1-cos <= 1e-4, the selected keypoints (where sigma gaps exceed the forward
+    tolerance), their positions and descriptors."""
+    from oracle import egonn_cpu
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([150, 900, 4000, 12000, 30000]))
+    q = float(rng.choice([0.1, 0.2, 0.35, 0.5]))
+    pc = _fuzz_cloud(rng, seed % 4, n)
+    w = H.seeded_weights(50 + seed)
+    mp = gpu.ModelParams(model="egonn", coordinates="cartesian", quantization_step=q)
+    m = gpu.model_factory(mp)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    m = m.to("cuda").eval()
+    ex = gpu.DescriptorExtractor(m, n_k=128)
+    out = ex.extract([torch.from_numpy(pc)])
+    g0, kp0, de0, c0, s0, counts = egonn_cpu.CpuOracle(w, q).compute_embedding(pc, 128)
+    ctx = m.context()
+    assert [ctx.level_count(l) for l in range(8)] == counts.tolist()
+    assert H.cosine_err(_np(out["global"]), g0).max() <= 1e-4
+    k = int(out["count"][0])
+    assert k == len(c0)
+    rows = _np(out["rows"][0, :k]).astype(np.int64)
+    got_c = _np(m.keypoint_coords()[0])[rows][:, 1:]
+    gap_ok = np.r_[True, np.diff(s0) > 2e-4 * np.maximum(1.0, np.abs(s0[1:]))] & \
+        np.r_[np.diff(s0) > 2e-4 * np.maximum(1.0, np.abs(s0[:-1])), True] if k > 1 else np.ones(k, bool)
+    same = np.all(got_c == c0, axis=1)
+    assert (same | ~gap_ok).all()
+    if same.any():
+        assert np.allclose(_np(out["keypoints"][0, :k])[same], kp0[same], atol=2e-3 + 1e-4 * 8 * q)
+        assert H.cosine_err(_np(out["descriptors"][0, :k])[same], de0[same]).max() <= 1e-4
