@@ -57,6 +57,8 @@ _SIGS = [
     ("egonn_affine_act", C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P]),
     ("egonn_affine3", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, _P, _P]),
     ("egonn_relu_backward", C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P]),
+    ("egonn_eca_gate", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    ("egonn_eca_gate_backward", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     ("egonn_act_backward", C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int, _P, _P]),
     ("egonn_l2_normalize", C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P]),
     ("egonn_gate_residual", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, _P]),

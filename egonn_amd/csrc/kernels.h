@@ -83,6 +83,9 @@ int seg_sums2(int mode, const float* a, const float* b, const float* x2, const f
 int gem_backward_rows(const float* x, const float* coef, const float* p, const int32_t* boff, int B, int64_t n, int c,
                       float* dx, hipStream_t stream);
 
+int eca_gate_forward(const float* mean, const float* w, int ks, int B, int c, float* gate, hipStream_t stream);
+int eca_gate_backward(const float* dgate, const float* gate, const float* mean, const float* w, int ks, int B, int c,
+                      float* dmean, float* dw, hipStream_t stream);
 int act_backward(int act, const float* g, const float* y, int64_t n, int c, float* out, hipStream_t stream);
 // g == nullptr: out = normalize(x) ; else out = d normalize / dx applied to g
 int l2norm_rows(const float* x, const float* g, int64_t n, int c, float* out, hipStream_t stream);

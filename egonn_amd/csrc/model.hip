@@ -851,6 +851,19 @@ API int egonn_relu_backward(const float* grad_out, const float* out, int64_t n, 
   EGONN_REQUIRE(grad_out && out && grad_in, EGONN_ERR_INVALID, "relu_backward: null argument");
   return gate_residual_backward(grad_out, out, nullptr, nullptr, 0, n, c, grad_in, nullptr, (hipStream_t)stream);
 }
+API int egonn_eca_gate(const float* mean, const float* conv_weight, int kernel_size, int batch_size, int channels,
+                       float* gate, void* stream) {
+  EGONN_REQUIRE(mean && conv_weight && gate, EGONN_ERR_INVALID, "eca_gate: null argument");
+  return eca_gate_forward(mean, conv_weight, kernel_size, batch_size, channels, gate, (hipStream_t)stream);
+}
+API int egonn_eca_gate_backward(const float* grad_gate, const float* gate, const float* mean, const float* conv_weight,
+                                int kernel_size, int batch_size, int channels, float* grad_mean, float* grad_weight,
+                                void* stream) {
+  EGONN_REQUIRE(grad_gate && gate && mean && conv_weight && grad_mean && grad_weight, EGONN_ERR_INVALID,
+                "eca_gate_backward: null argument");
+  return eca_gate_backward(grad_gate, gate, mean, conv_weight, kernel_size, batch_size, channels, grad_mean, grad_weight,
+                           (hipStream_t)stream);
+}
 API int egonn_act_backward(int act, const float* grad_out, const float* out, int64_t n, int c, float* grad_in, void* stream) {
   EGONN_REQUIRE(grad_out && out && grad_in && act >= 0 && act <= 4, EGONN_ERR_INVALID, "act_backward: bad arguments");
   return act_backward(act, grad_out, out, n, c, grad_in, (hipStream_t)stream);

@@ -691,6 +691,77 @@ int gem_backward_rows(const float* x, const float* coef, const float* p, const i
   return EGONN_OK;
 }
 
+// ------------------------------------------------------------------------------------------ ECA gate on (B, C) means
+// gate = sigmoid(Conv1d_k(mean)) over the channel axis, zero padding (k-1)/2, no bias (layers/eca_block.py:17-19,28-31).
+// One workgroup per sample forward; backward: dz = dgate * g * (1 - g), dmean = correlation of dz with w,
+// dw[j] = sum_{b,c} dz[b][c] * mean[b][c + j - pad] reduced by ONE workgroup in fixed order (deterministic).
+__global__ void eca_gate_fwd_kernel(const float* __restrict__ mean, const float* __restrict__ w, int ks, int c,
+                                    float* __restrict__ gate) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t >= c) return;
+  const int pad = (ks - 1) / 2;
+  float z = 0.f;
+  for (int j = 0; j < ks; ++j) {
+    const int q = t + j - pad;
+    if (q >= 0 && q < c) z = fmaf(w[j], mean[(int64_t)b * c + q], z);
+  }
+  gate[(int64_t)b * c + t] = 1.f / (1.f + expf(-z));
+}
+__global__ __launch_bounds__(256) void eca_gate_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                          const float* __restrict__ mean, const float* __restrict__ w,
+                                                          int ks, int B, int c, float* __restrict__ dmean,
+                                                          float* __restrict__ dw) {
+  __shared__ float red[256];
+  const int t = threadIdx.x;
+  const int pad = (ks - 1) / 2;
+  const int total = B * c;
+  for (int e = t; e < total; e += 256) {                 // dmean[b][q] = sum_j w[j] * dz[b][q - j + pad]
+    const int b = e / c, q = e - b * c;
+    float s = 0.f;
+    for (int j = 0; j < ks; ++j) {
+      const int cc = q - j + pad;
+      if (cc >= 0 && cc < c) {
+        const float g = gate[(int64_t)b * c + cc];
+        s = fmaf(w[j], dgate[(int64_t)b * c + cc] * g * (1.f - g), s);
+      }
+    }
+    dmean[e] = s;
+  }
+  for (int j = 0; j < ks; ++j) {
+    float s = 0.f;
+    for (int e = t; e < total; e += 256) {
+      const int b = e / c, cc = e - b * c;
+      const int q = cc + j - pad;
+      if (q >= 0 && q < c) {
+        const float g = gate[e];
+        s = fmaf(dgate[e] * g * (1.f - g), mean[(int64_t)b * c + q], s);
+      }
+    }
+    red[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) red[t] += red[t + o];
+      __syncthreads();
+    }
+    if (t == 0) dw[j] = red[0];
+    __syncthreads();
+  }
+}
+int eca_gate_forward(const float* mean, const float* w, int ks, int B, int c, float* gate, hipStream_t stream) {
+  EGONN_REQUIRE(c >= 1 && c <= 256 && ks >= 1 && ks <= 15 && (ks & 1), EGONN_ERR_INVALID, "eca_gate: bad shape");
+  if (B == 0) return EGONN_OK;
+  hipLaunchKernelGGL(eca_gate_fwd_kernel, dim3((unsigned)B), dim3(256), 0, stream, mean, w, ks, c, gate);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+int eca_gate_backward(const float* dgate, const float* gate, const float* mean, const float* w, int ks, int B, int c,
+                      float* dmean, float* dw, hipStream_t stream) {
+  EGONN_REQUIRE(c >= 1 && c <= 256 && ks >= 1 && ks <= 15 && (ks & 1), EGONN_ERR_INVALID, "eca_gate: bad shape");
+  hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(1), dim3(256), 0, stream, dgate, gate, mean, w, ks, B, c, dmean, dw);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
 // ------------------------------------------------------------------------------------------ activations / L2 normalisation
 // grad_in = grad_out * act'(.) expressed through the activation's OUTPUT y:
 //   relu: [y > 0]   tanh: 1 - y^2   softplus: 1 - exp(-y)  (= sigmoid(x))   sigmoid: y (1 - y)

@@ -193,21 +193,38 @@ class GateResidualFn(Function):
         return dx, dgate, dres, None, None
 
 
+class EcaGateFn(Function):
+    """sigmoid(Conv1d_k(mean)) over the channel axis of the (B, C) per-sample means (layers/eca_block.py:28-31)."""
+
+    @staticmethod
+    def forward(fctx, mean, weight, ctx: _lib.Context):
+        w = _c(weight.detach().reshape(-1))
+        B, c = mean.shape
+        gate = torch.empty_like(mean)
+        ctx._call(ctx.lib.egonn_eca_gate, mean.data_ptr(), w.data_ptr(), w.numel(), B, c, gate.data_ptr())
+        fctx.save_for_backward(mean, weight, gate)
+        fctx.meta = ctx
+        return gate
+
+    @staticmethod
+    def backward(fctx, g):
+        mean, weight, gate = fctx.saved_tensors
+        ctx = fctx.meta
+        w = _c(weight.detach().reshape(-1))
+        B, c = mean.shape
+        g = _c(g)
+        dmean = torch.empty_like(mean)
+        dw = torch.empty(w.numel(), dtype=torch.float32, device=mean.device)
+        ctx._call(ctx.lib.egonn_eca_gate_backward, g.data_ptr(), gate.data_ptr(), mean.data_ptr(), w.data_ptr(), w.numel(),
+                  B, c, dmean.data_ptr(), dw.data_ptr())
+        return dmean, dw.reshape(weight.shape), None
+
+
 def eca_tail(ctx, level, x, residual, eca_module):
     """layers/eca_block.py:21-36,66-73: gate = sigmoid(Conv1d_k(mean_b(x))), out = relu(x * gate + residual)."""
     m = SegmentMeanFn.apply(x, ctx, level)                                       # (B, C)
-    conv = eca_module.conv
-    # Conv1d(1, 1, k, padding=(k-1)/2, bias=False) over the channel axis of the (B, C) means, written as k shifted
-    # multiply-adds: F.conv1d's weight gradient uses atomics on this backend (run-to-run differences in the last bit),
-    # this form is deterministic
-    w = conv.weight.reshape(-1)
-    pad = int(conv.padding[0])
-    mp = F.pad(m, (pad, pad))
-    c = m.shape[1]
-    z = mp[:, 0:c] * w[0]
-    for t in range(1, w.shape[0]):
-        z = z + mp[:, t:t + c] * w[t]
-    return GateResidualFn.apply(x, torch.sigmoid(z), residual, ctx, level)
+    gate = EcaGateFn.apply(m, eca_module.conv.weight, ctx)                       # fixed-order sums: deterministic
+    return GateResidualFn.apply(x, gate, residual, ctx, level)
 
 
 class AddFn(Function):

@@ -189,6 +189,13 @@ int egonn_act_backward(int act, const float* grad_out, const float* out, int64_t
 /* MinkowskiFunctional.normalize = F.normalize(x, p=2, dim=1, eps=1e-12) (models/minkgl.py:222-223): grad_out == NULL:
  * out = normalised rows; else out = the input gradient for grad_out. */
 int egonn_l2_normalize(const float* x, const float* grad_out, int64_t n, int c, float* out, void* stream);
+/* ECALayer gate on the (B, channels) per-sample means: gate = sigmoid(Conv1d(1,1,k,padding=(k-1)/2,bias=False)(mean))
+ * (layers/eca_block.py:17-19,28-31) and its backward (grad_mean (B,channels), grad_weight (k,), fixed-order sums). */
+int egonn_eca_gate(const float* mean, const float* conv_weight, int kernel_size, int batch_size, int channels, float* gate,
+                   void* stream);
+int egonn_eca_gate_backward(const float* grad_gate, const float* gate, const float* mean, const float* conv_weight,
+                            int kernel_size, int batch_size, int channels, float* grad_mean, float* grad_weight,
+                            void* stream);
 /* out = relu?(x * gate[sample] + residual): MinkowskiBroadcastMultiplication + residual add + MinkowskiReLU
  * (layers/eca_block.py:69-73) with an explicit (B,c) gate (nullable = 1); backward: d = grad_out*[out>0],
  * grad_residual = d (nullable), grad_x = d*gate. */
