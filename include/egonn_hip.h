@@ -39,7 +39,10 @@ enum { EGONN_FLAG_DISABLE_GLOBAL = 1, EGONN_FLAG_DISABLE_LOCAL = 2, EGONN_FLAG_I
 int egonn_ctx_create(egonn_ctx** ctx, int device, int coord_bits);
 void egonn_ctx_destroy(egonn_ctx* ctx);
 const char* egonn_last_error(void);
-/* debug: 1 = route sparse convolutions through the naive (non-MFMA) HIP kernel (cross-check only). */
+/* debug / measurement only (tests, tools/bench_sconv.py): bit 0 = route sparse convolutions through the naive
+ * (non-MFMA) HIP kernel; bit 8 = tuning word valid: bits 4-6 workgroup-split policy, bits 12-13 tile rows (0 = auto);
+ * bits 16-18 = ablation of the MFMA kernel (weight loads / gathers return zeros without traffic, main loop skipped):
+ * results are then WRONG on purpose.  Process-global, not thread-safe; never set by the product path. */
 int egonn_debug_set_naive_conv(int on);
 
 /* ------------------------------------------------------------------ coordinate plan
