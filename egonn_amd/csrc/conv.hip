@@ -74,8 +74,8 @@ template <int CIN, int COUT>
 static size_t sconv_lds_bytes(int K, int T) {
   using C = SconvCfg<CIN, COUT>;
   size_t b = 0;
-  b += (size_t)C::WAVES_M * (T + 1) * C::LDC * 4;         // accumulators (+1 dummy row) per chunk group
-  b += (size_t)T * K * 4;                                 // raw neighbour-table tile
+  // accumulators (+1 dummy row) per chunk group; the raw neighbour-table tile of phase A lives in the same bytes
+  b += std::max((size_t)C::WAVES_M * (T + 1) * C::LDC * 4, (size_t)T * K * 4);
   b += (size_t)(T * K + 16 * K + 16) * 4;                 // pair input rows, chunk-major (+ padding)
   b += (size_t)(T * K + 16 * K + 16);                     // pair output rows (u8)
   b += (size_t)(K + 1) * 4 * 2 + 64;                      // cnt, cbase
@@ -124,9 +124,10 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
   constexpr int DDEPTH = (SLOT_F4 <= 4) ? 4 : ((SLOT_F4 <= 12) ? 3 : 2);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* accL = reinterpret_cast<float*>(smem);                               // [WAVES_M][T+1][LDC]
-  int32_t* tbl = reinterpret_cast<int32_t*>(accL + (size_t)C::WAVES_M * (T + 1) * C::LDC);   // [T][K]
+  int32_t* tbl = reinterpret_cast<int32_t*>(accL);        // [T][K], phase A only: aliased with the accumulators
   const int list_cap = T * K + 16 * K + 16;
-  int32_t* pj = tbl + (size_t)T * K;                                          // [chunk][16] input row or -1
+  const size_t acc_bytes = std::max((size_t)C::WAVES_M * (T + 1) * C::LDC * 4, (size_t)T * K * 4);
+  int32_t* pj = reinterpret_cast<int32_t*>(smem + acc_bytes);                 // [chunk][16] input row or -1
   int32_t* cnt = pj + list_cap;                                               // [K+1]
   int32_t* cbase = cnt + (K + 1);                                             // [K+1] first chunk of offset k
   uint8_t* pr = reinterpret_cast<uint8_t*>(cbase + (K + 1) + 8);              // [chunk][16] output row (T = dummy)
@@ -138,9 +139,7 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
   const int nsplit = gridDim.y, split = blockIdx.y;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-  // ---- zero accumulators, stage the tile of the neighbour table (coalesced)
-  for (int i = tid; i < C::WAVES_M * (T + 1) * C::LDC / 4; i += 256)
-    reinterpret_cast<float4*>(accL)[i] = make_float4(0, 0, 0, 0);
+  // ---- stage the tile of the neighbour table (coalesced); the accumulators are zeroed after phase A
   {
     const int32_t* src = nbr + (int64_t)row0 * K;
     const int n = rows * K;
@@ -205,6 +204,9 @@ __global__ __launch_bounds__(256) void sconv_mfma_kernel(const float* __restrict
     pr[total_chunks * 16 + tid] = (uint8_t)T;
     if (tid == 0) ck[total_chunks] = (uint8_t)(total_chunks ? ck[total_chunks - 1] : 0);
   }
+  __syncthreads();
+  for (int i = tid; i < C::WAVES_M * (T + 1) * C::LDC / 4; i += 256)          // the table tile is dead now
+    reinterpret_cast<float4*>(accL)[i] = make_float4(0, 0, 0, 0);
   __syncthreads();
 
   const int grp = wave / C::WAVES_N;          // chunk group of this wave (chunks are dealt round-robin to groups)
