@@ -44,7 +44,6 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work given to the C/OpenMP oracle baseline")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--layer-table", type=str, default="", help="write a per-layer timing table (json) here")
-    p.add_argument("--tune", type=int, default=-1, help="library tuning hook value (debug)")
     p.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                    help="f32 = BASELINE configs[1] (default, the headline metric); bf16 = configs[2] arithmetic "
                         "(sparse-conv MFMA operands rounded to bf16, fp32 accumulate, fp32 feature maps)")
@@ -98,8 +97,6 @@ def main():
     points = torch.from_numpy(np.concatenate(scans, axis=0)).to(dev).contiguous()   # resident in HBM
 
     ctx = model.context()
-    if args.tune >= 0:
-        ctx.lib.egonn_debug_set_naive_conv(0x100 | ((args.tune & 7) << 4) | ((args.tune >> 4) << 12))
 
     def step():
         return ex.extract_packed(points, offsets)

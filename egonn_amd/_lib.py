@@ -23,7 +23,7 @@ _SIGS = [
     ("egonn_ctx_create", C.c_int, [C.POINTER(_P), C.c_int, C.c_int]),
     ("egonn_ctx_destroy", None, [_P]),
     ("egonn_last_error", C.c_char_p, []),
-    ("egonn_debug_set_naive_conv", C.c_int, [C.c_int]),
+    ("egonn_debug_set_naive_conv", C.c_int, [_P, C.c_int]),
     ("egonn_voxelize", C.c_int, [_P, _P, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     ("egonn_coords_set", C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     ("egonn_level_count", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
@@ -32,6 +32,8 @@ _SIGS = [
     ("egonn_input_index", C.c_int, [_P, _P, _P]),
     ("egonn_conv", C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P]),
     ("egonn_conv_transpose", C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P]),
+    ("egonn_sparse_conv", C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
+    ("egonn_map_groups", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P]),
     ("egonn_global_avg_pool", C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     ("egonn_bn_fold", C.c_int, [_P, _P, _P, _P, C.c_float, C.c_int, _P, _P, _P]),
     ("egonn_block_tail", C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, _P]),
@@ -220,6 +222,37 @@ class Context:
             check(self.lib.egonn_conv_transpose(self.h, level_in, x.data_ptr(), cin, kernel.data_ptr(), cout,
                                                 out.data_ptr(), _stream()))
         return out
+
+    def sparse_conv(self, map_kind: int, level_out: int, x: torch.Tensor, kernel: torch.Tensor, scale=None, shift=None,
+                    relu: bool = False, group_sums: bool = False):
+        """egonn_sparse_conv: x fp32 or bf16 (the output has x's dtype).  map_kind 0: k=3, 1: k=2/s=2 into level_out,
+        2: transposed onto level_out.  Returns out, or (out, sums) with the per-group column sums."""
+        assert x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous()
+        kernel = _dev_f32(kernel, self.device)
+        cin, cout = kernel.shape[-2], kernel.shape[-1]
+        assert x.shape[1] == cin
+        out = torch.empty((self.level_count(level_out), cout), dtype=x.dtype, device=self.device)
+        sc = None if scale is None else _dev_f32(scale, self.device)
+        sh = None if shift is None else _dev_f32(shift, self.device)
+        sums = None
+        if group_sums:
+            sums = torch.zeros((self.map_groups(map_kind, level_out)[0], cout), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_sparse_conv(self.h, map_kind, level_out, x.data_ptr(), cin, kernel.data_ptr(), cout,
+                                             int(x.dtype == torch.bfloat16), _ptr(sc), _ptr(sh), int(relu), out.data_ptr(),
+                                             _ptr(sums), _stream()))
+        return (out, sums) if group_sums else out
+
+    def map_groups(self, map_kind: int, level_out: int):
+        n = C.c_int64()
+        first = (C.c_int64 * (self.batch_size + 1))()
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_map_groups(self.h, map_kind, level_out, C.byref(n), first, _stream()))
+        return n.value, list(first)
+
+    def set_naive_conv(self, on: bool):
+        """tests only: route this context's sparse convolutions through the plain (non-MFMA) kernel."""
+        check(self.lib.egonn_debug_set_naive_conv(self.h, int(on)))
 
     def global_avg_pool(self, level: int, x: torch.Tensor):
         x = _dev_f32(x, self.device)

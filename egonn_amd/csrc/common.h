@@ -97,6 +97,29 @@ __host__ __device__ static inline uint64_t morton3(uint32_t x, uint32_t y, uint3
   return part1by2(x) | (part1by2(y) << 1) | (part1by2(z) << 2);
 }
 
+// ------------------------------------------------------------------ row-group tables (rowgroup.hip, sconv.hip)
+// The form of a kernel map the sparse-convolution kernel consumes: rows regrouped (per sample, per window, sorted by
+// neighbour-presence mask) into groups of 16 that share their set of present kernel offsets.
+static constexpr int RG_MAX_JOBS = 24;
+static constexpr int RG_MAX_WIN = 1024;
+struct RowGroups {
+  int K = 0;                  // kernel volume of the map (27 or 8)
+  int win = 0;                // rows per sort window (256 / 512 / 1024); groups per window = win / 16
+  int cap_groups = 0;         // groups the arrays can hold (multiple of win / 16)
+  int32_t* perm = nullptr;    // [cap_groups][16]      output row of every slot, -1 = padding
+  int32_t* snbr = nullptr;    // [cap_groups][K][16]   input row + 1, 0 = no neighbour
+  uint32_t* gmask = nullptr;  // [cap_groups]          OR of the 16 presence masks; bit 31 = group has real rows
+  int32_t* meta = nullptr;    // [0] groups in use, [1 + b] first group of sample b (b = 0..B)
+  bool built = false;
+};
+struct RGBuild {
+  RowGroups* rg;
+  const int32_t* nbr;         // [n][K] kernel map
+  const int32_t* n_dev;       // device: rows of the output level
+  const int32_t* boff;        // device: [B+1] per-sample offsets of the output level
+};
+int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream);
+
 // ------------------------------------------------------------------ coordinate plan ("coordinate manager")
 struct Level {
   int64_t n = 0;              // rows at this level (host copy, valid after the size query)
@@ -109,6 +132,7 @@ struct Level {
   int32_t* nbr27 = nullptr;   // [n][27] k=3 neighbour rows at the same level (levels 1..7), -1 = absent
   int32_t* nbr8 = nullptr;    // [n][8]  k=2,s=2 children rows at level l-1 by kernel slot (levels 1..7)
   int32_t* nbrT = nullptr;    // [n][8]  transposed conv: parent row (at level l+1) in slot (key&7), else -1
+  RowGroups rg27, rg8, rgT;   // row-group form of nbr27 / nbr8 / nbrT (built on first use: ensure_rowgroups)
 };
 
 struct Plan {
@@ -117,6 +141,7 @@ struct Plan {
   int coord_bits = 16;        // CB
   int64_t n_input = 0;        // rows/points handed in by the caller
   Level lv[EGONN_MAX_LEVELS];
+  int64_t cap[EGONN_MAX_LEVELS] = {};   // row capacity per level that grids / workspaces are sized for (>= lv[l].n)
   int32_t* perm0 = nullptr;   // [n0] caller row / point index that became sorted row i (first occurrence)
   int32_t* g0 = nullptr;      // [n0] level-2 row (4x4x4 block) of every level-0 row
   uint64_t* t2m = nullptr;    // [n2][27] occupancy masks of the 27 blocks around every level-2 row (0 = absent)
@@ -146,6 +171,8 @@ struct Ctx {
   unsigned long long* dev_pairs = nullptr;   // [16] kernel-map pair counters: [0] conv0 k5, [l] k3 map of level l
   int device = 0;
   int coord_bits = 16;
+  int conv_variant = 0;       // tests / A-B measurements only (egonn_debug_set_naive_conv): 0 = product kernel, 1 = per-wave
+                              // MFMA variant, 3 = plain one-thread-per-output kernel
   Arena plan_arena;           // keys, maps (lives until the next plan)
   Arena work_arena;           // features & scratch of one forward
   Arena sort_arena;           // radix-sort scratch
@@ -173,6 +200,9 @@ struct ProfScope {
 };
 
 int ensure_level0_parent_table(Ctx* ctx, hipStream_t stream);   // coords.hip
+// row-group form of kernel maps (coords.hip): kind 0 = k=3 map of `level`, 1 = k=2,s=2 map into `level`,
+// 2 = transposed map onto `level`; every missing table of the request is built in one launch
+int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, hipStream_t stream);
 
 // ------------------------------------------------------------------ sort.hip
 // LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits).  Result lands in (keys_out, vals_out).

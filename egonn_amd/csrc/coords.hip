@@ -454,9 +454,34 @@ __global__ void count_valid_kernel(const int32_t* __restrict__ tbl, int64_t n, u
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(red[0] + red[1] + red[2] + red[3]));
 }
+// pairs of the never-materialised 5x5x5 map of the first layer: for every level-0 voxel, the occupied voxels among its
+// 125 neighbours = bits of the 27 surrounding 4x4x4 block masks inside the voxel's 5x5x5 box (profiling only)
+__global__ void count_k5_pairs_kernel(const uint64_t* __restrict__ vkeys, const int32_t* __restrict__ g0,
+                                      const uint64_t* __restrict__ t2m, int32_t n, unsigned long long* __restrict__ out) {
+  __shared__ int32_t red[4];
+  int32_t c = 0;
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t lk = (uint32_t)(vkeys[i] & 63);
+    const int lx = (lk & 1) | ((lk >> 2) & 2), ly = ((lk >> 1) & 1) | ((lk >> 3) & 2), lz = ((lk >> 2) & 1) | ((lk >> 4) & 2);
+    const uint64_t* m27 = t2m + (int64_t)g0[i] * 27;
+    for (int k = 0; k < 125; ++k) {
+      const int nx = lx + k % 5 - 2, ny = ly + (k / 5) % 5 - 2, nz = lz + k / 25 - 2;
+      const int slot = ((nx < 0) ? 0 : (nx > 3 ? 2 : 1)) + 3 * ((ny < 0) ? 0 : (ny > 3 ? 2 : 1)) + 9 * ((nz < 0) ? 0 : (nz > 3 ? 2 : 1));
+      c += (int32_t)((m27[slot] >> bit_of_local((uint32_t)nx & 3, (uint32_t)ny & 3, (uint32_t)nz & 3)) & 1);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(red[0] + red[1] + red[2] + red[3]));
+}
 int count_map_pairs(Ctx* ctx, hipStream_t stream) {
   const Plan& P = ctx->plan;
-  HIP_CHECK(hipMemsetAsync(ctx->dev_pairs + 1, 0, sizeof(unsigned long long) * 7, stream));
+  HIP_CHECK(hipMemsetAsync(ctx->dev_pairs, 0, sizeof(unsigned long long) * 8, stream));
+  if (P.lv[0].n > 0 && P.g0 && P.t2m)
+    hipLaunchKernelGGL(count_k5_pairs_kernel, dim3(512), dim3(256), 0, stream, P.lv[0].keys, P.g0, P.t2m, (int32_t)P.lv[0].n,
+                       ctx->dev_pairs);
   for (int l = 1; l < EGONN_NUM_LEVELS; ++l) {
     const int64_t n = P.lv[l].n * 27;
     if (n == 0) continue;
@@ -584,7 +609,6 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
   Plan& P = ctx->plan;
   const int cb = ctx->coord_bits;
   Arena& A = ctx->plan_arena;
-  HIP_CHECK(hipMemsetAsync(ctx->dev_pairs, 0, sizeof(unsigned long long) * 16, stream));
   EGONN_TRY(radix_sort_pairs(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, 3 * cb + batch_bits(B), stream));
 
   const int ntiles = (int)cdiv(n, PYR_TILE);
@@ -621,7 +645,7 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
                 "out of range)", cb - 1, cb);
   EGONN_REQUIRE(ctx->host_counts[NL] <= B, EGONN_ERR_RANGE, "batch index %d >= batch size %d",
                 ctx->host_counts[NL] - 1, B);
-  for (int l = 0; l < NL; ++l) P.lv[l].n = ctx->host_counts[l];
+  for (int l = 0; l < NL; ++l) P.lv[l].n = P.cap[l] = ctx->host_counts[l];
   for (int l = 0; l < EGONN_NUM_LEVELS; ++l) {
     const int32_t* src = ctx->host_counts + 32 + (size_t)l * (B + 1);
     P.boff_host[l].assign(src, src + B + 1);
@@ -722,10 +746,58 @@ int ensure_level0_parent_table(Ctx* ctx, hipStream_t stream) {
   return EGONN_OK;
 }
 
+// ------------------------------------------------------------------ row-group tables (rowgroup.hip) of the plan's maps
+static int rg_window(int level) { return level <= 3 ? 1024 : 256; }
+
+// Builds the row-group form of the requested maps that do not exist yet, all in ONE launch.
+// kind: 0 = k=3 map of `level`, 1 = k=2,s=2 map into `level` (from level-1), 2 = transposed map onto `level` (from level+1)
+int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, hipStream_t stream) {
+  Plan& P = ctx->plan;
+  RGBuild jobs[RG_MAX_JOBS];
+  int nj = 0;
+  for (int i = 0; i < count; ++i) {
+    const int kind = kinds[i], l = levels[i];
+    EGONN_REQUIRE(kind >= 0 && kind <= 2 && l >= (kind == 2 ? 0 : 1) && l < EGONN_NUM_LEVELS - (kind == 2 ? 1 : 0),
+                  EGONN_ERR_INVALID, "rowgroups: map kind %d / level %d out of range", kind, l);
+    Level& V = P.lv[l];
+    RowGroups& rg = kind == 0 ? V.rg27 : (kind == 1 ? V.rg8 : V.rgT);
+    if (rg.built) continue;
+    bool dup = false;
+    for (int j = 0; j < nj; ++j) dup |= (jobs[j].rg == &rg);
+    if (dup) continue;
+    if (kind == 2 && l == 0) EGONN_TRY(ensure_level0_parent_table(ctx, stream));
+    const int32_t* nbr = kind == 0 ? V.nbr27 : (kind == 1 ? V.nbr8 : V.nbrT);
+    EGONN_REQUIRE(nbr, EGONN_ERR_STATE, "rowgroups: the plan has no kernel map of kind %d at level %d", kind, l);
+    rg.K = kind == 0 ? 27 : 8;
+    rg.win = rg_window(l);
+    const int gpw = rg.win / 16;
+    rg.cap_groups = (int)((cdiv(P.cap[l], rg.win) + P.batch) * gpw);
+    Arena& A = ctx->plan_arena;
+    rg.perm = A.alloc<int32_t>((size_t)rg.cap_groups * 16);
+    rg.snbr = A.alloc<int32_t>((size_t)rg.cap_groups * rg.K * 16);
+    rg.gmask = A.alloc<uint32_t>((size_t)rg.cap_groups);
+    rg.meta = A.alloc<int32_t>((size_t)P.batch + 2);
+    EGONN_REQUIRE(rg.perm && rg.snbr && rg.gmask && rg.meta, EGONN_ERR_STATE, "plan arena too small (row groups)");
+    EGONN_REQUIRE(nj < RG_MAX_JOBS, EGONN_ERR_INVALID, "rowgroups: too many maps in one request");
+    jobs[nj].rg = &rg;
+    jobs[nj].nbr = nbr;
+    jobs[nj].n_dev = ctx->dev_counts + l;
+    jobs[nj].boff = V.boff;
+    ++nj;
+  }
+  if (nj == 0) return EGONN_OK;
+  EGONN_TRY(rowgroup_build(jobs, nj, P.batch, stream));
+  for (int j = 0; j < nj; ++j) jobs[j].rg->built = true;
+  return EGONN_OK;
+}
+
 static size_t plan_arena_bytes(int64_t n, int B) {
   // raw+sorted keys/vals, 10 levels x (keys, parent, cstart, mask, bstart), perm, maps of levels 1..7 (<= n rows each)
   size_t per_row = 2 * (8 + 4) + NL * (8 + 4 + 4 + 8 + 4) + 4 + 9 * 27 * 4 + 7 * (8 + 8) * 4 + 4 + 27 * 12 + 8 * 4;
-  return (size_t)(n + 8) * per_row + (size_t)(B + 1) * 4 * EGONN_NUM_LEVELS + (size_t)cdiv(n, PYR_TILE) * NL * 4 +
+  // row-group tables: k=3 (27+1 ints + mask) and the two 8-slot maps, <= 2n rows over all levels + window rounding
+  per_row += 2 * ((27 + 1) * 4 + 1 + 2 * ((8 + 1) * 4 + 1));
+  const size_t rg_round = (size_t)(B + 8) * 1024 * (28 + 2 * 9) * 4 * EGONN_NUM_LEVELS;
+  return (size_t)(n + 8) * per_row + (size_t)(B + 1) * 4 * EGONN_NUM_LEVELS + (size_t)cdiv(n, PYR_TILE) * NL * 4 + rg_round +
          (1 << 20);
 }
 

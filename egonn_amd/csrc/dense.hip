@@ -28,12 +28,23 @@ __device__ static inline float apply_act(float v, int act) {
 // once into registers; all B loads of a pass are issued before its MFMA chains (CIN is a template parameter so
 // the loops unroll and the loads batch).  The contraction index inside a 16-wide k-block is permuted (lane
 // group g owns ci = 16t + 4g .. 4g+3) so that A and (out,in)-layout B come in as one float4 per lane.
-template <int W_OUT_IN, int CIN>
-__global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ in, int64_t n,
+// IN_BF16: the input rows are bf16 (configs[2] feature maps; widened exactly to fp32 in registers — the weights and the
+// arithmetic stay fp32); io bit 0: residual is bf16, bit 1: out is bf16.
+__device__ static inline float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ static inline uint32_t f2bf_rn(float a) {
+  uint32_t u = __float_as_uint(a);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+template <int W_OUT_IN, int CIN, bool IN_BF16>
+__global__ __launch_bounds__(256) void dense_kernel(const void* __restrict__ in_v, int64_t n,
                                                     const float* __restrict__ W, int cout,
                                                     const float* __restrict__ bias, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, int act,
-                                                    const float* __restrict__ residual, float* __restrict__ out) {
+                                                    const void* __restrict__ residual_v, void* __restrict__ out_v, int io) {
+  const float* in = reinterpret_cast<const float*>(in_v);
+  const float* residual = reinterpret_cast<const float*>(residual_v);
+  float* out = reinterpret_cast<float*>(out_v);
   constexpr int KS = CIN / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g4 = lane >> 4;
@@ -42,8 +53,17 @@ __global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ in
   const int64_t row = row_base + l15;
   float4 a[KS];
 #pragma unroll
-  for (int t = 0; t < KS; ++t)
-    a[t] = (row < n) ? *reinterpret_cast<const float4*>(in + row * CIN + 16 * t + 4 * g4) : make_float4(0, 0, 0, 0);
+  for (int t = 0; t < KS; ++t) {
+    a[t] = make_float4(0, 0, 0, 0);
+    if (row < n) {
+      if constexpr (IN_BF16) {
+        const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(in_v) + row * CIN + 16 * t + 4 * g4);
+        a[t] = make_float4(bf2f(h.x & 0xFFFFu), bf2f(h.x >> 16), bf2f(h.y & 0xFFFFu), bf2f(h.y >> 16));
+      } else {
+        a[t] = *reinterpret_cast<const float4*>(in + row * CIN + 16 * t + 4 * g4);
+      }
+    }
+  }
   const int ncol0 = blockIdx.y * 64;
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
@@ -94,8 +114,10 @@ __global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ in
             float v = acc[nt][r] + bi;
             if (scale) v = v * sc + sh;
             v = apply_act(v, act);
-            if (residual) v += residual[orow * cout + col];
-            out[orow * cout + col] = v;
+            if (residual_v)
+              v += (io & 1) ? bf2f(reinterpret_cast<const uint16_t*>(residual_v)[orow * cout + col]) : residual[orow * cout + col];
+            if (io & 2) reinterpret_cast<uint16_t*>(out_v)[orow * cout + col] = (uint16_t)f2bf_rn(v);
+            else out[orow * cout + col] = v;
           }
         }
       }
@@ -114,19 +136,19 @@ __global__ void dense_any_kernel(const float* __restrict__ in, int64_t total, in
   out[i] = apply_act(s, act);
 }
 
-int dense_forward(const float* in, int64_t n, int cin, const float* W, int w_out_in, int cout, const float* bias,
-                  const float* scale, const float* shift, int act, const float* residual, float* out,
-                  hipStream_t stream) {
+int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const float* W, int w_out_in, int cout,
+                     const float* bias, const float* scale, const float* shift, int act, const void* residual, int res_bf16,
+                     void* out, int out_bf16, hipStream_t stream) {
   if (n == 0) return EGONN_OK;
   const dim3 grid((unsigned)cdiv(n, 64), (unsigned)cdiv(cout, 64));
+  const int io = (res_bf16 ? 1 : 0) | (out_bf16 ? 2 : 0);
+#define EGONN_DENSE_LAUNCH(WOI, CI, INB)                                                                              \
+  hipLaunchKernelGGL((dense_kernel<WOI, CI, INB>), grid, dim3(256), 0, stream, in, n, W, cout, bias, scale, shift, act, \
+                     residual, out, io)
 #define EGONN_DENSE_CASE(CI)                                                                                       \
   if (cin == CI) {                                                                                                 \
-    if (w_out_in)                                                                                                  \
-      hipLaunchKernelGGL((dense_kernel<1, CI>), grid, dim3(256), 0, stream, in, n, W, cout, bias, scale, shift, act, \
-                         residual, out);                                                                           \
-    else                                                                                                           \
-      hipLaunchKernelGGL((dense_kernel<0, CI>), grid, dim3(256), 0, stream, in, n, W, cout, bias, scale, shift, act, \
-                         residual, out);                                                                           \
+    if (w_out_in) { if (in_bf16) EGONN_DENSE_LAUNCH(1, CI, true); else EGONN_DENSE_LAUNCH(1, CI, false); }         \
+    else          { if (in_bf16) EGONN_DENSE_LAUNCH(0, CI, true); else EGONN_DENSE_LAUNCH(0, CI, false); }         \
     HIP_CHECK(hipGetLastError());                                                                                  \
     return EGONN_OK;                                                                                               \
   }
@@ -137,13 +159,19 @@ int dense_forward(const float* in, int64_t n, int cin, const float* W, int w_out
   EGONN_DENSE_CASE(192)
   EGONN_DENSE_CASE(256)
 #undef EGONN_DENSE_CASE
+#undef EGONN_DENSE_LAUNCH
   // any other width (the 3- and 1-channel gradients of the keypoint / sigma regressors): plain kernel, thread per output
-  EGONN_REQUIRE(!scale && !shift && !residual, EGONN_ERR_INVALID, "dense: cin=%d has no fused epilogue", cin);
+  EGONN_REQUIRE(!scale && !shift && !residual && !in_bf16 && !out_bf16, EGONN_ERR_INVALID, "dense: cin=%d has no fused epilogue", cin);
   const int64_t total = n * cout;
-  hipLaunchKernelGGL(dense_any_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, in, total, cin, W, w_out_in,
-                     cout, bias, act, out);
+  hipLaunchKernelGGL(dense_any_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream,
+                     reinterpret_cast<const float*>(in), total, cin, W, w_out_in, cout, bias, act, reinterpret_cast<float*>(out));
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
+}
+int dense_forward(const float* in, int64_t n, int cin, const float* W, int w_out_in, int cout, const float* bias,
+                  const float* scale, const float* shift, int act, const float* residual, float* out,
+                  hipStream_t stream) {
+  return dense_forward_ex(in, 0, n, cin, W, w_out_in, cout, bias, scale, shift, act, residual, 0, out, 0, stream);
 }
 
 // ------------------------------------------------------------------ BatchNorm folding (eval mode)
@@ -252,23 +280,49 @@ __device__ static inline int sample_of_row(const int32_t* __restrict__ boff, int
   return lo;
 }
 
-__global__ void eca_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+template <bool BF16>
+__global__ void eca_apply_kernel(const void* __restrict__ x, const void* __restrict__ res,
                                  const float* __restrict__ gate, const int32_t* __restrict__ boff, int B, int64_t n,
-                                 int c4, float* __restrict__ out) {
+                                 int c4, void* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * c4) return;
   const int32_t r = (int32_t)(t / c4);
   const int q = (int)(t - (int64_t)r * c4);
   const int b = sample_of_row(boff, B, r);
-  const float4 xv = reinterpret_cast<const float4*>(x)[t];
-  const float4 rv = reinterpret_cast<const float4*>(res)[t];
+  float4 xv, rv;
+  if constexpr (BF16) {
+    const uint2 xh = reinterpret_cast<const uint2*>(x)[t], rh = reinterpret_cast<const uint2*>(res)[t];
+    xv = make_float4(bf2f(xh.x & 0xFFFFu), bf2f(xh.x >> 16), bf2f(xh.y & 0xFFFFu), bf2f(xh.y >> 16));
+    rv = make_float4(bf2f(rh.x & 0xFFFFu), bf2f(rh.x >> 16), bf2f(rh.y & 0xFFFFu), bf2f(rh.y >> 16));
+  } else {
+    xv = reinterpret_cast<const float4*>(x)[t];
+    rv = reinterpret_cast<const float4*>(res)[t];
+  }
   const float4 g = reinterpret_cast<const float4*>(gate)[(int64_t)b * c4 + q];
   float4 o;
   o.x = fmaxf(xv.x * g.x + rv.x, 0.f);
   o.y = fmaxf(xv.y * g.y + rv.y, 0.f);
   o.z = fmaxf(xv.z * g.z + rv.z, 0.f);
   o.w = fmaxf(xv.w * g.w + rv.w, 0.f);
-  reinterpret_cast<float4*>(out)[t] = o;
+  if constexpr (BF16) {
+    uint2 oh;
+    oh.x = f2bf_rn(o.x) | (f2bf_rn(o.y) << 16);
+    oh.y = f2bf_rn(o.z) | (f2bf_rn(o.w) << 16);
+    reinterpret_cast<uint2*>(out)[t] = oh;
+  } else {
+    reinterpret_cast<float4*>(out)[t] = o;
+  }
+}
+__global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ in, int64_t n, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) out[t] = bf2f(in[t]);
+}
+int convert_bf16_to_f32(const void* in, int64_t n, float* out, hipStream_t stream) {
+  if (n == 0) return EGONN_OK;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream,
+                     reinterpret_cast<const uint16_t*>(in), n, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
 }
 
 int eca_apply(const float* x, const float* res, const float* partial, const int32_t* boff, int B, int64_t n, int c,
@@ -279,8 +333,66 @@ int eca_apply(const float* x, const float* res, const float* partial, const int3
   hipLaunchKernelGGL(eca_gate_kernel, dim3(B), dim3(256), c * sizeof(float), stream, partial, boff, c, wconv, ksize,
                      gate);
   const int c4 = c / 4;
-  hipLaunchKernelGGL(eca_apply_kernel, dim3((unsigned)cdiv(n * c4, 256)), dim3(256), 0, stream, x, res, gate, boff, B,
+  hipLaunchKernelGGL(eca_apply_kernel<false>, dim3((unsigned)cdiv(n * c4, 256)), dim3(256), 0, stream, x, res, gate, boff, B,
                      n, c4, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ECA gate straight from the per-group column sums of the conv2 epilogue (sconv.hip): the groups of sample b are
+// rg.meta[1+b] .. rg.meta[2+b] (a window never straddles two samples), summed in fixed order => deterministic.
+__global__ __launch_bounds__(256) void eca_gate_groups_kernel(const float* __restrict__ psum,
+                                                               const uint32_t* __restrict__ gmask,
+                                                               const int32_t* __restrict__ meta,
+                                                               const int32_t* __restrict__ boff, int c,
+                                                               const float* __restrict__ wconv, int ksize,
+                                                               float* __restrict__ gate) {
+  __shared__ float red[256];
+  __shared__ float mean[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int g0 = meta[1 + b], g1 = meta[2 + b];
+  const int32_t cntr = boff[b + 1] - boff[b];
+  const int nsl = 256 / c, sl = tid / c, ch = tid - sl * c;     // c <= 256, power of two
+  float acc = 0.f;
+  if (sl < nsl)
+    for (int g = g0 + sl; g < g1; g += nsl)
+      if (gmask[g] >> 31) acc += psum[(int64_t)g * c + ch];
+  red[tid] = acc;
+  __syncthreads();
+  if (tid < c) {
+    float s = 0.f;
+    for (int k = 0; k < nsl; ++k) s += red[k * c + tid];
+    mean[tid] = cntr > 0 ? s / (float)cntr : 0.f;
+  }
+  __syncthreads();
+  if (tid < c) {
+    const int pad = (ksize - 1) / 2;
+    float y = 0.f;
+    for (int j = 0; j < ksize; ++j) {
+      const int q = tid + j - pad;
+      if (q >= 0 && q < c) y += wconv[j] * mean[q];
+    }
+    gate[(int64_t)b * c + tid] = 1.f / (1.f + expf(-y));
+  }
+}
+int eca_gate_groups(const float* psum, const RowGroups& rg, const int32_t* boff, int B, int c, const float* wconv, int ksize,
+                    float* gate, hipStream_t stream) {
+  EGONN_REQUIRE(c >= 32 && c <= 256 && 256 % c == 0, EGONN_ERR_INVALID, "eca gate: %d channels unsupported", c);
+  hipLaunchKernelGGL(eca_gate_groups_kernel, dim3(B), dim3(256), 0, stream, psum, rg.gmask, rg.meta, boff, c, wconv, ksize,
+                     gate);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+int eca_apply_gate(const void* x, const void* res, const float* gate, const int32_t* boff, int B, int64_t n, int c,
+                   void* out, int bf16, hipStream_t stream) {
+  if (n == 0) return EGONN_OK;
+  const int c4 = c / 4;
+  if (bf16)
+    hipLaunchKernelGGL(eca_apply_kernel<true>, dim3((unsigned)cdiv(n * c4, 256)), dim3(256), 0, stream, x, res, gate, boff, B, n,
+                       c4, out);
+  else
+    hipLaunchKernelGGL(eca_apply_kernel<false>, dim3((unsigned)cdiv(n * c4, 256)), dim3(256), 0, stream, x, res, gate, boff, B, n,
+                       c4, out);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }

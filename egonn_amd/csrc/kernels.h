@@ -6,21 +6,28 @@ namespace egonn {
 
 const char* last_error();
 
+// sconv.hip ------------------------------------------------------------------------------------
+// out[o] = act( (sum_k in[nbr[o][k]] @ W[k]) * scale + shift ) on the row-group form of a kernel map (rowgroup.hip).
+bool sconv_rg_supported(int cin, int cout);
+// W [K][cin][cout] (reference layout) -> item-major MFMA fragment order, fp32 or bf16; flip: W'[k] = W[K-1-k];
+// transpose: the source kernel is [K][cout][cin]
+int pack_rg_weights(const float* W, int K, int cin, int cout, int bf16, int flip, int transpose, void* out,
+                    hipStream_t stream);
+int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wp, int cin,
+                     int cout, int bf16, const float* scale, const float* shift, int relu, void* out, float* psum,
+                     hipStream_t stream, int variant = 0);
+// Convolution over a map of the plan.  kind 0: k=3 on `level`; 1: k=2,s=2 from level-1 into `level`; 2: transposed from
+// level+1 onto `level`.  Wp: kernel already packed for this precision (or null: W is packed into `scratch` first).
+// bf16: feature maps in/out and weights are bf16.  psum (nullable): [groups][cout] per-group column sums of the output.
+int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, int cin, int cout, int bf16,
+              const float* scale, const float* shift, int relu, void* out, float* psum, float* scratch,
+              size_t scratch_floats, hipStream_t stream);
+static constexpr size_t SCONV_SCRATCH_FLOATS = (size_t)2 << 20;   // 8 MB: one packed kernel (27 x 256 x 256 fp32 = 7 MB)
 // conv.hip -------------------------------------------------------------------------------------
-// out[o] = act( (sum_k in[nbr[o][k]] @ W[k]) * scale + shift ), nbr: [n_out][K] rows or -1, W: [K][cin][cout]
-// scratch (nullable): scratch_floats floats for the split-over-offsets path used on small levels
-// in: [n_in][cin] rows gathered through nbr; W: reference layout [K][cin][cout]; Wp: the same kernel in MFMA fragment order (pack_sconv_weights), or null
-int sconv_forward(const float* in, int64_t n_in, const int32_t* nbr, const float* W, const float* Wp, const float* scale,
-                  const float* shift, int relu, float* out, int32_t n_out, int K, int cin, int cout, float* scratch,
-                  size_t scratch_floats, hipStream_t stream, int bf16 = 0);   // bf16: Wp (if given) is the bf16 packing
-int pack_sconv_weights(const float* W, int K, int cin, int cout, float* out, hipStream_t stream);
-int pack_sconv_weights_bf16(const float* W, int K, int cin, int cout, void* out, hipStream_t stream);
-static constexpr size_t SCONV_SCRATCH_FLOATS = (size_t)8 << 20;   // 32 MB: >= 512 tiles x 64 rows x 128 ch
-void sconv_set_naive(bool on);
-void sconv_set_variant(int v);
-void sconv_set_skip(int m);
+int sconv_naive(const float* in, const int32_t* nbr, const float* W, const float* scale, const float* shift, int relu,
+                float* out, int64_t n_out, int K, int cin, int cout, hipStream_t stream);
 int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, const float* scale,
-                     const float* shift, int relu, float* out, hipStream_t stream);
+                     const float* shift, int relu, void* out, int out_bf16, hipStream_t stream);
 
 // dense.hip ------------------------------------------------------------------------------------
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SOFTPLUS = 3, ACT_SIGMOID = 4 };
@@ -29,6 +36,10 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SOFTPLUS = 3, ACT_SIGMO
 int dense_forward(const float* in, int64_t n, int cin, const float* W, int w_out_in, int cout, const float* bias,
                   const float* scale, const float* shift, int act, const float* residual, float* out,
                   hipStream_t stream);
+// the same with bf16 feature maps on any of the three row operands (weights and arithmetic stay fp32)
+int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const float* W, int w_out_in, int cout,
+                     const float* bias, const float* scale, const float* shift, int act, const void* residual, int res_bf16,
+                     void* out, int out_bf16, hipStream_t stream);
 int bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps, int c, float* scale,
             float* shift, hipStream_t stream);
 int gather_rows(const float* in, const int32_t* perm, int64_t n, int c, float* out, hipStream_t stream);
@@ -39,6 +50,13 @@ int segment_partial_sums(const float* in, const int32_t* boff, int B, int c, int
 // out[r] = relu(x[r] * sigmoid(conv1d_k(mean_b))[c] + res[r])  (ECA gate + residual + ReLU)
 int eca_apply(const float* x, const float* res, const float* partial, const int32_t* boff, int B, int64_t n, int c,
               const float* wconv, int ksize, float* out, hipStream_t stream);
+// ECA gate from the per-group column sums a convolution epilogue left behind (sconv.hip): gate[b][c]
+int eca_gate_groups(const float* psum, const RowGroups& rg, const int32_t* boff, int B, int c, const float* wconv, int ksize,
+                    float* gate, hipStream_t stream);
+// out = relu(x * gate[sample] + res); bf16: x, res and out are bf16 feature maps
+int eca_apply_gate(const void* x, const void* res, const float* gate, const int32_t* boff, int B, int64_t n, int c,
+                   void* out, int bf16, hipStream_t stream);
+int convert_bf16_to_f32(const void* in, int64_t n, float* out, hipStream_t stream);
 // GeM: out[b][c] = (mean_b clamp(x,eps)^p)^(1/p) from the pow-mode partial sums
 int gem_finish(const float* partial, const int32_t* boff, int B, int c, const float* p, float* out,
                hipStream_t stream);

@@ -17,8 +17,9 @@ using namespace egonn;
 
 struct egonn_ctx : public Ctx {
   // scratch kept between egonn_forward and its readers
-  float* level_feat[EGONN_NUM_LEVELS] = {};
+  void* level_feat[EGONN_NUM_LEVELS] = {};
   int level_ch[EGONN_NUM_LEVELS] = {};
+  int level_bf16 = 0;                // precision of level_feat (last forward)
   int64_t* scan_off_dev = nullptr;   // device copy of the scan offsets (voxelize plans)
   bool from_points = false;
 };
@@ -76,10 +77,9 @@ struct egonn_model {
 // ------------------------------------------------------------------------------------------ lifecycle
 API const char* egonn_last_error(void) { return last_error(); }
 
-API int egonn_debug_set_naive_conv(int on) {
-  sconv_set_naive((on & 1) != 0);
-  sconv_set_skip((on >> 16) & 7);   // measurement hook: operand loads that return zeros without traffic
-  if (on & 0x100) sconv_set_variant(((on >> 4) & 7) | (((on >> 12) & 3) << 8));   // tuning hook: variant, tile
+API int egonn_debug_set_naive_conv(egonn_ctx* c, int on) {
+  EGONN_REQUIRE(c, EGONN_ERR_INVALID, "debug_set_naive_conv: null context");
+  c->conv_variant = (on == 1) ? 3 : (on == 2 ? 1 : 0);
   return EGONN_OK;
 }
 
@@ -222,18 +222,18 @@ API int egonn_conv(egonn_ctx* c, int level_in, int level_out, int ks, const floa
   if (ks == 5) {
     EGONN_REQUIRE(level_in == 0 && level_out == 0 && cin == 1, EGONN_ERR_INVALID,
                   "k=5 convolution is implemented for the stride-1 input layer with Cin=1 only");
-    return conv0_k5_forward(c, in, kernel, cout, scale, shift, relu, out, st);
+    return conv0_k5_forward(c, in, kernel, cout, scale, shift, relu, out, 0, st);
   }
   if (ks == 3) {
     EGONN_REQUIRE(level_in == level_out && level_in >= 1, EGONN_ERR_INVALID,
                   "k=3 convolution is implemented for levels 1..7 (same in/out level)");
-    return sconv_forward(in, P.lv[level_in].n, P.lv[level_in].nbr27, kernel, nullptr, scale, shift, relu, out, (int32_t)P.lv[level_in].n, 27, cin,
-                         cout, op_scratch(c), SCONV_SCRATCH_FLOATS, st);
+    return sconv_map(c, 0, level_out, in, kernel, nullptr, cin, cout, 0, scale, shift, relu, out, nullptr, op_scratch(c),
+                     SCONV_SCRATCH_FLOATS, st);
   }
   if (ks == 2) {
     EGONN_REQUIRE(level_out == level_in + 1, EGONN_ERR_INVALID, "k=2,s=2 convolution maps level l to l+1");
-    return sconv_forward(in, P.lv[level_in].n, P.lv[level_out].nbr8, kernel, nullptr, scale, shift, relu, out, (int32_t)P.lv[level_out].n, 8, cin,
-                         cout, op_scratch(c), SCONV_SCRATCH_FLOATS, st);
+    return sconv_map(c, 1, level_out, in, kernel, nullptr, cin, cout, 0, scale, shift, relu, out, nullptr, op_scratch(c),
+                     SCONV_SCRATCH_FLOATS, st);
   }
   set_error("conv: kernel_size %d not supported (1, 2, 3, 5)", ks);
   return EGONN_ERR_INVALID;
@@ -246,9 +246,36 @@ API int egonn_conv_transpose(egonn_ctx* c, int level_in, const float* in, int ci
   EGONN_REQUIRE(level_in >= 1 && level_in < EGONN_NUM_LEVELS, EGONN_ERR_INVALID,
                 "transposed conv: input level %d out of range [1,7]", level_in);
   if (level_in == 1) EGONN_TRY(ensure_level0_parent_table(c, (hipStream_t)stream));
-  const Level& L = c->plan.lv[level_in - 1];
-  return sconv_forward(in, c->plan.lv[level_in].n, L.nbrT, kernel, nullptr, nullptr, nullptr, 0, out, (int32_t)L.n, 8, cin, cout, op_scratch(c),
-                       SCONV_SCRATCH_FLOATS, (hipStream_t)stream);
+  return sconv_map(c, 2, level_in - 1, in, kernel, nullptr, cin, cout, 0, nullptr, nullptr, 0, out, nullptr, op_scratch(c),
+                   SCONV_SCRATCH_FLOATS, (hipStream_t)stream);
+}
+
+// Sparse convolution on a map of the plan with explicit precision (the operator behind egonn_conv / egonn_conv_transpose).
+API int egonn_sparse_conv(egonn_ctx* c, int map_kind, int level_out, const void* in, int cin, const float* kernel, int cout,
+                          int bf16, const float* scale, const float* shift, int relu, void* out, float* group_sums,
+                          void* stream) {
+  REQUIRE_PLAN(c);
+  HIP_CHECK(hipSetDevice(c->device));
+  EGONN_REQUIRE(in && kernel && out, EGONN_ERR_INVALID, "sparse_conv: null argument");
+  return sconv_map(c, map_kind, level_out, in, kernel, nullptr, cin, cout, bf16, scale, shift, relu, out, group_sums,
+                   op_scratch(c), SCONV_SCRATCH_FLOATS, (hipStream_t)stream);
+}
+// Number of row groups (16 output rows each) of a map: rows of the `group_sums` output of egonn_sparse_conv; the groups of
+// sample b are [first_group[b], first_group[b+1]) (HOST copy, B+1 entries).  [SYNC]
+API int egonn_map_groups(egonn_ctx* c, int map_kind, int level_out, int64_t* n_groups, int64_t* first_group, void* stream) {
+  REQUIRE_PLAN(c);
+  HIP_CHECK(hipSetDevice(c->device));
+  EGONN_REQUIRE(n_groups, EGONN_ERR_INVALID, "map_groups: null argument");
+  EGONN_TRY(ensure_rowgroups(c, &map_kind, &level_out, 1, (hipStream_t)stream));
+  const Level& V = c->plan.lv[level_out];
+  const RowGroups& rg = map_kind == 0 ? V.rg27 : (map_kind == 1 ? V.rg8 : V.rgT);
+  std::vector<int32_t> h((size_t)c->plan.batch + 2);
+  HIP_CHECK(hipMemcpyAsync(h.data(), rg.meta, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  *n_groups = h[0];
+  if (first_group)
+    for (int b = 0; b <= c->plan.batch; ++b) first_group[b] = h[1 + b];
+  return EGONN_OK;
 }
 
 __global__ void avg_finish_kernel(const float* __restrict__ partial, const int32_t* __restrict__ boff, int c,
@@ -469,7 +496,7 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
   EGONN_TRY(get_mlp(m, "local_keypoint_regressor", LOCAL_CH, LOCAL_CH / 2, 3, &m->kp));
   EGONN_TRY(get_mlp(m, "local_sigma_regressor", LOCAL_CH, LOCAL_CH / 2, 1, &m->sg));
 
-  // ---- repack every sparse-conv kernel into fragment order
+  // ---- repack every sparse-conv kernel into item-major MFMA fragment order (sconv.hip), fp32 and bf16
   {
     size_t need_p = 0;
     for (int i = 1; i <= 7; ++i) {
@@ -484,33 +511,24 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
     }
     float* pc = m->packed;
     uint16_t* qc = reinterpret_cast<uint16_t*>(m->packed + need_p);      // bf16 copies behind the fp32 ones
-    auto pack16 = [&](const float* w, int K, int ci, int co, const float** dst) -> int {
-      EGONN_TRY(pack_sconv_weights_bf16(w, K, ci, co, qc, st));
-      *dst = reinterpret_cast<const float*>(qc);
-      qc += (size_t)K * ci * co;
-      return EGONN_OK;
-    };
-    auto pack = [&](const float* w, int K, int ci, int co, const float** dst) -> int {
-      EGONN_TRY(pack_sconv_weights(w, K, ci, co, pc, st));
-      *dst = pc;
+    auto pack2 = [&](const float* w, int K, int ci, int co, const float** dst32, const float** dst16) -> int {
+      EGONN_TRY(pack_rg_weights(w, K, ci, co, 0, 0, 0, pc, st));
+      EGONN_TRY(pack_rg_weights(w, K, ci, co, 1, 0, 0, qc, st));
+      *dst32 = pc;
+      *dst16 = reinterpret_cast<const float*>(qc);
       pc += (size_t)K * ci * co;
+      qc += (size_t)K * ci * co;
       return EGONN_OK;
     };
     for (int i = 1; i <= 7; ++i) {
       const BlockRef& b = m->blk[i];
-      EGONN_TRY(pack(m->convs[i], 8, b.cin, b.cin, &m->p_convs[i]));
-      EGONN_TRY(pack(b.conv1, 27, b.cin, b.cout, &m->p_c1[i]));
-      EGONN_TRY(pack(b.conv2, 27, b.cout, b.cout, &m->p_c2[i]));
-      EGONN_TRY(pack16(m->convs[i], 8, b.cin, b.cin, &m->q_convs[i]));
-      EGONN_TRY(pack16(b.conv1, 27, b.cin, b.cout, &m->q_c1[i]));
-      EGONN_TRY(pack16(b.conv2, 27, b.cout, b.cout, &m->q_c2[i]));
+      EGONN_TRY(pack2(m->convs[i], 8, b.cin, b.cin, &m->p_convs[i], &m->q_convs[i]));
+      EGONN_TRY(pack2(b.conv1, 27, b.cin, b.cout, &m->p_c1[i], &m->q_c1[i]));
+      EGONN_TRY(pack2(b.conv2, 27, b.cout, b.cout, &m->p_c2[i], &m->q_c2[i]));
     }
-    EGONN_TRY(pack(m->gt[6], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[6]));
-    EGONN_TRY(pack(m->gt[7], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[7]));
-    EGONN_TRY(pack(m->lt[4], 8, LOCAL_CH, LOCAL_CH, &m->p_lt[4]));
-    EGONN_TRY(pack16(m->gt[6], 8, GLOBAL_CH, GLOBAL_CH, &m->q_gt[6]));
-    EGONN_TRY(pack16(m->gt[7], 8, GLOBAL_CH, GLOBAL_CH, &m->q_gt[7]));
-    EGONN_TRY(pack16(m->lt[4], 8, LOCAL_CH, LOCAL_CH, &m->q_lt[4]));
+    EGONN_TRY(pack2(m->gt[6], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[6], &m->q_gt[6]));
+    EGONN_TRY(pack2(m->gt[7], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[7], &m->q_gt[7]));
+    EGONN_TRY(pack2(m->lt[4], 8, LOCAL_CH, LOCAL_CH, &m->p_lt[4], &m->q_lt[4]));
   }
   EGONN_TRY(fold(m->bn[0], st));
   for (int i = 1; i <= 7; ++i) {
@@ -540,19 +558,30 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   EGONN_REQUIRE(step, EGONN_ERR_INVALID, "forward: null argument");
   HIP_CHECK(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
-  const Plan& P = c->plan;
+  Plan& P = c->plan;
   const int B = P.batch;
-  const int bf16 = (flags & EGONN_FLAG_BF16) ? 1 : 0;          // bf16 MFMA operands for the sparse convolutions
+  const int bf16 = (flags & EGONN_FLAG_BF16) ? 1 : 0;          // feature maps + sparse-conv weights in bf16 (configs[2])
+  const size_t es = bf16 ? 2 : 4;                              // bytes per feature-map element
   const bool do_global = !(flags & EGONN_FLAG_DISABLE_GLOBAL);
   const bool do_local = !(flags & EGONN_FLAG_DISABLE_LOCAL);
   EGONN_REQUIRE(!do_global || out_global, EGONN_ERR_INVALID, "forward: out_global is null");
   EGONN_REQUIRE(!do_local || (out_desc && out_kp && out_sigma), EGONN_ERR_INVALID, "forward: local outputs are null");
 
+  // ---- row-group tables of every map the graph uses: one launch per plan
+  {
+    int kinds[RG_MAX_JOBS], levels[RG_MAX_JOBS], nreq = 0;
+    for (int l = 1; l <= 7; ++l) { kinds[nreq] = 0; levels[nreq++] = l; }
+    for (int l = 1; l <= 7; ++l) { kinds[nreq] = 1; levels[nreq++] = l; }
+    if (do_global) { kinds[nreq] = 2; levels[nreq++] = 6; kinds[nreq] = 2; levels[nreq++] = 5; }
+    if (do_local) { kinds[nreq] = 2; levels[nreq++] = 3; }
+    EGONN_TRY(ensure_rowgroups(c, kinds, levels, nreq, st));
+  }
+
   // ---- workspace: every intermediate gets its own buffer (HBM is plentiful; no aliasing hazards)
-  size_t need = (size_t)P.lv[0].n * (1 + 32) * 4;
-  for (int i = 1; i <= 7; ++i) need += (size_t)P.lv[i].n * 128 * 4 * 6;
-  need += (size_t)P.lv[5].n * (192 + 256 + 128 * 2) * 4 + (size_t)P.lv[3].n * (96 + 32 + 32 + 3 + 64 * 2) * 4;
-  need += (size_t)B * SEG_CHUNKS * 256 * 4 * 10 + (size_t)P.lv[3].n * 32 + (4u << 20) + SCONV_SCRATCH_FLOATS * 4;
+  size_t need = (size_t)P.cap[0] * (1 + 32) * 4;
+  for (int i = 1; i <= 7; ++i) need += (size_t)P.cap[i] * 128 * 4 * 6 + (size_t)P.lv[i].rg27.cap_groups * 128 * 4;
+  need += (size_t)P.cap[5] * (192 + 256 + 128 * 2) * 4 + (size_t)P.cap[3] * (96 + 32 + 32 + 3 + 64 * 2) * 4;
+  need += (size_t)B * SEG_CHUNKS * 256 * 4 * 10 + (size_t)P.cap[3] * 32 + (4u << 20);
   for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
   EGONN_TRY(c->work_arena.ensure(need));
   Arena& A = c->work_arena;
@@ -560,8 +589,11 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
 #define WALLOC(var, count)                                                         \
   float* var = A.alloc<float>((size_t)(count));                                    \
   EGONN_REQUIRE(var != nullptr, EGONN_ERR_STATE, "work arena too small (" #var ")")
+  // feature maps: `count` elements of the map precision (bf16 maps use half of the fp32-sized slot)
+#define FALLOC(var, count)                                                         \
+  void* var = A.alloc<char>((size_t)(count) * es);                                 \
+  EGONN_REQUIRE(var != nullptr, EGONN_ERR_STATE, "work arena too small (" #var ")")
 
-  WALLOC(scr, SCONV_SCRATCH_FLOATS);
   // ---- trunk (models/minkgl.py:136-153)
   const int64_t n0 = P.lv[0].n;
   const float* f0 = features;          // voxelize plans: features are already in level-0 row order; NULL = all ones
@@ -570,49 +602,54 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     EGONN_TRY(gather_rows(features, P.perm0, n0, 1, fg, st));
     f0 = fg;
   }
-  WALLOC(x0, n0 * 32);
+  FALLOC(x0, n0 * 32);
   {
     ProfScope ps(c, st, "conv0_k5_kernel/L0", PK_CONV0, 0, 125, 1, 32, n0, n0);
-    EGONN_TRY(conv0_k5_forward(c, f0, m->conv0, 32, m->bn[0].scale, m->bn[0].shift, 1, x0, st));
+    EGONN_TRY(conv0_k5_forward(c, f0, m->conv0, 32, m->bn[0].scale, m->bn[0].shift, 1, x0, bf16, st));
   }
-  const float* x[8] = {x0};
+  const void* x[8] = {x0};
   c->level_feat[0] = x0;
   c->level_ch[0] = 32;
+  c->level_bf16 = bf16;
   for (int i = 1; i <= 7; ++i) {
     const BlockRef& b = m->blk[i];
     const Level& L = P.lv[i];
     const int64_t n = L.n;
-    WALLOC(y, n * b.cin);
+    FALLOC(y, n * b.cin);
     char tag[64];
     {
-      snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k2s2", b.cin, b.cin, i);
+      snprintf(tag, sizeof(tag), "sconv_rg_kernel<%d,%d>/L%d/k2s2", b.cin, b.cin, i);
       ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, P.lv[i - 1].n, n);
-      EGONN_TRY(sconv_forward(x[i - 1], P.lv[i - 1].n, L.nbr8, m->convs[i], bf16 ? m->q_convs[i] : m->p_convs[i], m->bn[i].scale, m->bn[i].shift, 1, y, (int32_t)n, 8,
-                              b.cin, b.cin, scr, SCONV_SCRATCH_FLOATS, st, bf16));
+      EGONN_TRY(sconv_map(c, 1, i, x[i - 1], nullptr, bf16 ? m->q_convs[i] : m->p_convs[i], b.cin, b.cin, bf16, m->bn[i].scale,
+                          m->bn[i].shift, 1, y, nullptr, nullptr, 0, st));
     }
     // ECABasicBlock (layers/eca_block.py:56-73)
-    WALLOC(t1, n * b.cout);
+    FALLOC(t1, n * b.cout);
     {
-      snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k3.conv1", b.cin, b.cout, i);
+      snprintf(tag, sizeof(tag), "sconv_rg_kernel<%d,%d>/L%d/k3.conv1", b.cin, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cin, b.cout, n, n);
-      EGONN_TRY(sconv_forward(y, n, L.nbr27, b.conv1, bf16 ? m->q_c1[i] : m->p_c1[i], b.n1.scale, b.n1.shift, 1, t1, (int32_t)n, 27, b.cin, b.cout, scr, SCONV_SCRATCH_FLOATS, st, bf16));
+      EGONN_TRY(sconv_map(c, 0, i, y, nullptr, bf16 ? m->q_c1[i] : m->p_c1[i], b.cin, b.cout, bf16, b.n1.scale, b.n1.shift, 1, t1,
+                          nullptr, nullptr, 0, st));
     }
-    WALLOC(t2, n * b.cout);
+    FALLOC(t2, n * b.cout);
+    WALLOC(psum, (size_t)L.rg27.cap_groups * b.cout);
     {
-      snprintf(tag, sizeof(tag), "sconv_mfma_kernel<%d,%d>/L%d/k3.conv2", b.cout, b.cout, i);
+      snprintf(tag, sizeof(tag), "sconv_rg_kernel<%d,%d>/L%d/k3.conv2", b.cout, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cout, b.cout, n, n);
-      EGONN_TRY(sconv_forward(t1, n, L.nbr27, b.conv2, bf16 ? m->q_c2[i] : m->p_c2[i], b.n2.scale, b.n2.shift, 0, t2, (int32_t)n, 27, b.cout, b.cout, scr, SCONV_SCRATCH_FLOATS, st, bf16));
+      EGONN_TRY(sconv_map(c, 0, i, t1, nullptr, bf16 ? m->q_c2[i] : m->p_c2[i], b.cout, b.cout, bf16, b.n2.scale, b.n2.shift, 0, t2,
+                          psum, nullptr, 0, st));
     }
-    WALLOC(partial, (size_t)B * SEG_CHUNKS * b.cout + (size_t)B * b.cout);
-    EGONN_TRY(segment_partial_sums(t2, L.boff, B, b.cout, 0, nullptr, partial, st));
-    const float* res = y;
+    WALLOC(gate, (size_t)B * b.cout);
+    EGONN_TRY(eca_gate_groups(psum, L.rg27, L.boff, B, b.cout, b.eca, b.eca_k, gate, st));
+    const void* res = y;
     if (b.down) {
-      WALLOC(rd, n * b.cout);
-      EGONN_TRY(dense_forward(y, n, b.cin, b.down, 0, b.cout, nullptr, b.dn.scale, b.dn.shift, ACT_NONE, nullptr, rd, st));
+      FALLOC(rd, n * b.cout);
+      EGONN_TRY(dense_forward_ex(y, bf16, n, b.cin, b.down, 0, b.cout, nullptr, b.dn.scale, b.dn.shift, ACT_NONE, nullptr, 0, rd,
+                                 bf16, st));
       res = rd;
     }
-    WALLOC(xo, n * b.cout);
-    EGONN_TRY(eca_apply(t2, res, partial, L.boff, B, n, b.cout, b.eca, b.eca_k, xo, st));
+    FALLOC(xo, n * b.cout);
+    EGONN_TRY(eca_apply_gate(t2, res, gate, L.boff, B, n, b.cout, xo, bf16, st));
     x[i] = xo;
     c->level_feat[i] = xo;
     c->level_ch[i] = b.cout;
@@ -620,16 +657,21 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
 
   // ---- global head + decoder + GeM (models/minkgl.py:46-60, 207-225; layers/pooling.py:82-86)
   if (do_global) {
-    WALLOC(g7, P.lv[7].n * GLOBAL_CH);
-    EGONN_TRY(dense_forward(x[7], P.lv[7].n, 128, m->g1x1[7], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, g7, st));
-    WALLOC(u6, P.lv[6].n * GLOBAL_CH);
-    EGONN_TRY(sconv_forward(g7, P.lv[7].n, P.lv[6].nbrT, m->gt[7], bf16 ? m->q_gt[7] : m->p_gt[7], nullptr, nullptr, 0, u6, (int32_t)P.lv[6].n, 8, GLOBAL_CH, GLOBAL_CH, scr, SCONV_SCRATCH_FLOATS, st, bf16));
-    WALLOC(g6, P.lv[6].n * GLOBAL_CH);
-    EGONN_TRY(dense_forward(x[6], P.lv[6].n, 128, m->g1x1[6], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u6, g6, st));
-    WALLOC(u5, P.lv[5].n * GLOBAL_CH);
-    EGONN_TRY(sconv_forward(g6, P.lv[6].n, P.lv[5].nbrT, m->gt[6], bf16 ? m->q_gt[6] : m->p_gt[6], nullptr, nullptr, 0, u5, (int32_t)P.lv[5].n, 8, GLOBAL_CH, GLOBAL_CH, scr, SCONV_SCRATCH_FLOATS, st, bf16));
+    FALLOC(g7, P.lv[7].n * GLOBAL_CH);
+    EGONN_TRY(dense_forward_ex(x[7], bf16, P.lv[7].n, 128, m->g1x1[7], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0,
+                               g7, bf16, st));
+    FALLOC(u6, P.lv[6].n * GLOBAL_CH);
+    EGONN_TRY(sconv_map(c, 2, 6, g7, nullptr, bf16 ? m->q_gt[7] : m->p_gt[7], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u6,
+                        nullptr, nullptr, 0, st));
+    FALLOC(g6, P.lv[6].n * GLOBAL_CH);
+    EGONN_TRY(dense_forward_ex(x[6], bf16, P.lv[6].n, 128, m->g1x1[6], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u6, bf16,
+                               g6, bf16, st));
+    FALLOC(u5, P.lv[5].n * GLOBAL_CH);
+    EGONN_TRY(sconv_map(c, 2, 5, g6, nullptr, bf16 ? m->q_gt[6] : m->p_gt[6], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u5,
+                        nullptr, nullptr, 0, st));
     WALLOC(g5, P.lv[5].n * GLOBAL_CH);
-    EGONN_TRY(dense_forward(x[5], P.lv[5].n, 128, m->g1x1[5], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u5, g5, st));
+    EGONN_TRY(dense_forward_ex(x[5], bf16, P.lv[5].n, 128, m->g1x1[5], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u5, bf16,
+                               g5, 0, st));
     WALLOC(gh, P.lv[5].n * m->gdec.mid);
     WALLOC(gd, P.lv[5].n * GLOBAL_DIM);
     EGONN_TRY(run_mlp(m->gdec, g5, P.lv[5].n, ACT_NONE, gh, gd, st));
@@ -641,12 +683,14 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   // ---- local head, descriptor / keypoint / sigma regressors (models/minkgl.py:287-308)
   if (do_local) {
     const int64_t n3 = P.lv[3].n, n4 = P.lv[4].n;
-    WALLOC(l4, n4 * LOCAL_CH);
-    EGONN_TRY(dense_forward(x[4], n4, 128, m->l1x1[4], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, l4, st));
-    WALLOC(u3, n3 * LOCAL_CH);
-    EGONN_TRY(sconv_forward(l4, n4, P.lv[3].nbrT, m->lt[4], bf16 ? m->q_lt[4] : m->p_lt[4], nullptr, nullptr, 0, u3, (int32_t)n3, 8, LOCAL_CH, LOCAL_CH, scr, SCONV_SCRATCH_FLOATS, st, bf16));
+    FALLOC(l4, n4 * LOCAL_CH);
+    EGONN_TRY(dense_forward_ex(x[4], bf16, n4, 128, m->l1x1[4], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0, l4,
+                               bf16, st));
+    FALLOC(u3, n3 * LOCAL_CH);
+    EGONN_TRY(sconv_map(c, 2, 3, l4, nullptr, bf16 ? m->q_lt[4] : m->p_lt[4], LOCAL_CH, LOCAL_CH, bf16, nullptr, nullptr, 0, u3,
+                        nullptr, nullptr, 0, st));
     WALLOC(l3, n3 * LOCAL_CH);
-    EGONN_TRY(dense_forward(x[3], n3, 64, m->l1x1[3], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u3, l3, st));
+    EGONN_TRY(dense_forward_ex(x[3], bf16, n3, 64, m->l1x1[3], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u3, bf16, l3, 0, st));
     WALLOC(dh, n3 * m->ldec.mid);
     EGONN_TRY(run_mlp(m->ldec, l3, n3, ACT_NONE, dh, out_desc, st));
     EGONN_TRY(l2_normalize_rows(out_desc, n3, LOCAL_DIM, st));
@@ -659,6 +703,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     EGONN_TRY(run_mlp(m->sg, l3, n3, ACT_SOFTPLUS, sh, out_sigma, st));
   }
 #undef WALLOC
+#undef FALLOC
   return EGONN_OK;
 }
 
@@ -668,8 +713,9 @@ API int egonn_forward_level_features(egonn_ctx* c, int level, float* out, int ch
                 "no features for level %d (run egonn_forward first)", level);
   EGONN_REQUIRE(channels == c->level_ch[level], EGONN_ERR_INVALID, "level %d has %d channels, caller expects %d", level,
                 c->level_ch[level], channels);
-  HIP_CHECK(hipMemcpyAsync(out, c->level_feat[level], sizeof(float) * c->plan.lv[level].n * channels,
-                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  const int64_t cnt = c->plan.lv[level].n * channels;
+  if (c->level_bf16) return convert_bf16_to_f32(c->level_feat[level], cnt, out, (hipStream_t)stream);
+  HIP_CHECK(hipMemcpyAsync(out, c->level_feat[level], sizeof(float) * cnt, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return EGONN_OK;
 }
 
@@ -711,12 +757,10 @@ API int egonn_profile_fetch(egonn_ctx* c, int cap, int* n, char* names, float* m
                             void* stream) {
   EGONN_REQUIRE(c && n && names && ms && bytes && flops, EGONN_ERR_INVALID, "profile_fetch: null argument");
   HIP_CHECK(hipSetDevice(c->device));
-  if (c->plan.valid) EGONN_TRY(count_map_pairs(c, (hipStream_t)stream));
+  if (c->plan.valid) EGONN_TRY(count_map_pairs(c, (hipStream_t)stream));   // [0] = first-layer pairs, [l] = k=3 map of level l
   HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   unsigned long long pairs[16];
   HIP_CHECK(hipMemcpy(pairs, c->dev_pairs, sizeof(pairs), hipMemcpyDeviceToHost));
-  pairs[0] = 0;
-  for (int i = 8; i < 16; ++i) pairs[0] += pairs[i];   // conv0 counters of the LAST forward
   int w = 0;
   for (auto& r : c->prof.recs) {
     float t = 0.f;

@@ -1,0 +1,645 @@
+// Sparse convolution for gfx950: row-group kernel with register accumulators.
+//
+// Replaces MinkowskiConvolution / MinkowskiConvolutionTranspose forward as called from the reference
+// (models/minkgl.py:39,100,105 and :46-60; ME BasicBlock conv1/conv2 via layers/eca_block.py:58-63;
+// models/minkfpn.py:50-52):
+//
+//   out[o] = act( (sum_k in[nbr[o][k]] @ W[k]) * scale + shift )
+//
+// Work decomposition (tables: rowgroup.hip).  A wave owns one GROUP of 16 output rows x 32 output columns; its
+// accumulators (2 MFMA tiles, 8 VGPRs) never leave registers.  It walks the kernel offsets k present in the group
+// (bits of gmask[g], scalar loop) and the 32-channel blocks cb of the input; one ITEM (k, cb) is
+//   fp32:  A = 16 gathered rows x 32 ch  (2 x buffer_load_b128 per lane)     W[k][cb][32 cols] (4 x b128, fragment order)
+//          16 x v_mfma_f32_16x16x4_f32   (exact fp32)
+//   bf16:  A = 16 rows x 32 ch           (1 x b128)                          W (2 x b128)
+//           2 x v_mfma_f32_16x16x32_bf16 (fp32 accumulate)
+// Missing neighbours are row "-1": the buffer resource's bounds check returns zeros without touching memory, so the
+// loop has no predicates.  Operands are fed swapped (D^T = W^T A^T): lane (row = l&15, g = l>>4) ends up with four
+// CONSECUTIVE output columns of its row, i.e. one 16-byte (fp32) / 8-byte (bf16) store per tile, BN scale/shift and
+// ReLU fused.  There is no LDS accumulator, no atomics, no split over offsets and no workgroup barrier: every output row
+// is produced by one wave, summed in ascending k, ascending channel order => results do not depend on the grouping
+// (batch-invariant, bitwise reproducible).
+// Items are software pipelined through a register ring (D slots of A+W), issued in consumption order because
+// s_waitcnt vmcnt is in-order; the neighbour rows of a group (K x 16 ints) are staged once into wave-private LDS so the
+// index lookups ride the lgkm counter and never drain the vector-memory queue.
+// The launch is persistent: the number of groups is read from device memory (meta[0]), workgroups stride over the
+// group range XCD by XCD (block b runs on XCD b % 8: consecutive groups — Z-order neighbours — share an L2).
+// Optional epilogue: per-group column sums of the stored values (fixed order) for the ECA / GeM pooling.
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include <hip/hip_ext.h>
+#include "kernels.h"
+
+namespace egonn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ static inline uint32_t f2bf(float a) {       // round to nearest even
+  uint32_t u = __float_as_uint(a);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// ------------------------------------------------------------------ weight packing
+// W[k][ci][co] (reference layout: MinkowskiConvolution.kernel) -> item-major fragment order
+//   fp32:  Wp[k][cb][ns][nt][t][lane][u] = W[k][32cb + 16t + 4(lane>>4) + u][32ns + 16nt + (lane&15)]
+//   bf16:  Wp[k][cb][ns][nt][lane][e]    = W[k][32cb + 8(lane>>4) + e]      [32ns + 16nt + (lane&15)]   (rounded)
+// so that the SLAB W[k][cb][all columns] the workgroup stages into LDS per item is one contiguous block.
+// flip: the kernel of the input-gradient convolution, W'[k] = W[K-1-k]^T (same map, nbr[o][k]=j <=> nbr[j][K-1-k]=o);
+// `transpose` alone serves k=2,s=2 <-> transposed pairs (same slot, W^T).
+__global__ void pack_rg_weights_kernel(const float* __restrict__ W, int K, int cin, int cout, int bf16, int flip,
+                                       int transpose, void* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per_k = (int64_t)cin * cout;
+  if (e >= K * per_k) return;
+  const int ncb = cin / 32, ns_n = cout / 32;
+  int64_t r = e;
+  int ci, co, k;
+  if (!bf16) {
+    const int u = (int)(r & 3); r >>= 2;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int t = (int)(r & 1); r >>= 1;
+    const int nt = (int)(r & 1); r >>= 1;
+    const int ns = (int)(r % ns_n); r /= ns_n;
+    const int cb = (int)(r % ncb); r /= ncb;
+    k = (int)r;
+    ci = 32 * cb + 16 * t + 4 * (lane >> 4) + u;
+    co = 32 * ns + 16 * nt + (lane & 15);
+  } else {
+    const int el = (int)(r & 7); r >>= 3;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int nt = (int)(r & 1); r >>= 1;
+    const int ns = (int)(r % ns_n); r /= ns_n;
+    const int cb = (int)(r % ncb); r /= ncb;
+    k = (int)r;
+    ci = 32 * cb + 8 * (lane >> 4) + el;
+    co = 32 * ns + 16 * nt + (lane & 15);
+  }
+  const int ks = flip ? K - 1 - k : k;
+  // source kernel is [K][cin_src][cout_src]; with transpose the packed (ci, co) reads W[ks][co][ci] of a [cout][cin] kernel
+  const float v = transpose ? W[(int64_t)ks * per_k + (int64_t)co * cin + ci] : W[(int64_t)ks * per_k + (int64_t)ci * cout + co];
+  if (bf16) reinterpret_cast<uint16_t*>(out)[e] = (uint16_t)f2bf(v);
+  else reinterpret_cast<float*>(out)[e] = v;
+}
+
+int pack_rg_weights(const float* W, int K, int cin, int cout, int bf16, int flip, int transpose, void* out,
+                    hipStream_t stream) {
+  EGONN_REQUIRE(cin % 32 == 0 && cout % 32 == 0, EGONN_ERR_INVALID, "sconv: channel counts must be multiples of 32 (%d->%d)", cin, cout);
+  const int64_t n = (int64_t)K * cin * cout;
+  hipLaunchKernelGGL(pack_rg_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, W, K, cin, cout, bf16, flip,
+                     transpose, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ the kernel
+struct SconvArgs {
+  const void* in;            // [n_in][CIN] fp32 or bf16
+  const int32_t* snbr;       // row-group tables
+  const uint32_t* gmask;
+  const int32_t* perm;
+  const int32_t* meta;       // [0] = groups in use
+  const void* Wp;            // packed kernel (pack_rg_weights)
+  const float* scale;        // folded BatchNorm (nullable)
+  const float* shift;
+  void* out;                 // [n_out][COUT]
+  float* psum;               // [groups][COUT] column sums of the stored values (nullable)
+  uint32_t in_bytes, w_bytes;
+  int K, relu;
+};
+
+template <int CIN, int COUT, bool BF16, int D>
+__global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
+  constexpr int NS = COUT / 32, NCB = CIN / 32;
+  constexpr int ES = BF16 ? 2 : 4;                       // bytes per feature element
+  constexpr int ALD = BF16 ? 1 : 2;                      // b128 loads of A per lane per item
+  constexpr int WLD = BF16 ? 2 : 4;                      // b128 loads of W per lane per item
+  constexpr uint32_t ITEM_BYTES = 32 * 32 * ES;
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int K = p.K;
+  int32_t* const ldsw = lds + wave * ((27 + 1) * 16);
+
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wp), 0, (int)p.w_bytes, 0x00020000);
+
+  const int ngroups = __builtin_amdgcn_readfirstlane(p.meta[0]);
+  const int ntask = (ngroups * NS + 3) >> 2;             // workgroup tasks (4 wave tasks each)
+  const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3; // gridDim.x is a multiple of 8
+  const int cpx = (ntask + 7) >> 3;
+  const int tend = min((xcd + 1) * cpx, ntask);
+
+  for (int t = xcd * cpx + (blockIdx.x >> 3); t < tend; t += nper) {
+    const int task = t * 4 + wave;
+    const int g = task / NS, ns = task - g * NS;
+    if (g >= ngroups) continue;
+    const uint32_t gm = __builtin_amdgcn_readfirstlane(p.gmask[g]);
+    if (!(gm >> 31)) continue;
+
+    // ---- stage the group's neighbour rows (K x 16 ints) + one all-absent row into wave-private LDS
+    {
+      const int4* src = reinterpret_cast<const int4*>(p.snbr + (int64_t)g * K * 16);
+      const int n16 = K * 4;                             // 16-byte pieces
+      int4 v0 = make_int4(0, 0, 0, 0), v1 = make_int4(0, 0, 0, 0);
+      if (lane < n16) v0 = src[lane];
+      if (lane + 64 < n16) v1 = src[lane + 64];
+      reinterpret_cast<int4*>(ldsw)[lane] = v0;          // lanes >= n16 write zeros: row K (all absent) and beyond
+      if (lane + 64 < 28 * 4) reinterpret_cast<int4*>(ldsw)[lane + 64] = v1;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // ---- item generator (scalar): set bits of the group mask x channel blocks
+    uint32_t mk = gm & 0x07FFFFFFu;
+    const int n_items = __builtin_amdgcn_readfirstlane(__popc(mk) * NCB);
+    int gen_k = 0, gen_cb = 0;
+    // pending item (the one whose loads are issued next): gathered-row byte offset per lane, W offset, validity
+    int32_t pend_idx;                                    // raw LDS value: consumed one step later, so the read latency is hidden
+    uint32_t pend_acb;
+    uint32_t pend_woff, pend_wbad;
+    auto generate = [&]() {                              // branch-free: scalar selects only
+      const bool need = (gen_cb == 0);
+      const bool take = need && (mk != 0);
+      const bool valid = !need || take;                  // items in the middle of a k are always real
+      gen_k = take ? __builtin_ctz(mk | 0x80000000u) : gen_k;
+      mk = take ? (mk & (mk - 1)) : mk;
+      const int krow = valid ? gen_k : K;
+      pend_idx = ldsw[krow * 16 + l15];
+      pend_acb = (uint32_t)(gen_cb * 32 * ES);
+      pend_woff = (uint32_t)(((gen_k * NCB + gen_cb) * NS + ns)) * ITEM_BYTES;
+      pend_wbad = valid ? 0u : 0x80000000u;
+      gen_cb = (valid && gen_cb + 1 < NCB) ? gen_cb + 1 : 0;
+    };
+
+    f32x4 aring[D][ALD];
+    f32x4 wring[D][WLD];
+    auto issue = [&](auto RS) {
+      constexpr int rs = decltype(RS)::value;
+      const uint32_t pend_aoff = (uint32_t)(pend_idx - 1) * (uint32_t)(CIN * ES) + pend_acb + (uint32_t)(g4 * 16);
+      const int wv = (int)((uint32_t)(lane * 16) | pend_wbad);
+      const int ws = __builtin_amdgcn_readfirstlane((int)pend_woff);
+#pragma unroll
+      for (int i = 0; i < WLD; ++i)
+        wring[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv + i * 1024, ws, 0));
+#pragma unroll
+      for (int i = 0; i < ALD; ++i)
+        aring[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(pend_aoff + 64 * i), 0, 0));
+    };
+
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    auto compute = [&](auto RS) {
+      constexpr int rs = decltype(RS)::value;
+      if constexpr (BF16) {
+        const bf16x8_t av = __builtin_bit_cast(bf16x8_t, aring[rs][0]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wring[rs][nt]), av, acc[nt], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wring[rs][nt * 2 + tt][u], aring[rs][tt][u], acc[nt], 0, 0, 0);
+      }
+    };
+
+    // ---- prologue: D-1 items in flight
+    generate();
+    [&]<int... Is>(std::integer_sequence<int, Is...>) {
+      ((issue(std::integral_constant<int, Is>{}), generate(), __builtin_amdgcn_sched_barrier(0)), ...);
+    }(std::make_integer_sequence<int, D - 1>{});
+    // ---- main loop: straight-line groups of D items (no branch between a load and its wait)
+    const int n_main = n_items / D;
+    for (int it = 0; it < n_main; ++it) {
+      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        // the scheduling barriers pin the issue order: hipcc otherwise sinks the loads below the MFMAs and interleaves
+        // the loads of different items, and the in-order vmcnt then waits for data that is not needed yet
+        ((issue(std::integral_constant<int, (Is + D - 1) % D>{}), generate(), __builtin_amdgcn_sched_barrier(0),
+          compute(std::integral_constant<int, Is>{}), __builtin_amdgcn_sched_barrier(0)), ...);
+      }(std::make_integer_sequence<int, D>{});
+    }
+    // ---- remainder (< D items, already in flight in slots 0..rem-1)
+    const int rem = n_items - n_main * D;
+    [&]<int... Is>(std::integer_sequence<int, Is...>) {
+      ((Is < rem ? compute(std::integral_constant<int, Is>{}) : (void)0), ...);
+    }(std::make_integer_sequence<int, D - 1>{});
+
+    // ---- epilogue: BN scale/shift (+ReLU), one store per tile; optional per-group column sums
+    const int32_t row = p.perm[(int64_t)g * 16 + l15];
+    float sums[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int c0 = ns * 32 + nt * 16 + 4 * g4;
+      f32x4 v = acc[nt];
+      if (p.scale) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c0);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + c0);
+        v = v * sc + sh;
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+      }
+      if (row >= 0) {
+        if constexpr (BF16) {
+          uint2 o;
+          o.x = f2bf(v[0]) | (f2bf(v[1]) << 16);
+          o.y = f2bf(v[2]) | (f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)row * COUT + c0) = o;
+        } else {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)row * COUT + c0) = v;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sums[nt][u] = row >= 0 ? v[u] : 0.f;
+    }
+    if (p.psum) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float s = sums[nt][u];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+          sums[nt][u] = s;
+        }
+      if (l15 == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          *reinterpret_cast<f32x4*>(p.psum + (int64_t)g * COUT + ns * 32 + nt * 16 + 4 * g4) =
+              (f32x4){sums[nt][0], sums[nt][1], sums[nt][2], sums[nt][3]};
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                     // the next task overwrites the wave's LDS rows
+  }
+}
+
+// ------------------------------------------------------------------ workgroup-cooperative variant
+// What the per-wave kernel above taught (profiles/r02a_pmc_sweep.txt): the texture-address unit is 71 % busy and the MFMA
+// pipe 45-50 % — four of the six vector loads of an item are the W fragments, re-fetched by every wave for every item.
+// Here the NW waves of a workgroup own NW consecutive groups (sorted => nearly the same offsets present) and walk the
+// UNION of their offsets in lock-step; per item the slab W[k][cb][all COUT columns] is copied ONCE per workgroup into an
+// LDS double buffer (each wave copies 1/NW of it) and every wave reads its B fragments from LDS (ds_read_b128,
+// lane-linear, conflict-free).  A wave now covers ALL output columns of its group (accumulators: COUT/16 MFMA tiles),
+// so the gathered rows are loaded once instead of once per 32-column slice; a wave whose group lacks the offset skips
+// the item's MFMAs (wave-uniform branch) but still takes part in the copy and the barrier.  One barrier per item:
+//   step i:  ds_write W(i+1) -> slab[(i+1)&1]   (data loaded one step earlier; slab last read in step i-1, before the barrier)
+//            issue W(i+2) -> registers, A(i+2) -> ring slot            (issue order = consumption order: vmcnt is in-order)
+//            if (group has k_i)  B <- slab[i&1];  MFMAs with A(i)
+//            barrier
+template <int CIN, int COUT, bool BF16, int NW>
+__global__ __launch_bounds__(NW * 64) void sconv_wg_kernel(const SconvArgs p) {
+  constexpr int D = 3;
+  constexpr int NS = COUT / 32, NCB = CIN / 32;
+  constexpr int ES = BF16 ? 2 : 4;
+  constexpr int ALD = BF16 ? 1 : 2;                      // b128 loads of A per lane per item
+  constexpr int BLD = BF16 ? 2 : 4;                      // ds_read_b128 of B fragments per 32-column slice
+  constexpr uint32_t ITEM_BYTES = 32 * 32 * ES;          // one (k, cb, 32-column slice) fragment block
+  constexpr uint32_t SLAB = ITEM_BYTES * NS;             // W[k][cb][all columns]
+  constexpr int LB = SLAB / (NW * 64);                   // bytes of the slab each lane copies
+  constexpr int SVEC = LB >= 16 ? 16 : 8;
+  constexpr int SW = LB / SVEC;                          // stage loads per lane per item
+  static_assert(LB >= 8 && SW * SVEC == LB, "slab / workgroup size mismatch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int K = p.K;
+  int32_t* const ldsw = reinterpret_cast<int32_t*>(smem + 2 * SLAB) + wave * (28 * 16);
+
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wp), 0, (int)p.w_bytes, 0x00020000);
+
+  const int ngroups = __builtin_amdgcn_readfirstlane(p.meta[0]);
+  const int ntask = ngroups / NW;                        // groups in use are a multiple of 16
+  // chunks of CHK consecutive tasks (= one 1024-row window for NW = 4) go round-robin to the XCDs: neighbours share an
+  // L2, and every XCD gets a sample of the whole cloud (contiguous eighths were unbalanced by up to the density contrast)
+  constexpr int CHK = 64 / NW;
+  const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3; // gridDim.x is a multiple of 8
+  const int nchunks = (ntask + CHK - 1) / CHK;
+
+  for (int lt = blockIdx.x >> 3;; lt += nper) {
+    const int chunk = (lt / CHK) * 8 + xcd;
+    if (chunk >= nchunks) break;
+    const int task = chunk * CHK + lt % CHK;
+    if (task >= ntask) continue;
+    const int g0 = task * NW;
+    uint32_t U = 0, own = 0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const uint32_t m = p.gmask[g0 + j];
+      U |= m;
+      own = (j == wave) ? m : own;
+    }
+    U = __builtin_amdgcn_readfirstlane(U);
+    own = __builtin_amdgcn_readfirstlane(own);
+    if (!(U >> 31)) continue;                            // four empty groups (tail of a partial window)
+    const int g = g0 + wave;
+
+    // ---- the group's neighbour rows (K x 16 ints) + an all-absent row -> wave-private LDS
+    {
+      const int4* src = reinterpret_cast<const int4*>(p.snbr + (int64_t)g * K * 16);
+      const int n16 = (own >> 31) ? K * 4 : 0;           // 16-byte pieces; an empty group reads nothing
+      int4 v0 = make_int4(0, 0, 0, 0), v1 = make_int4(0, 0, 0, 0);
+      if (lane < n16) v0 = src[lane];
+      if (lane + 64 < n16) v1 = src[lane + 64];
+      reinterpret_cast<int4*>(ldsw)[lane] = v0;
+      if (lane + 64 < 28 * 4) reinterpret_cast<int4*>(ldsw)[lane + 64] = v1;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // ---- item generator (scalar, identical in every wave): set bits of the union mask x channel blocks
+    uint32_t mk = U & 0x07FFFFFFu;
+    const int n_items = __popc(mk) * NCB;
+    const int n_steps = (n_items + D - 1) / D;           // groups of D steps; surplus steps are empty items
+    int gen_k = 0, gen_cb = 0;
+    int32_t pend_idx;
+    uint32_t pend_acb, pend_woff, pend_wbad;
+    int pend_has;
+    auto generate = [&]() {                              // branch-free: scalar selects only
+      const bool need = (gen_cb == 0);
+      const bool take = need && (mk != 0);
+      const bool valid = !need || take;
+      gen_k = take ? __builtin_ctz(mk | 0x80000000u) : gen_k;
+      mk = take ? (mk & (mk - 1)) : mk;
+      pend_has = (valid && ((own >> gen_k) & 1u)) ? 1 : 0;
+      const int krow = pend_has ? gen_k : K;
+      pend_idx = ldsw[krow * 16 + l15];
+      pend_acb = (uint32_t)(gen_cb * 32 * ES);
+      pend_woff = (uint32_t)(gen_k * NCB + gen_cb) * SLAB;
+      pend_wbad = valid ? 0u : 0x80000000u;
+      gen_cb = (valid && gen_cb + 1 < NCB) ? gen_cb + 1 : 0;
+    };
+
+    using svec_t = std::conditional_t<SVEC == 16, f32x4, float2>;
+    svec_t wreg[SW];
+    f32x4 aring[D][ALD];
+    int has[D];
+    auto issue = [&](auto RS) {                          // W slab piece of the pending item, then its gathered rows
+      constexpr int rs = decltype(RS)::value;
+      const int wv = (int)((uint32_t)((wave * 64 + lane) * SVEC) | pend_wbad);
+      const int ws = __builtin_amdgcn_readfirstlane((int)pend_woff);
+#pragma unroll
+      for (int i = 0; i < SW; ++i) {
+        if constexpr (SVEC == 16)
+          wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv + i * (NW * 64 * SVEC), ws, 0));
+        else
+          wreg[i] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, wv + i * (NW * 64 * SVEC), ws, 0));
+      }
+      const uint32_t aoff = (uint32_t)(pend_idx - 1) * (uint32_t)(CIN * ES) + pend_acb + (uint32_t)(g4 * 16);
+#pragma unroll
+      for (int i = 0; i < ALD; ++i)
+        aring[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(aoff + 64 * i), 0, 0));
+      has[rs] = pend_has;
+    };
+    auto stage_write = [&](int par) {                    // wreg -> slab[par]
+      char* dst = smem + par * SLAB + (wave * 64 + lane) * SVEC;
+#pragma unroll
+      for (int i = 0; i < SW; ++i) *reinterpret_cast<svec_t*>(dst + i * (NW * 64 * SVEC)) = wreg[i];
+    };
+
+    f32x4 acc[NS][2];
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[sidx][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](auto RS, int par) {
+      constexpr int rs = decltype(RS)::value;
+      if (has[rs]) {
+        const char* sl = smem + par * SLAB + lane * 16;
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+          f32x4 bfr[BLD];
+#pragma unroll
+          for (int i = 0; i < BLD; ++i) bfr[i] = *reinterpret_cast<const f32x4*>(sl + sidx * ITEM_BYTES + i * 1024);
+          if constexpr (BF16) {
+            const bf16x8_t av = __builtin_bit_cast(bf16x8_t, aring[rs][0]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[sidx][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[nt]), av, acc[sidx][nt], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                  acc[sidx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[nt * 2 + tt][u], aring[rs][tt][u], acc[sidx][nt], 0, 0, 0);
+          }
+        }
+      }
+    };
+
+    // ---- prologue: W(0) in slab 0, W(1) in registers, A(0), A(1) in flight, item 2 pending
+    generate();
+    issue(std::integral_constant<int, 0>{});
+    generate();
+    stage_write(0);
+    issue(std::integral_constant<int, 1>{});
+    generate();
+    __syncthreads();
+    int par = 0;
+    for (int it = 0; it < n_steps; ++it) {
+      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        ((stage_write(par ^ 1), issue(std::integral_constant<int, (Is + D - 1) % D>{}), generate(),
+          __builtin_amdgcn_sched_barrier(0), compute(std::integral_constant<int, Is>{}, par),
+          __builtin_amdgcn_sched_barrier(0), __syncthreads(), par ^= 1), ...);
+      }(std::make_integer_sequence<int, D>{});
+    }
+
+    // ---- epilogue: BN scale/shift (+ReLU), one store per tile; optional per-group column sums
+    const int32_t row = (own >> 31) ? p.perm[(int64_t)g * 16 + l15] : -1;
+#pragma unroll
+    for (int sidx = 0; sidx < NS; ++sidx) {
+      float sums[2][4];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int c0 = sidx * 32 + nt * 16 + 4 * g4;
+        f32x4 v = acc[sidx][nt];
+        if (p.scale) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c0);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + c0);
+          v = v * sc + sh;
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+        }
+        if (row >= 0) {
+          if constexpr (BF16) {
+            uint2 o;
+            o.x = f2bf(v[0]) | (f2bf(v[1]) << 16);
+            o.y = f2bf(v[2]) | (f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + (int64_t)row * COUT + c0) = o;
+          } else {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)row * COUT + c0) = v;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sums[nt][u] = row >= 0 ? v[u] : 0.f;
+      }
+      if (p.psum && (own >> 31)) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            float sv = sums[nt][u];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sv += __shfl_xor(sv, o, 64);
+            sums[nt][u] = sv;
+          }
+        if (l15 == 0) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            *reinterpret_cast<f32x4*>(p.psum + (int64_t)g * COUT + sidx * 32 + nt * 16 + 4 * g4) =
+                (f32x4){sums[nt][0], sums[nt][1], sums[nt][2], sums[nt][3]};
+        }
+      }
+    }
+  }
+}
+
+template <int CIN, int COUT, bool BF16>
+static int launch_wg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
+  constexpr int NW = 4;
+  constexpr int ES = BF16 ? 2 : 4;
+  const size_t lds = 2 * (size_t)(32 * COUT * ES) + NW * 28 * 16 * sizeof(int32_t);
+  static int wg_per_cu = 0;                              // resident workgroups per CU of this instantiation (constant)
+  if (!wg_per_cu) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_wg_kernel<CIN, COUT, BF16, NW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int nb = 0;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sconv_wg_kernel<CIN, COUT, BF16, NW>, NW * 64, lds));
+    wg_per_cu = std::max(nb, 1);
+  }
+  const int64_t ntask = cdiv(groups_hint, NW);
+  int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), (int64_t)256 * wg_per_cu);
+  grid = (grid + 7) / 8 * 8;
+  hipEvent_t* pev = prof_kernel_events();
+  if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
+    hipExtLaunchKernelGGL((sconv_wg_kernel<CIN, COUT, BF16, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, pev[0], pev[1], 0, a);
+    pev[0] = pev[1] = nullptr;
+  } else {
+    hipLaunchKernelGGL((sconv_wg_kernel<CIN, COUT, BF16, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
+  }
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ launcher
+template <int CIN, int COUT, bool BF16>
+static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
+  constexpr int D = BF16 ? 4 : 3;
+  constexpr int NS = COUT / 32;
+  const int64_t ntask = cdiv(groups_hint * NS, 4);
+  int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 2048);
+  grid = (grid + 7) / 8 * 8;
+  const size_t lds = 4 * 28 * 16 * sizeof(int32_t);
+  hipEvent_t* pev = prof_kernel_events();
+  if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
+    hipExtLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D>), dim3((unsigned)grid), dim3(256), lds, stream, pev[0], pev[1], 0, a);
+    pev[0] = pev[1] = nullptr;
+  } else {
+    hipLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+  }
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+bool sconv_rg_supported(int cin, int cout) {
+  auto ok = [](int c) { return c == 32 || c == 64 || c == 128 || c == 256; };
+  return ok(cin) && ok(cout);
+}
+
+// in: [n_in][cin]; rg: row-group tables of the map; Wp: pack_rg_weights(bf16 matching); groups_hint: host upper bound of
+// the groups in use (sizes the persistent grid only; the kernel reads the true count from rg.meta[0]).
+int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wp, int cin,
+                     int cout, int bf16, const float* scale, const float* shift, int relu, void* out, float* psum,
+                     hipStream_t stream, int variant) {
+  EGONN_REQUIRE(rg.built, EGONN_ERR_STATE, "sconv: row-group tables not built");
+  EGONN_REQUIRE(sconv_rg_supported(cin, cout), EGONN_ERR_INVALID, "sconv: channel plan %d->%d not supported (32/64/128/256)", cin, cout);
+  const uint64_t ib = (uint64_t)n_in_cap * cin * (bf16 ? 2 : 4);
+  EGONN_REQUIRE(ib < (1ull << 32) - (1ull << 20), EGONN_ERR_INVALID,
+                "sconv: input feature map of %lld rows exceeds the 4 GiB buffer-resource range", (long long)n_in_cap);
+  if (groups_hint <= 0) return EGONN_OK;
+  SconvArgs a;
+  a.in = in; a.snbr = rg.snbr; a.gmask = rg.gmask; a.perm = rg.perm; a.meta = rg.meta; a.Wp = Wp;
+  a.scale = scale; a.shift = shift; a.out = out; a.psum = psum;
+  a.in_bytes = (uint32_t)ib;
+  a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * (bf16 ? 2 : 4));
+  a.K = rg.K; a.relu = relu ? 1 : 0;
+#define EGONN_RG_CASE(CI, CO)                                                                    \
+  if (cin == CI && cout == CO)                                                                   \
+    return bf16 ? launch_wg<CI, CO, true>(a, groups_hint, stream) : launch_wg<CI, CO, false>(a, groups_hint, stream);
+#define EGONN_RG1_CASE(CI, CO)                                                                   \
+  if (variant == 1 && cin == CI && cout == CO)                                                   \
+    return bf16 ? launch_rg<CI, CO, true>(a, groups_hint, stream) : launch_rg<CI, CO, false>(a, groups_hint, stream);
+  EGONN_RG1_CASE(32, 32)      // per-wave variant (kept for A/B measurements: egonn_debug_set_naive_conv(ctx, 2))
+  EGONN_RG1_CASE(64, 64)
+  EGONN_RG1_CASE(128, 128)
+  EGONN_RG_CASE(32, 32)
+  EGONN_RG_CASE(32, 64)
+  EGONN_RG_CASE(64, 64)
+  EGONN_RG_CASE(64, 128)
+  EGONN_RG_CASE(128, 128)
+  EGONN_RG_CASE(64, 32)       // input gradients of the 32->64 / 64->128 layers (training)
+  EGONN_RG_CASE(128, 64)
+  EGONN_RG_CASE(256, 256)     // MinkLoc3D lateral / transposed convolutions (models/minkfpn.py:50-52)
+  EGONN_RG_CASE(128, 256)
+  EGONN_RG_CASE(256, 128)
+  EGONN_RG_CASE(64, 256)
+  EGONN_RG_CASE(256, 64)
+  EGONN_RG_CASE(32, 128)
+  EGONN_RG_CASE(128, 32)
+  EGONN_RG_CASE(32, 256)
+  EGONN_RG_CASE(256, 32)
+#undef EGONN_RG1_CASE
+#undef EGONN_RG_CASE
+  set_error("sconv: channel plan %d->%d has no instantiation", cin, cout);
+  return EGONN_ERR_INVALID;
+}
+
+int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, int cin, int cout, int bf16,
+              const float* scale, const float* shift, int relu, void* out, float* psum, float* scratch,
+              size_t scratch_floats, hipStream_t stream) {
+  Plan& P = ctx->plan;
+  EGONN_REQUIRE(kind >= 0 && kind <= 2, EGONN_ERR_INVALID, "sconv: map kind %d", kind);
+  const int lin = kind == 0 ? level : (kind == 1 ? level - 1 : level + 1);
+  EGONN_REQUIRE(level >= 0 && level < EGONN_NUM_LEVELS && lin >= 0 && lin < EGONN_NUM_LEVELS, EGONN_ERR_INVALID,
+                "sconv: level %d out of range for map kind %d", level, kind);
+  Level& V = P.lv[level];
+  if (V.n == 0) return EGONN_OK;
+  const int K = kind == 0 ? 27 : 8;
+  if (ctx->conv_variant == 3 || !sconv_rg_supported(cin, cout)) {
+    EGONN_REQUIRE(!bf16, EGONN_ERR_INVALID, "sconv: bf16 feature maps need a 32/64/128/256-channel plan (%d->%d)", cin, cout);
+    EGONN_REQUIRE(W, EGONN_ERR_INVALID, "sconv: the plain kernel needs the reference-layout kernel");
+    if (kind == 2 && level == 0) EGONN_TRY(ensure_level0_parent_table(ctx, stream));
+    const int32_t* nbr = kind == 0 ? V.nbr27 : (kind == 1 ? V.nbr8 : V.nbrT);
+    EGONN_REQUIRE(!psum, EGONN_ERR_INVALID, "sconv: group sums are produced by the MFMA kernel only");
+    return sconv_naive(reinterpret_cast<const float*>(in), nbr, W, scale, shift, relu, reinterpret_cast<float*>(out), V.n, K,
+                       cin, cout, stream);
+  }
+  EGONN_TRY(ensure_rowgroups(ctx, &kind, &level, 1, stream));
+  const RowGroups& rg = kind == 0 ? V.rg27 : (kind == 1 ? V.rg8 : V.rgT);
+  if (!Wp) {      // stand-alone operator call: pack into the caller's scratch
+    const size_t wn = (size_t)K * cin * cout;
+    EGONN_REQUIRE(W && scratch && scratch_floats >= wn, EGONN_ERR_STATE, "sconv: no scratch to pack the kernel into");
+    EGONN_TRY(pack_rg_weights(W, K, cin, cout, bf16, 0, 0, scratch, stream));
+    Wp = scratch;
+  }
+  return sconv_rg_forward(in, P.cap[lin], rg, rg.cap_groups, Wp, cin, cout, bf16, scale, shift, relu, out, psum, stream,
+                          ctx->conv_variant);
+}
+
+}  // namespace egonn

@@ -31,7 +31,8 @@ typedef struct egonn_model egonn_model;   /* EgoNN weights registered by state_d
 
 enum { EGONN_QUANT_CARTESIAN = 0, EGONN_QUANT_POLAR = 1 };
 enum { EGONN_FLAG_DISABLE_GLOBAL = 1, EGONN_FLAG_DISABLE_LOCAL = 2, EGONN_FLAG_IGNORE_KP_REGRESSOR = 4,
-       /* BASELINE configs[2]: sparse-conv MFMA operands rounded to bf16, fp32 accumulate, feature maps fp32 in HBM */
+       /* BASELINE configs[2]: feature maps and sparse-conv weights are bf16 in HBM (2 bytes per element), products
+        * accumulate in fp32 on v_mfma_f32_16x16x32_bf16; the dense heads, pooling and all outputs stay fp32 */
        EGONN_FLAG_BF16 = 8 };
 
 /* ------------------------------------------------------------------ lifecycle / errors */
@@ -39,11 +40,10 @@ enum { EGONN_FLAG_DISABLE_GLOBAL = 1, EGONN_FLAG_DISABLE_LOCAL = 2, EGONN_FLAG_I
 int egonn_ctx_create(egonn_ctx** ctx, int device, int coord_bits);
 void egonn_ctx_destroy(egonn_ctx* ctx);
 const char* egonn_last_error(void);
-/* debug / measurement only (tests, tools/bench_sconv.py): bit 0 = route sparse convolutions through the naive
- * (non-MFMA) HIP kernel; bit 8 = tuning word valid: bits 4-6 workgroup-split policy, bits 12-13 tile rows (0 = auto);
- * bits 16-18 = ablation of the MFMA kernel (weight loads / gathers return zeros without traffic, main loop skipped):
- * results are then WRONG on purpose.  Process-global, not thread-safe; never set by the product path. */
-int egonn_debug_set_naive_conv(int on);
+/* tests / measurements only: on = 1 routes this context's sparse convolutions through the plain one-thread-per-output
+ * HIP kernel (cross-check of the MFMA kernel), on = 2 through the per-wave MFMA variant (A/B timing); 0 = product
+ * kernel.  Never set by the product path. */
+int egonn_debug_set_naive_conv(egonn_ctx* ctx, int on);
 
 /* ------------------------------------------------------------------ coordinate plan
  * replaces ME.utils.sparse_quantize      datasets/quantization.py:42,83   (Cartesian/Polar quantizer __call__)
@@ -80,6 +80,16 @@ int egonn_conv(egonn_ctx* ctx, int level_in, int level_out, int kernel_size, con
 /* MinkowskiConvolutionTranspose(k=2,s=2) onto the cached finer map: models/minkgl.py:39,53. level_out = level_in-1 */
 int egonn_conv_transpose(egonn_ctx* ctx, int level_in, const float* in, int cin, const float* kernel, int cout,
                          float* out, void* stream);
+/* The operator behind the two calls above, with explicit map and precision.  map_kind 0: kernel_size 3 on level_out;
+ * 1: kernel_size 2 / stride 2 from level_out-1 into level_out; 2: transposed (k=2,s=2) from level_out+1 onto level_out.
+ * bf16 = 1: `in` and `out` are bf16 feature maps (BASELINE configs[2]); the fp32 kernel is rounded to bf16, products
+ * accumulate in fp32.  group_sums (nullable): (n_groups, cout) fp32 column sums of the stored output per group of 16
+ * rows (egonn_map_groups) — the conv2 epilogue form of MinkowskiGlobalPooling (layers/eca_block.py:16,26). */
+int egonn_sparse_conv(egonn_ctx* ctx, int map_kind, int level_out, const void* in, int cin, const float* kernel, int cout,
+                      int bf16, const float* scale, const float* shift, int relu, void* out, float* group_sums,
+                      void* stream);
+/* n_groups / first_group (HOST, B+1 entries, nullable) of a map's row groups.  [SYNC] */
+int egonn_map_groups(egonn_ctx* ctx, int map_kind, int level_out, int64_t* n_groups, int64_t* first_group, void* stream);
 /* MinkowskiGlobalAvgPooling: layers/eca_block.py:16, layers/pooling.py:80.  out (B,C) */
 int egonn_global_avg_pool(egonn_ctx* ctx, int level, const float* in, int channels, float* out, void* stream);
 

@@ -162,7 +162,7 @@ def test_conv_primitives_vs_oracle(gpu, naive):
     ctx = gpu._lib.Context()
     ctx.coords_set(torch.from_numpy(c4).cuda(), 2)
     rng = np.random.default_rng(1)
-    gpu._lib.load().egonn_debug_set_naive_conv(int(naive))
+    ctx.set_naive_conv(naive)
     try:
         def feats(level, c):
             """random features defined per coordinate; returns (oracle-order, hip-order) arrays"""
@@ -217,7 +217,7 @@ def test_conv_primitives_vs_oracle(gpu, naive):
         got = _np(ctx.global_avg_pool(2, torch.from_numpy(fh)))
         np.testing.assert_allclose(got, ops.global_avg_pool(fo, lv.coords[2], 2), rtol=1e-4, atol=1e-5)
     finally:
-        gpu._lib.load().egonn_debug_set_naive_conv(0)
+        ctx.set_naive_conv(False)
 
 
 def test_conv_known_answer_line(gpu):
