@@ -9,7 +9,7 @@ from .params import ModelParams
 from .quantization import CartesianQuantizer, PolarQuantizer, Quantizer
 from .model import MinkGL, MinkHead, MinkTrunk, model_factory, create_egonn_model
 from .minkloc import MinkFPN, MinkLoc, MinkLoc3D
-from .evaluator import DescriptorExtractor
+from .evaluator import DescriptorExtractor, GraphExtractor
 
 __all__ = ["ModelParams", "model_factory", "create_egonn_model", "MinkGL", "MinkHead", "MinkTrunk",
-           "CartesianQuantizer", "PolarQuantizer", "Quantizer", "DescriptorExtractor", "MinkFPN", "MinkLoc", "MinkLoc3D"]
+           "CartesianQuantizer", "PolarQuantizer", "Quantizer", "DescriptorExtractor", "GraphExtractor", "MinkFPN", "MinkLoc", "MinkLoc3D"]

@@ -25,6 +25,14 @@ _SIGS = [
     ("egonn_last_error", C.c_char_p, []),
     ("egonn_debug_set_naive_conv", C.c_int, [_P, C.c_int]),
     ("egonn_voxelize", C.c_int, [_P, _P, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
+    ("egonn_ctx_reserve", C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
+    ("egonn_voxelize_device", C.c_int, [_P, _P, C.c_int64, _P, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
+    ("egonn_plan_status", C.c_int, [_P, _P]),
+    ("egonn_level_capacity", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
+    ("egonn_graph_begin", C.c_int, [_P]),
+    ("egonn_graph_end", C.c_int, [_P, C.POINTER(_P)]),
+    ("egonn_graph_launch", C.c_int, [_P, _P]),
+    ("egonn_graph_destroy", None, [_P]),
     ("egonn_coords_set", C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     ("egonn_level_count", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
     ("egonn_level_batch_offsets", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
@@ -47,6 +55,7 @@ _SIGS = [
     ("egonn_forward", C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_float), C.c_int, _P, _P, _P, _P, _P]),
     ("egonn_forward_level_features", C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     ("egonn_select_keypoints", C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
+    ("egonn_topk_rows", C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     ("egonn_triplet_loss_scratch_floats", C.c_int64, [C.c_int]),
     ("egonn_triplet_loss", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
     ("egonn_dense", C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
@@ -164,6 +173,37 @@ class Context:
         with torch.cuda.device(self.device):
             check(self.lib.egonn_voxelize(self.h, points.data_ptr(), off, B, mode, st, _stream()))
         self.batch_size = B
+
+    def reserve(self, max_points: int, batch_size: int, level_capacity: Optional[Sequence[int]] = None):
+        """egonn_ctx_reserve: fixed capacities => later voxelize_device plans neither allocate nor synchronise."""
+        caps = None
+        if level_capacity is not None:
+            assert len(level_capacity) == 8
+            caps = (C.c_int64 * 8)(*[int(v) for v in level_capacity])
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_ctx_reserve(self.h, int(max_points), int(batch_size), caps))
+        self.batch_size = int(batch_size)
+
+    def voxelize_device(self, points: torch.Tensor, scan_offsets: torch.Tensor, batch_size: int, mode: int,
+                        step: Sequence[float]):
+        """points (n_rows,3) f32 and scan_offsets (B+1,) int64 both on the device; no host synchronisation."""
+        assert points.is_cuda and points.dtype == torch.float32 and points.is_contiguous() and points.shape[1] == 3
+        assert scan_offsets.is_cuda and scan_offsets.dtype == torch.int64 and scan_offsets.numel() == batch_size + 1
+        st = (C.c_float * 3)(*([float(s) for s in step] + [0.0, 0.0])[:3])
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_voxelize_device(self.h, points.data_ptr(), points.shape[0], scan_offsets.data_ptr(),
+                                                 int(batch_size), mode, st, _stream()))
+        self.batch_size = int(batch_size)
+
+    def plan_status(self):
+        """[SYNC] raises if the latest (replayed) plan left the coordinate range or the reserved capacities."""
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_plan_status(self.h, _stream()))
+
+    def level_capacity(self, level: int) -> int:
+        n = C.c_int64()
+        check(self.lib.egonn_level_capacity(self.h, level, C.byref(n)))
+        return n.value
 
     def coords_set(self, coords: torch.Tensor, batch_size: int):
         assert coords.is_cuda and coords.dtype == torch.int32 and coords.is_contiguous()

@@ -137,6 +137,10 @@ struct Level {
 
 struct Plan {
   bool valid = false;
+  bool built_reserved = false;   // built by egonn_voxelize_device: its structure (pointers, capacities) survives a failed batch
+  bool exact = false;         // lv[l].n / boff_host hold the true sizes (false: reserved plan not yet synchronised; n = capacity)
+  int64_t cap_points = 0;     // rows of the key buffers
+  int64_t* scan_off = nullptr;   // device copy of the scan offsets (voxelize plans)
   int batch = 0;              // B
   int coord_bits = 16;        // CB
   int64_t n_input = 0;        // rows/points handed in by the caller
@@ -171,15 +175,19 @@ struct Ctx {
   unsigned long long* dev_pairs = nullptr;   // [16] kernel-map pair counters: [0] conv0 k5, [l] k3 map of level l
   int device = 0;
   int coord_bits = 16;
-  int conv_variant = 0;       // tests / A-B measurements only (egonn_debug_set_naive_conv): 0 = product kernel, 1 = per-wave
-                              // MFMA variant, 3 = plain one-thread-per-output kernel
+  int conv_variant = 0;       // tests / A-B measurements only (egonn_debug_set_naive_conv): 0 = product choice, 1 = per-wave
+                              // MFMA kernel, 2 = workgroup-cooperative MFMA kernel, 3 = plain one-thread-per-output kernel
   Arena plan_arena;           // keys, maps (lives until the next plan)
   Arena work_arena;           // features & scratch of one forward
   Arena sort_arena;           // radix-sort scratch
   Plan plan;
   int32_t* host_counts = nullptr;    // pinned staging for the size query
   int32_t* dev_counts = nullptr;
-  int32_t* dev_flags = nullptr;      // [0] = out-of-range coordinate seen
+  int32_t* dev_flags = nullptr;      // bit 0 = out-of-range coordinate seen, bit 1 = batch larger than the reserved capacities
+  bool reserved = false;             // egonn_ctx_reserve: fixed capacities, plans neither allocate nor synchronise
+  int64_t reserve_points = 0;
+  int reserve_batch = 0;
+  int64_t reserve_cap[EGONN_MAX_LEVELS] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -207,13 +215,16 @@ int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, h
 // ------------------------------------------------------------------ sort.hip
 // LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits).  Result lands in (keys_out, vals_out).
 // Stable.  keys_in/vals_in are clobbered.  Scratch comes from ctx->sort_arena.
+// n_dev (nullable): device-resident element count (<= n); n then only sizes the grid and the scratch.
 int radix_sort_pairs(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
-                     int64_t n, int nbits, hipStream_t stream);
+                     int64_t n, int nbits, hipStream_t stream, const int64_t* n_dev = nullptr);
 size_t radix_sort_scratch_bytes(int64_t n);
 
 // ------------------------------------------------------------------ coords.hip
-int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets_host, int B, int mode,
-                     const float* step, hipStream_t stream);
+int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets, int64_t n_cap, int offsets_on_device,
+                     int B, int mode, const float* step, hipStream_t stream);
+int plan_reserve(Ctx* ctx, int64_t max_points, int B, const int64_t* level_caps);
+int plan_sync(Ctx* ctx, hipStream_t stream);      // [SYNC] host copy of the level sizes / error flags of a reserved plan
 int plan_from_coords(Ctx* ctx, const int32_t* coords, int64_t n, int B, hipStream_t stream);
 int plan_level_coords(Ctx* ctx, int level, int32_t* out, hipStream_t stream);
 int count_map_pairs(Ctx* ctx, hipStream_t stream);   // fills dev_pairs[1..7] from the k=3 tables (profiling only)

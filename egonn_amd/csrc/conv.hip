@@ -67,8 +67,9 @@ __global__ __launch_bounds__(256) void conv0_k5_kernel(const float* __restrict__
                                                         const int32_t* __restrict__ g0,         // level-2 block of row
                                                         const uint64_t* __restrict__ t2m,       // [n2][27] masks
                                                         const int32_t* __restrict__ t2s,        // [n2][27] first rows
-                                                        int32_t n2, int32_t nvox,
-                                                        int32_t ntiles, const float* __restrict__ W,   // [125][32]
+                                                        const int32_t* __restrict__ counts,     // device rows per level
+                                                        int32_t cap2, int32_t cap0,             // capacities (grid sizing)
+                                                        const float* __restrict__ W,            // [125][32]
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int relu,
                                                         void* __restrict__ out_v,
@@ -80,6 +81,9 @@ __global__ __launch_bounds__(256) void conv0_k5_kernel(const float* __restrict__
   __shared__ uint16_t s_lut[64 * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g4 = lane >> 4;
+  const int32_t nvox = min(__builtin_amdgcn_readfirstlane(counts[0]), cap0);
+  const int32_t n2 = min(__builtin_amdgcn_readfirstlane(counts[2]), cap2);
+  const int32_t ntiles = (nvox + 15) >> 4;
   for (int e = tid; e < 64 * 128 / 2; e += 256)       // precomputed table (conv0_lut_host), 16 KB, coalesced
     reinterpret_cast<uint32_t*>(s_lut)[e] = reinterpret_cast<const uint32_t*>(lut)[e];
   float breg[2][32];
@@ -220,25 +224,29 @@ static void conv0_lut_host(uint16_t* lut) {
     }
 }
 
+int conv0_lut_init(Ctx* ctx) {
+  if (ctx->conv0_lut) return EGONN_OK;
+  std::vector<uint16_t> h(64 * 128);
+  conv0_lut_host(h.data());
+  HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->conv0_lut), h.size() * sizeof(uint16_t)));
+  HIP_CHECK(hipMemcpy(ctx->conv0_lut, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  return EGONN_OK;
+}
+
 int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, const float* scale,
                      const float* shift, int relu, void* out, int out_bf16, hipStream_t stream) {
   const Plan& P = ctx->plan;
-  if (!ctx->conv0_lut) {
-    std::vector<uint16_t> h(64 * 128);
-    conv0_lut_host(h.data());
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->conv0_lut), h.size() * sizeof(uint16_t)));
-    HIP_CHECK(hipMemcpy(ctx->conv0_lut, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-  }
+  EGONN_TRY(conv0_lut_init(ctx));
   EGONN_REQUIRE(cout == COUT0, EGONN_ERR_INVALID, "conv0: %d output channels not supported (expected %d)", cout, COUT0);
   const Level& V = P.lv[0];
   const Level& B = P.lv[2];
-  if (V.n == 0) return EGONN_OK;
-  const int32_t ntiles = (int32_t)cdiv(V.n, 16);
+  if (P.cap[0] == 0) return EGONN_OK;
+  const int32_t ntiles = (int32_t)cdiv(P.cap[0], 16);
   const unsigned grid = (unsigned)std::min<int64_t>(cdiv(ntiles, 4), 1536);
   EGONN_REQUIRE(P.g0 && P.t2m && P.t2s, EGONN_ERR_STATE, "conv0: plan has no block-neighbourhood table");
 #define EGONN_CONV0_LAUNCH(U, OB)                                                                                      \
   hipLaunchKernelGGL((conv0_k5_kernel<U, OB>), dim3(grid), dim3(256), 0, stream, feat, V.keys, P.g0, P.t2m, P.t2s,       \
-                     (int32_t)B.n, (int32_t)V.n, ntiles, W, scale, shift, relu, out, ctx->conv0_lut)
+                     ctx->dev_counts, (int32_t)P.cap[2], (int32_t)P.cap[0], W, scale, shift, relu, out, ctx->conv0_lut)
   if (feat) { if (out_bf16) EGONN_CONV0_LAUNCH(false, true); else EGONN_CONV0_LAUNCH(false, false); }
   else      { if (out_bf16) EGONN_CONV0_LAUNCH(true, true); else EGONN_CONV0_LAUNCH(true, false); }      // unit features
 #undef EGONN_CONV0_LAUNCH

@@ -11,6 +11,7 @@
 // exact grids.
 #include "common.h"
 
+#include <algorithm>
 #include <stdarg.h>
 
 namespace egonn {
@@ -122,11 +123,14 @@ __device__ static inline bool encode_key(int32_t b, int32_t cx, int32_t cy, int3
   return ok;
 }
 
-__global__ void points_to_keys_kernel(const float* __restrict__ pts, int64_t n, const int64_t* __restrict__ scan_off,
+// n_cap sizes the grid; the true point count is scan_off[B] (device memory: capturable plans never tell the host)
+__global__ void points_to_keys_kernel(const float* __restrict__ pts, int64_t n_cap, const int64_t* __restrict__ scan_off,
                                       int B, QuantParams qp, int cb, uint64_t* __restrict__ keys,
                                       uint32_t* __restrict__ vals, int32_t* __restrict__ flags) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const int64_t nn = scan_off[B];
+  if (i == 0 && nn > n_cap) atomicOr(flags, 2);         // more points than the plan was reserved for
+  if (i >= (nn < n_cap ? nn : n_cap)) return;
   // sample index = last b with scan_off[b] <= i
   int lo = 0, hi = B;   // invariant: scan_off[lo] <= i < scan_off[hi]
   while (hi - lo > 1) {
@@ -177,9 +181,16 @@ __device__ static inline int head_levels(const uint64_t* __restrict__ keys, int6
   return (t >= NL - 1) ? NL : t + 1;
 }
 
-__global__ __launch_bounds__(PYR_BLOCK) void pyramid_count_kernel(const uint64_t* __restrict__ keys, int64_t n,
+__device__ static inline int64_t clip_count(int64_t cap, const int64_t* __restrict__ n_dev) {
+  if (!n_dev) return cap;
+  const int64_t v = *n_dev;
+  return v < cap ? v : cap;
+}
+__global__ __launch_bounds__(PYR_BLOCK) void pyramid_count_kernel(const uint64_t* __restrict__ keys, int64_t n_cap,
+                                                                  const int64_t* __restrict__ n_dev,
                                                                   int32_t* __restrict__ tilecnt) {
   __shared__ int32_t cnt[PYR_BLOCK / 64][NL];
+  const int64_t n = clip_count(n_cap, n_dev);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t wbase = (int64_t)blockIdx.x * PYR_TILE + (int64_t)wave * 64 * PYR_ROUNDS;
   int32_t c[NL];
@@ -209,14 +220,18 @@ struct PyramidOut {
   int32_t* cstart[NL];
   int32_t* boff[EGONN_NUM_LEVELS];
   int32_t* perm0;
-  int32_t* counts;    // [NL] rows per level, [NL] = batch size seen (max batch index + 1)
+  int32_t* counts;    // [NL] rows per level, [NL] = batch size seen (max batch index + 1), [NL+1] = input rows
+  int32_t* flags;     // bit 1: a level has more rows than its capacity
+  int32_t cap[NL];    // row capacity of every level (maps and workspaces are sized for it)
 };
 
 __global__ __launch_bounds__(PYR_BLOCK) void pyramid_apply_kernel(const uint64_t* __restrict__ keys,
-                                                                  const uint32_t* __restrict__ vals, int64_t n,
+                                                                  const uint32_t* __restrict__ vals, int64_t n_cap,
+                                                                  const int64_t* __restrict__ n_dev,
                                                                   const int32_t* __restrict__ tilecnt, int ntiles,
                                                                   int cb, int B, PyramidOut out) {
   __shared__ int32_t red[PYR_BLOCK / 64][NL];
+  const int64_t n = clip_count(n_cap, n_dev);
   __shared__ int32_t tilebase[NL];
   __shared__ int32_t wavecnt[PYR_BLOCK / 64][NL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -318,6 +333,7 @@ __global__ __launch_bounds__(PYR_BLOCK) void pyramid_apply_kernel(const uint64_t
       for (int l = 0; l < NL; ++l) {
         const int32_t total = excl[l] + (h > l ? 1 : 0);
         out.counts[l] = total;
+        if (total > out.cap[l]) atomicOr(out.flags, 2);
         if (l >= 1) {
           const int32_t below = excl[l - 1] + (h > l - 1 ? 1 : 0);
           out.cstart[l][total] = below;
@@ -327,6 +343,7 @@ __global__ __launch_bounds__(PYR_BLOCK) void pyramid_apply_kernel(const uint64_t
         }
       }
       out.counts[NL] = blast + 1;
+      out.counts[NL + 1] = (int32_t)n;
     }
   }
 }
@@ -338,9 +355,14 @@ struct MaskArgs {
   const uint64_t* keys[NL];       // keys of level L
   uint64_t* mask[NL];
   int32_t* bstart[NL];
-  int32_t n[NL];
-  int32_t prefix[NL + 1];         // prefix over levels 2..NL-1 of n[L]
+  const int32_t* counts;          // device row counts per level
+  int32_t prefix[NL + 1];         // prefix over levels 2..NL-1 of the level capacities (grid layout)
 };
+
+__device__ static inline int32_t level_rows(const int32_t* __restrict__ counts, int l, int32_t cap) {
+  const int32_t v = counts[l];
+  return v < cap ? v : cap;
+}
 
 __global__ void block_mask_kernel(MaskArgs a) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -348,6 +370,7 @@ __global__ void block_mask_kernel(MaskArgs a) {
   int L = 2;
   while (L < NL - 1 && t >= a.prefix[L + 1]) ++L;
   const int32_t j = (int32_t)(t - a.prefix[L]);
+  if (j >= level_rows(a.counts, L, a.prefix[L + 1] - a.prefix[L])) return;
   const int32_t* cs1 = a.cstartL[L];
   const int32_t* cs2 = a.cstartL[L - 1];
   const int32_t s = cs2[cs1[j]];
@@ -391,8 +414,10 @@ __device__ static inline int32_t lookup_local(const uint64_t* nbm, const int32_t
 // Row adjacency by direct search: adj[i][s] = row of the same-level voxel at offset s (27 slots, x fastest), -1 =
 // absent.  Used for the two top (virtual) levels only, where N is tiny; every level below derives its table
 // from the table two levels up (nbr27_kernel), so no level with many rows ever binary-searches.
-__global__ void adj27_search_kernel(const uint64_t* __restrict__ keys, int32_t n, int cbL, int32_t* __restrict__ adj) {
+__global__ void adj27_search_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ counts, int level,
+                                    int32_t cap, int cbL, int32_t* __restrict__ adj) {
   const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t n = level_rows(counts, level, cap);
   if (t >= n * 27) return;
   const int32_t i = t / 27, sl = t - i * 27;
   const uint64_t key = keys[i];
@@ -414,12 +439,14 @@ __global__ void adj27_search_kernel(const uint64_t* __restrict__ keys, int32_t n
 __global__ __launch_bounds__(256) void nbr27_kernel(const uint64_t* __restrict__ vkeys,      // level l
                                                      const int32_t* __restrict__ badj,        // [nblocks][27] level l+2
                                                      const uint64_t* __restrict__ bmask,
-                                                     const int32_t* __restrict__ bstart, int32_t nblocks,
-                                                     int32_t nvox, int32_t* __restrict__ nbr) {
+                                                     const int32_t* __restrict__ bstart,
+                                                     const int32_t* __restrict__ counts, int level, int32_t cap_blocks,
+                                                     int32_t cap_vox, int32_t* __restrict__ nbr) {
   __shared__ uint64_t s_m[4][27];
   __shared__ int32_t s_s[4][27];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int32_t j = blockIdx.x * 4 + wave;
+  const int32_t nblocks = level_rows(counts, level + 2, cap_blocks), nvox = level_rows(counts, level, cap_vox);
   if (j >= nblocks) return;
   if (lane < 27) {
     const int32_t idx = badj[(int64_t)j * 27 + lane];
@@ -492,16 +519,16 @@ int count_map_pairs(Ctx* ctx, hipStream_t stream) {
 }
 
 // first-layer helpers: level-2 block of every level-0 row, and per block the (mask, first row) of its 27 neighbours
-__global__ void grandparent_kernel(const int32_t* __restrict__ parent0, const int32_t* __restrict__ parent1, int32_t n,
-                                   int32_t* __restrict__ g0) {
+__global__ void grandparent_kernel(const int32_t* __restrict__ parent0, const int32_t* __restrict__ parent1,
+                                   const int32_t* __restrict__ counts, int32_t cap, int32_t* __restrict__ g0) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) g0[i] = parent1[parent0[i]];
+  if (i < level_rows(counts, 0, cap)) g0[i] = parent1[parent0[i]];
 }
 __global__ void blk27_kernel(const int32_t* __restrict__ badj, const uint64_t* __restrict__ bmask,
-                             const int32_t* __restrict__ bstart, int32_t n27, uint64_t* __restrict__ t2m,
-                             int32_t* __restrict__ t2s) {
+                             const int32_t* __restrict__ bstart, const int32_t* __restrict__ counts, int32_t cap2,
+                             uint64_t* __restrict__ t2m, int32_t* __restrict__ t2s) {
   const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n27) return;
+  if (t >= level_rows(counts, 2, cap2) * 27) return;
   const int32_t a = badj[t];
   t2m[t] = a >= 0 ? bmask[a] : 0ull;
   t2s[t] = a >= 0 ? bstart[a] : 0;
@@ -525,10 +552,10 @@ __global__ void nbr8_kernel(const int32_t* __restrict__ cstart, const uint64_t* 
   o[1] = make_int4(r[4], r[5], r[6], r[7]);
 }
 
-__global__ void nbrT_kernel(const int32_t* __restrict__ parent, const uint64_t* __restrict__ keys, int32_t n,
-                            int32_t* __restrict__ nbrT) {
+__global__ void nbrT_kernel(const int32_t* __restrict__ parent, const uint64_t* __restrict__ keys,
+                            const int32_t* __restrict__ counts, int32_t cap, int32_t* __restrict__ nbrT) {
   const int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+  if (c >= level_rows(counts, 0, cap)) return;
   const int slot = (int)(keys[c] & 7);
   const int32_t p = parent[c];
   int32_t r[8];
@@ -547,7 +574,8 @@ struct Nbr8TArgs {
   const uint64_t* keys[EGONN_NUM_LEVELS];
   int32_t* nbr8[EGONN_NUM_LEVELS];
   int32_t* nbrT[EGONN_NUM_LEVELS];
-  int32_t prefix[EGONN_NUM_LEVELS + 1];       // prefix over levels 1..7 of their row counts; [0] unused
+  const int32_t* counts;                      // device row counts per level
+  int32_t prefix[EGONN_NUM_LEVELS + 1];       // prefix over levels 1..7 of their row capacities; [0] unused
 };
 __global__ void nbr8T_all_kernel(Nbr8TArgs a) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -555,6 +583,7 @@ __global__ void nbr8T_all_kernel(Nbr8TArgs a) {
   int l = 1;
   while (l < EGONN_NUM_LEVELS - 1 && t >= a.prefix[l + 1]) ++l;
   const int32_t p = (int32_t)(t - a.prefix[l]);
+  if (p >= level_rows(a.counts, l, a.prefix[l + 1] - a.prefix[l])) return;
   {
     int32_t r[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
     const int32_t s = a.cstart[l][p], e = a.cstart[l][p + 1];
@@ -604,12 +633,59 @@ static int batch_bits(int B) {
   return b < 1 ? 1 : b;
 }
 
+// Copies the per-level row counts, the range/overflow flags and the per-sample offsets to the host (the plan's only
+// host synchronisation).  Eager plans call it at build time; reserved (capturable) plans only when the host asks for a
+// size (egonn_level_count, output allocation) or for the error state.
+int plan_sync(Ctx* ctx, hipStream_t stream) {
+  Plan& P = ctx->plan;
+  EGONN_REQUIRE(P.valid, EGONN_ERR_STATE, "no coordinate plan");
+  if (P.exact) return EGONN_OK;
+  const int B = P.batch, cb = P.coord_bits;
+  HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ctx->dev_counts, sizeof(int32_t) * 17, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipMemcpyAsync(ctx->host_counts + 32, P.lv[0].boff, sizeof(int32_t) * EGONN_NUM_LEVELS * (B + 1),
+                           hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  const int32_t flags = ctx->host_counts[16];
+  if (flags & 1) {
+    P.valid = false;
+    set_error("coordinate outside the +-2^%d voxel range of coord_bits=%d (or non-finite point / batch index out of range)",
+              cb - 1, cb);
+    return EGONN_ERR_RANGE;
+  }
+  if (ctx->host_counts[NL] > B) {
+    P.valid = false;
+    set_error("batch index %d >= batch size %d", ctx->host_counts[NL] - 1, B);
+    return EGONN_ERR_RANGE;
+  }
+  if (flags & 2) {
+    P.valid = false;
+    set_error("the batch does not fit the reserved plan (points %d / capacity %lld; level rows %d %d %d %d %d %d %d %d / "
+              "capacities %lld %lld %lld %lld %lld %lld %lld %lld): call egonn_ctx_reserve with larger capacities",
+              ctx->host_counts[NL + 1], (long long)P.cap_points, ctx->host_counts[0], ctx->host_counts[1], ctx->host_counts[2],
+              ctx->host_counts[3], ctx->host_counts[4], ctx->host_counts[5], ctx->host_counts[6], ctx->host_counts[7],
+              (long long)P.cap[0], (long long)P.cap[1], (long long)P.cap[2], (long long)P.cap[3], (long long)P.cap[4],
+              (long long)P.cap[5], (long long)P.cap[6], (long long)P.cap[7]);
+    return EGONN_ERR_RANGE;
+  }
+  for (int l = 0; l < NL; ++l) P.lv[l].n = ctx->host_counts[l];
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) {
+    const int32_t* src = ctx->host_counts + 32 + (size_t)l * (B + 1);
+    P.boff_host[l].assign(src, src + B + 1);
+  }
+  P.n_input = ctx->host_counts[NL + 1];
+  P.exact = true;
+  return EGONN_OK;
+}
+
+// n_cap: rows the key buffers hold; n_dev (nullable): device-resident row count.  reserved = false: the level capacities
+// are the exact row counts (one host sync right after the pyramid); true: ctx->reserve_cap[] (no host sync at all).
 static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* vals_raw, uint64_t* keys_sorted,
-                                        uint32_t* vals_sorted, int64_t n, int B, hipStream_t stream) {
+                                        uint32_t* vals_sorted, int64_t n, const int64_t* n_dev, int B, bool reserved,
+                                        hipStream_t stream) {
   Plan& P = ctx->plan;
   const int cb = ctx->coord_bits;
   Arena& A = ctx->plan_arena;
-  EGONN_TRY(radix_sort_pairs(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, 3 * cb + batch_bits(B), stream));
+  EGONN_TRY(radix_sort_pairs(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, 3 * cb + batch_bits(B), stream, n_dev));
 
   const int ntiles = (int)cdiv(n, PYR_TILE);
   int32_t* tilecnt = A.alloc<int32_t>((size_t)ntiles * NL);
@@ -622,37 +698,38 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
     P.lv[l].parent = po.parent[l] = A.alloc<int32_t>(n);
     P.lv[l].cstart = po.cstart[l] = A.alloc<int32_t>(n + 1);
     EGONN_REQUIRE(po.keys[l] && po.parent[l] && po.cstart[l], EGONN_ERR_STATE, "plan arena too small");
+    // capacity of the level: everything downstream (maps, workspaces, grids) is sized for it
+    P.cap[l] = reserved ? std::min<int64_t>(ctx->reserve_cap[l], n) : n;
+    po.cap[l] = (int32_t)P.cap[l];
   }
   int32_t* boff_all = A.alloc<int32_t>((size_t)EGONN_NUM_LEVELS * (B + 1));   // contiguous: one D2H copy
   EGONN_REQUIRE(boff_all, EGONN_ERR_STATE, "plan arena too small");
   for (int l = 0; l < EGONN_NUM_LEVELS; ++l) P.lv[l].boff = po.boff[l] = boff_all + (size_t)l * (B + 1);
   P.perm0 = po.perm0 = A.alloc<int32_t>(n);
   po.counts = ctx->dev_counts;
+  po.flags = ctx->dev_flags;
   EGONN_REQUIRE(tilecnt && po.perm0, EGONN_ERR_STATE, "plan arena too small");
 
-  hipLaunchKernelGGL(pyramid_count_kernel, dim3(ntiles), dim3(PYR_BLOCK), 0, stream, keys_sorted, n, tilecnt);
-  hipLaunchKernelGGL(pyramid_apply_kernel, dim3(ntiles), dim3(PYR_BLOCK), 0, stream, keys_sorted, vals_sorted, n,
+  hipLaunchKernelGGL(pyramid_count_kernel, dim3(ntiles), dim3(PYR_BLOCK), 0, stream, keys_sorted, n, n_dev, tilecnt);
+  hipLaunchKernelGGL(pyramid_apply_kernel, dim3(ntiles), dim3(PYR_BLOCK), 0, stream, keys_sorted, vals_sorted, n, n_dev,
                      tilecnt, ntiles, cb, B, po);
   HIP_CHECK(hipGetLastError());
-
-  // ---- the size query (single host sync of the plan): counts, range flag, per-sample offsets
-  HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ctx->dev_counts, sizeof(int32_t) * 17, hipMemcpyDeviceToHost, stream));
-  HIP_CHECK(hipMemcpyAsync(ctx->host_counts + 32, boff_all, sizeof(int32_t) * EGONN_NUM_LEVELS * (B + 1),
-                           hipMemcpyDeviceToHost, stream));
-  HIP_CHECK(hipStreamSynchronize(stream));
-  EGONN_REQUIRE(ctx->host_counts[16] == 0, EGONN_ERR_RANGE,
-                "coordinate outside the +-2^%d voxel range of coord_bits=%d (or non-finite point / batch index "
-                "out of range)", cb - 1, cb);
-  EGONN_REQUIRE(ctx->host_counts[NL] <= B, EGONN_ERR_RANGE, "batch index %d >= batch size %d",
-                ctx->host_counts[NL] - 1, B);
-  for (int l = 0; l < NL; ++l) P.lv[l].n = P.cap[l] = ctx->host_counts[l];
-  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) {
-    const int32_t* src = ctx->host_counts + 32 + (size_t)l * (B + 1);
-    P.boff_host[l].assign(src, src + B + 1);
-  }
   P.batch = B;
   P.coord_bits = cb;
   P.n_input = n;
+  P.cap_points = n;
+  P.valid = true;
+  P.exact = false;
+  P.built_reserved = reserved;
+  if (!reserved) {
+    // ---- the size query (single host sync of an eager plan): counts, range flag, per-sample offsets
+    EGONN_TRY(plan_sync(ctx, stream));
+    for (int l = 0; l < NL; ++l) P.cap[l] = P.lv[l].n;
+  } else {
+    for (int l = 0; l < NL; ++l) P.lv[l].n = P.cap[l];      // upper bounds until somebody asks (plan_sync)
+  }
+  P.valid = false;                                           // until the maps are enqueued
+  const int32_t* counts = ctx->dev_counts;
 
   // ---- masks for levels 2..9 (blocks of levels 0..7)
   MaskArgs ma;
@@ -660,17 +737,17 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
   for (int L = 0; L < NL; ++L) {
     ma.cstartL[L] = P.lv[L].cstart;
     ma.keys[L] = P.lv[L].keys;
-    ma.n[L] = (int32_t)P.lv[L].n;
     ma.mask[L] = nullptr;
     ma.bstart[L] = nullptr;
     ma.prefix[L] = 0;
   }
+  ma.counts = counts;
   for (int L = 2; L < NL; ++L) {
-    P.lv[L].mask = ma.mask[L] = A.alloc<uint64_t>(P.lv[L].n);
-    P.lv[L].bstart = ma.bstart[L] = A.alloc<int32_t>(P.lv[L].n);
+    P.lv[L].mask = ma.mask[L] = A.alloc<uint64_t>(P.cap[L]);
+    P.lv[L].bstart = ma.bstart[L] = A.alloc<int32_t>(P.cap[L]);
     EGONN_REQUIRE(ma.mask[L] && ma.bstart[L], EGONN_ERR_STATE, "plan arena too small");
     ma.prefix[L] = pre;
-    pre += (int32_t)P.lv[L].n;
+    pre += (int32_t)P.cap[L];
   }
   ma.prefix[NL] = pre;
   if (pre > 0) hipLaunchKernelGGL(block_mask_kernel, dim3((unsigned)cdiv(pre, 256)), dim3(256), 0, stream, ma);
@@ -679,38 +756,39 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
   //      table of the level two above (which is the adjacency of its 4x4x4 blocks)
   for (int l = NL - 1; l >= 1; --l) {
     Level& V = P.lv[l];
-    const int32_t nv = (int32_t)V.n;
+    const int32_t nv = (int32_t)P.cap[l];
     V.nbr27 = A.alloc<int32_t>((size_t)nv * 27);
     EGONN_REQUIRE(V.nbr27, EGONN_ERR_STATE, "plan arena too small");
     if (nv == 0) continue;
     if (l + 2 >= NL) {
       hipLaunchKernelGGL(adj27_search_kernel, dim3((unsigned)cdiv((int64_t)nv * 27, 256)), dim3(256), 0, stream, V.keys,
-                         nv, cb - l, V.nbr27);
+                         counts, l, nv, cb - l, V.nbr27);
     } else {
       const Level& Bk = P.lv[l + 2];
-      hipLaunchKernelGGL(nbr27_kernel, dim3((unsigned)cdiv(Bk.n, 4)), dim3(256), 0, stream, V.keys, Bk.nbr27, Bk.mask,
-                         Bk.bstart, (int32_t)Bk.n, nv, V.nbr27);
+      hipLaunchKernelGGL(nbr27_kernel, dim3((unsigned)cdiv(P.cap[l + 2], 4)), dim3(256), 0, stream, V.keys, Bk.nbr27, Bk.mask,
+                         Bk.bstart, counts, l, (int32_t)P.cap[l + 2], nv, V.nbr27);
     }
   }
   {   // first-layer (k=5) helpers
-    const int32_t n0 = (int32_t)P.lv[0].n, n2 = (int32_t)P.lv[2].n;
+    const int32_t n0 = (int32_t)P.cap[0], n2 = (int32_t)P.cap[2];
     P.g0 = A.alloc<int32_t>(n0);
     P.t2m = A.alloc<uint64_t>((size_t)n2 * 27);
     P.t2s = A.alloc<int32_t>((size_t)n2 * 27);
     EGONN_REQUIRE(P.g0 && P.t2m && P.t2s, EGONN_ERR_STATE, "plan arena too small");
     if (n0 > 0) {
       hipLaunchKernelGGL(grandparent_kernel, dim3((unsigned)cdiv(n0, 256)), dim3(256), 0, stream, P.lv[0].parent,
-                         P.lv[1].parent, n0, P.g0);
+                         P.lv[1].parent, counts, n0, P.g0);
       hipLaunchKernelGGL(blk27_kernel, dim3((unsigned)cdiv((int64_t)n2 * 27, 256)), dim3(256), 0, stream, P.lv[2].nbr27,
-                         P.lv[2].mask, P.lv[2].bstart, n2 * 27, P.t2m, P.t2s);
+                         P.lv[2].mask, P.lv[2].bstart, counts, n2, P.t2m, P.t2s);
     }
   }
   {
     Nbr8TArgs na;
     na.prefix[0] = na.prefix[1] = 0;
+    na.counts = counts;
     for (int l = 1; l < EGONN_NUM_LEVELS; ++l) {
       Level& V = P.lv[l];
-      const int32_t nv = (int32_t)V.n;
+      const int32_t nv = (int32_t)P.cap[l];
       V.nbr8 = A.alloc<int32_t>((size_t)nv * 8);
       V.nbrT = A.alloc<int32_t>((size_t)nv * 8);
       EGONN_REQUIRE(V.nbr8 && V.nbrT, EGONN_ERR_STATE, "plan arena too small");
@@ -737,11 +815,11 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
 int ensure_level0_parent_table(Ctx* ctx, hipStream_t stream) {
   Plan& P = ctx->plan;
   Level& V = P.lv[0];
-  if (V.nbrT || V.n == 0) return EGONN_OK;
-  V.nbrT = ctx->plan_arena.alloc<int32_t>((size_t)V.n * 8);
+  if (V.nbrT || P.cap[0] == 0) return EGONN_OK;
+  V.nbrT = ctx->plan_arena.alloc<int32_t>((size_t)P.cap[0] * 8);
   EGONN_REQUIRE(V.nbrT, EGONN_ERR_STATE, "plan arena too small for the level-0 parent table");
-  hipLaunchKernelGGL(nbrT_kernel, dim3((unsigned)cdiv(V.n, 256)), dim3(256), 0, stream, V.parent, V.keys, (int32_t)V.n,
-                     V.nbrT);
+  hipLaunchKernelGGL(nbrT_kernel, dim3((unsigned)cdiv(P.cap[0], 256)), dim3(256), 0, stream, V.parent, V.keys,
+                     ctx->dev_counts, (int32_t)P.cap[0], V.nbrT);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
@@ -801,16 +879,26 @@ static size_t plan_arena_bytes(int64_t n, int B) {
          (1 << 20);
 }
 
-int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets_host, int B, int mode,
-                     const float* step, hipStream_t stream) {
+// scan_offsets: HOST (B+1) when offsets_on_device == 0 (eager plan: exact capacities, one host sync), DEVICE int64 (B+1)
+// otherwise (reserved plan: capacities from egonn_ctx_reserve, no host sync, capturable; n_cap = rows of `points`).
+int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets, int64_t n_cap, int offsets_on_device,
+                     int B, int mode, const float* step, hipStream_t stream) {
   ctx->plan.valid = false;
   EGONN_REQUIRE(B >= 1 && B <= EGONN_MAX_BATCH, EGONN_ERR_INVALID, "batch size %d outside [1,%d]", B, EGONN_MAX_BATCH);
-  const int64_t n = scan_offsets_host[B];
-  EGONN_REQUIRE(scan_offsets_host[0] == 0 && n >= 1, EGONN_ERR_INVALID, "empty input (n=%lld points)", (long long)n);
-  for (int b = 0; b < B; ++b)
-    EGONN_REQUIRE(scan_offsets_host[b] <= scan_offsets_host[b + 1], EGONN_ERR_INVALID, "scan offsets not monotone");
   EGONN_REQUIRE(mode == 0 || mode == 1, EGONN_ERR_INVALID, "unknown quantiser mode %d", mode);
-  EGONN_TRY(ctx->plan_arena.ensure(plan_arena_bytes(n, B)));
+  int64_t n;
+  if (!offsets_on_device) {
+    n = scan_offsets[B];
+    EGONN_REQUIRE(scan_offsets[0] == 0 && n >= 1, EGONN_ERR_INVALID, "empty input (n=%lld points)", (long long)n);
+    for (int b = 0; b < B; ++b)
+      EGONN_REQUIRE(scan_offsets[b] <= scan_offsets[b + 1], EGONN_ERR_INVALID, "scan offsets not monotone");
+    EGONN_TRY(ctx->plan_arena.ensure(plan_arena_bytes(n, B)));
+  } else {
+    n = n_cap;
+    EGONN_REQUIRE(ctx->reserved && n >= 1 && n <= ctx->reserve_points && B == ctx->reserve_batch, EGONN_ERR_STATE,
+                  "device-offset plans need egonn_ctx_reserve (points %lld / reserved %lld, batch %d / %d)", (long long)n,
+                  (long long)ctx->reserve_points, B, ctx->reserve_batch);
+  }
   Arena& A = ctx->plan_arena;
   A.reset();
   uint64_t* k0 = A.alloc<uint64_t>(n);
@@ -819,12 +907,20 @@ int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets_
   uint32_t* v1 = A.alloc<uint32_t>(n);
   int64_t* doff = A.alloc<int64_t>(B + 1);
   EGONN_REQUIRE(k0 && k1 && v0 && v1 && doff, EGONN_ERR_STATE, "plan arena too small");
-  HIP_CHECK(hipMemcpyAsync(doff, scan_offsets_host, sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice, stream));
+  if (!offsets_on_device) {
+    // pageable caller memory -> the context's pinned staging buffer -> device (the caller may reuse its array at once)
+    int64_t* stage = reinterpret_cast<int64_t*>(ctx->host_counts + 32 + (size_t)EGONN_NUM_LEVELS * (EGONN_MAX_BATCH + 1));
+    memcpy(stage, scan_offsets, sizeof(int64_t) * (B + 1));
+    HIP_CHECK(hipMemcpyAsync(doff, stage, sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice, stream));
+  } else {
+    HIP_CHECK(hipMemcpyAsync(doff, scan_offsets, sizeof(int64_t) * (B + 1), hipMemcpyDeviceToDevice, stream));
+  }
+  ctx->plan.scan_off = doff;
   HIP_CHECK(hipMemsetAsync(ctx->dev_flags, 0, sizeof(int32_t), stream));
   QuantParams qp{mode, step[0], mode ? step[1] : step[0], mode ? step[2] : step[0]};
   hipLaunchKernelGGL(points_to_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, points, n, doff, B, qp,
                      ctx->coord_bits, k0, v0, ctx->dev_flags);
-  return build_plan_from_sorted_input(ctx, k0, v0, k1, v1, n, B, stream);
+  return build_plan_from_sorted_input(ctx, k0, v0, k1, v1, n, doff + B, B, offsets_on_device != 0, stream);
 }
 
 int plan_from_coords(Ctx* ctx, const int32_t* coords, int64_t n, int B, hipStream_t stream) {
@@ -839,15 +935,35 @@ int plan_from_coords(Ctx* ctx, const int32_t* coords, int64_t n, int B, hipStrea
   uint32_t* v0 = A.alloc<uint32_t>(n);
   uint32_t* v1 = A.alloc<uint32_t>(n);
   EGONN_REQUIRE(k0 && k1 && v0 && v1, EGONN_ERR_STATE, "plan arena too small");
+  ctx->plan.scan_off = nullptr;
   HIP_CHECK(hipMemsetAsync(ctx->dev_flags, 0, sizeof(int32_t), stream));
   hipLaunchKernelGGL(coords_to_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, coords, n,
                      ctx->coord_bits, B, k0, v0, ctx->dev_flags);
-  return build_plan_from_sorted_input(ctx, k0, v0, k1, v1, n, B, stream);
+  return build_plan_from_sorted_input(ctx, k0, v0, k1, v1, n, nullptr, B, false, stream);
+}
+
+// Fixes the sizes of everything a plan allocates, so that later plans neither allocate nor synchronise (capturable).
+int plan_reserve(Ctx* ctx, int64_t max_points, int B, const int64_t* level_caps) {
+  EGONN_REQUIRE(max_points >= 1 && B >= 1 && B <= EGONN_MAX_BATCH, EGONN_ERR_INVALID, "reserve: bad sizes");
+  ctx->plan.valid = false;
+  for (int l = 0; l < NL; ++l) {
+    int64_t c = max_points;
+    if (level_caps && l < EGONN_NUM_LEVELS) c = std::min<int64_t>(std::max<int64_t>(level_caps[l], 64), max_points);
+    if (level_caps && l >= EGONN_NUM_LEVELS) c = ctx->reserve_cap[EGONN_NUM_LEVELS - 1];   // virtual levels: <= level 7
+    ctx->reserve_cap[l] = c;
+  }
+  ctx->reserve_points = max_points;
+  ctx->reserve_batch = B;
+  EGONN_TRY(ctx->plan_arena.ensure(plan_arena_bytes(max_points, B)));
+  EGONN_TRY(ctx->sort_arena.ensure(radix_sort_scratch_bytes(max_points)));
+  ctx->reserved = true;
+  return EGONN_OK;
 }
 
 int plan_level_coords(Ctx* ctx, int level, int32_t* out, hipStream_t stream) {
   EGONN_REQUIRE(ctx->plan.valid, EGONN_ERR_STATE, "no coordinate plan (call egonn_voxelize / egonn_coords_set first)");
   EGONN_REQUIRE(level >= 0 && level < EGONN_MAX_LEVELS, EGONN_ERR_INVALID, "level %d out of range", level);
+  EGONN_TRY(plan_sync(ctx, stream));
   const Level& L = ctx->plan.lv[level];
   if (L.n == 0) return EGONN_OK;
   hipLaunchKernelGGL(decode_coords_kernel, dim3((unsigned)cdiv(L.n, 256)), dim3(256), 0, stream, L.keys, (int32_t)L.n,

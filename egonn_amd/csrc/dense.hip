@@ -41,7 +41,9 @@ __global__ __launch_bounds__(256) void dense_kernel(const void* __restrict__ in_
                                                     const float* __restrict__ W, int cout,
                                                     const float* __restrict__ bias, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, int act,
-                                                    const void* __restrict__ residual_v, void* __restrict__ out_v, int io) {
+                                                    const void* __restrict__ residual_v, void* __restrict__ out_v, int io,
+                                                    const int32_t* __restrict__ n_dev) {
+  if (n_dev) n = min((int64_t)*n_dev, n);               // reserved plans: the grid is sized for the capacity
   const float* in = reinterpret_cast<const float*>(in_v);
   const float* residual = reinterpret_cast<const float*>(residual_v);
   float* out = reinterpret_cast<float*>(out_v);
@@ -126,8 +128,10 @@ __global__ __launch_bounds__(256) void dense_kernel(const void* __restrict__ in_
 }
 
 __global__ void dense_any_kernel(const float* __restrict__ in, int64_t total, int cin, const float* __restrict__ W,
-                                 int w_out_in, int cout, const float* __restrict__ bias, int act, float* __restrict__ out) {
+                                 int w_out_in, int cout, const float* __restrict__ bias, int act, float* __restrict__ out,
+                                 const int32_t* __restrict__ n_dev) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) total = min((int64_t)*n_dev * cout, total);
   if (i >= total) return;
   const int64_t r = i / cout;
   const int co = (int)(i - r * cout);
@@ -138,13 +142,13 @@ __global__ void dense_any_kernel(const float* __restrict__ in, int64_t total, in
 
 int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const float* W, int w_out_in, int cout,
                      const float* bias, const float* scale, const float* shift, int act, const void* residual, int res_bf16,
-                     void* out, int out_bf16, hipStream_t stream) {
+                     void* out, int out_bf16, hipStream_t stream, const int32_t* n_dev) {
   if (n == 0) return EGONN_OK;
   const dim3 grid((unsigned)cdiv(n, 64), (unsigned)cdiv(cout, 64));
   const int io = (res_bf16 ? 1 : 0) | (out_bf16 ? 2 : 0);
 #define EGONN_DENSE_LAUNCH(WOI, CI, INB)                                                                              \
   hipLaunchKernelGGL((dense_kernel<WOI, CI, INB>), grid, dim3(256), 0, stream, in, n, W, cout, bias, scale, shift, act, \
-                     residual, out, io)
+                     residual, out, io, n_dev)
 #define EGONN_DENSE_CASE(CI)                                                                                       \
   if (cin == CI) {                                                                                                 \
     if (w_out_in) { if (in_bf16) EGONN_DENSE_LAUNCH(1, CI, true); else EGONN_DENSE_LAUNCH(1, CI, false); }         \
@@ -164,14 +168,15 @@ int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const floa
   EGONN_REQUIRE(!scale && !shift && !residual && !in_bf16 && !out_bf16, EGONN_ERR_INVALID, "dense: cin=%d has no fused epilogue", cin);
   const int64_t total = n * cout;
   hipLaunchKernelGGL(dense_any_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream,
-                     reinterpret_cast<const float*>(in), total, cin, W, w_out_in, cout, bias, act, reinterpret_cast<float*>(out));
+                     reinterpret_cast<const float*>(in), total, cin, W, w_out_in, cout, bias, act, reinterpret_cast<float*>(out),
+                     n_dev);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
 int dense_forward(const float* in, int64_t n, int cin, const float* W, int w_out_in, int cout, const float* bias,
                   const float* scale, const float* shift, int act, const float* residual, float* out,
                   hipStream_t stream) {
-  return dense_forward_ex(in, 0, n, cin, W, w_out_in, cout, bias, scale, shift, act, residual, 0, out, 0, stream);
+  return dense_forward_ex(in, 0, n, cin, W, w_out_in, cout, bias, scale, shift, act, residual, 0, out, 0, stream, nullptr);
 }
 
 // ------------------------------------------------------------------ BatchNorm folding (eval mode)
@@ -194,16 +199,17 @@ int bn_fold(const float* w, const float* b, const float* rm, const float* rv, fl
 
 // ------------------------------------------------------------------ row gather (features -> sorted row order)
 __global__ void gather_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ perm, int64_t n, int c,
-                                   float* __restrict__ out) {
+                                   float* __restrict__ out, const int32_t* __restrict__ n_dev) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) n = min((int64_t)*n_dev, n);
   if (t >= n * c) return;
   const int64_t r = t / c;
   const int ch = (int)(t - r * c);
   out[t] = in[(int64_t)perm[r] * c + ch];
 }
-int gather_rows(const float* in, const int32_t* perm, int64_t n, int c, float* out, hipStream_t stream) {
+int gather_rows(const float* in, const int32_t* perm, int64_t n, int c, float* out, hipStream_t stream, const int32_t* n_dev) {
   if (n == 0) return EGONN_OK;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(n * c, 256)), dim3(256), 0, stream, in, perm, n, c, out);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(n * c, 256)), dim3(256), 0, stream, in, perm, n, c, out, n_dev);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
@@ -285,6 +291,7 @@ __global__ void eca_apply_kernel(const void* __restrict__ x, const void* __restr
                                  const float* __restrict__ gate, const int32_t* __restrict__ boff, int B, int64_t n,
                                  int c4, void* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  n = min((int64_t)boff[B], n);                          // rows in use (reserved plans size the grid for the capacity)
   if (t >= n * c4) return;
   const int32_t r = (int32_t)(t / c4);
   const int q = (int)(t - (int64_t)r * c4);
@@ -353,10 +360,20 @@ __global__ __launch_bounds__(256) void eca_gate_groups_kernel(const float* __res
   const int g0 = meta[1 + b], g1 = meta[2 + b];
   const int32_t cntr = boff[b + 1] - boff[b];
   const int nsl = 256 / c, sl = tid / c, ch = tid - sl * c;     // c <= 256, power of two
+  // fixed order per slice; the loads of 8 groups are in flight together (the loop used to walk ~100 dependent loads)
   float acc = 0.f;
-  if (sl < nsl)
-    for (int g = g0 + sl; g < g1; g += nsl)
+  if (sl < nsl) {
+    int g = g0 + sl;
+    for (; g + 7 * nsl < g1; g += 8 * nsl) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (gmask[g + u * nsl] >> 31) ? psum[(int64_t)(g + u * nsl) * c + ch] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; g < g1; g += nsl)
       if (gmask[g] >> 31) acc += psum[(int64_t)g * c + ch];
+  }
   red[tid] = acc;
   __syncthreads();
   if (tid < c) {
@@ -430,9 +447,10 @@ int gem_finish(const float* partial, const int32_t* boff, int B, int c, const fl
 }
 
 // ------------------------------------------------------------------ row L2 normalisation (F.normalize eps=1e-12)
-__global__ void l2norm_kernel(float* __restrict__ x, int64_t n, int c) {
+__global__ void l2norm_kernel(float* __restrict__ x, int64_t n, int c, const int32_t* __restrict__ n_dev) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n_dev) n = min((int64_t)*n_dev, n);
   if (row >= n) return;
   float* p = x + row * c;
   float ss = 0.f;
@@ -442,9 +460,9 @@ __global__ void l2norm_kernel(float* __restrict__ x, int64_t n, int c) {
   const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
   for (int i = lane; i < c; i += 64) p[i] *= inv;
 }
-int l2_normalize_rows(float* x, int64_t n, int c, hipStream_t stream) {
+int l2_normalize_rows(float* x, int64_t n, int c, hipStream_t stream, const int32_t* n_dev) {
   if (n == 0) return EGONN_OK;
-  hipLaunchKernelGGL(l2norm_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream, x, n, c);
+  hipLaunchKernelGGL(l2norm_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream, x, n, c, n_dev);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
@@ -452,8 +470,9 @@ int l2_normalize_rows(float* x, int64_t n, int c, hipStream_t stream) {
 // ------------------------------------------------------------------ keypoint positions
 __global__ void keypoint_kernel(const uint64_t* __restrict__ keys, int64_t n, int level, int cb,
                                 const float* __restrict__ offs, int mode, float s0, float s1, float s2, int ignore,
-                                float* __restrict__ out) {
+                                float* __restrict__ out, const int32_t* __restrict__ n_dev) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) n = min((int64_t)*n_dev, n);
   if (i >= n) return;
   const int cbL = cb - level;
   const uint64_t mort = keys[i] & ((1ull << (3 * cbL)) - 1);
@@ -479,71 +498,83 @@ __global__ void keypoint_kernel(const uint64_t* __restrict__ keys, int64_t n, in
   }
 }
 int keypoint_positions(const uint64_t* keys, int64_t n, int level, int cb, const float* offsets, int mode,
-                       const float* step, int ignore_offsets, float* out, hipStream_t stream) {
+                       const float* step, int ignore_offsets, float* out, hipStream_t stream, const int32_t* n_dev) {
   if (n == 0) return EGONN_OK;
   const float s0 = step[0], s1 = mode ? step[1] : step[0], s2 = mode ? step[2] : step[0];
   hipLaunchKernelGGL(keypoint_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, keys, n, level, cb, offsets,
-                     mode, s0, s1, s2, ignore_offsets, out);
+                     mode, s0, s1, s2, ignore_offsets, out, n_dev);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
 
 // ------------------------------------------------------------------ top-k (smallest sigma, ascending, ties by row)
-__global__ void topk_keys_kernel(const float* __restrict__ sigma, const int32_t* __restrict__ boff, int B, int64_t n,
-                                 uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t u = __float_as_uint(sigma[i]);
-  const uint32_t s = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotone float -> uint
-  const int b = sample_of_row(boff, B, (int32_t)i);
-  keys[i] = ((uint64_t)(uint32_t)b << 32) | s;
-  vals[i] = (uint32_t)i;
+// MinkLocGLEvaluator.get_keypoints_idxes (eval/evaluate.py:352-361: torch.topk(sigma, n_k, largest=False) per scan) +
+// the gather of the selected keypoints / descriptors, ONE launch: workgroup = scan.  Keys = (monotone sigma bits << 32 |
+// row inside the scan) are unique, so the order is total (ties by Z-order row, as the stable radix sort it replaces).
+// The scan's rows stream through an LDS bitonic sorter S keys at a time together with the best k so far.
+__device__ static inline uint32_t sigma_bits(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotone float -> uint
 }
-__global__ void topk_pick_kernel(const uint32_t* __restrict__ sorted_rows, const int32_t* __restrict__ boff, int B,
-                                 int k, int32_t* __restrict__ sel_rows, int32_t* __restrict__ sel_count) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= B * k) return;
-  const int b = t / k, i = t - b * k;
-  const int32_t s = boff[b], cntr = min(boff[b + 1] - s, k);
-  sel_rows[t] = (i < cntr) ? (int32_t)sorted_rows[s + i] : -1;
-  if (i == 0) sel_count[b] = cntr;
-}
-int topk_select(Ctx* ctx, const float* sigma, const int32_t* boff_dev, const int32_t* /*boff_host*/, int B, int64_t n,
-                int k, int32_t* sel_rows, int32_t* sel_count, hipStream_t stream) {
-  EGONN_REQUIRE(k >= 1, EGONN_ERR_INVALID, "topk: k=%d", k);
-  Arena& A = ctx->work_arena;
-  uint64_t* k0 = A.alloc<uint64_t>(n + 1);
-  uint64_t* k1 = A.alloc<uint64_t>(n + 1);
-  uint32_t* v0 = A.alloc<uint32_t>(n + 1);
-  uint32_t* v1 = A.alloc<uint32_t>(n + 1);
-  EGONN_REQUIRE(k0 && k1 && v0 && v1, EGONN_ERR_STATE, "work arena too small (topk)");
-  if (n > 0) {
-    hipLaunchKernelGGL(topk_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, sigma, boff_dev, B, n, k0,
-                       v0);
-    int bb = 1;
-    while ((1 << bb) < B) ++bb;
-    EGONN_TRY(radix_sort_pairs(ctx, k0, v0, k1, v1, n, 32 + bb, stream));
+__global__ __launch_bounds__(256) void select_topk_kernel(const float* __restrict__ sigma, const int32_t* __restrict__ boff,
+                                                           int k, int S, const float* __restrict__ kp,
+                                                           const float* __restrict__ desc, int dc,
+                                                           int32_t* __restrict__ sel_rows, int32_t* __restrict__ sel_count,
+                                                           float* __restrict__ out_kp, float* __restrict__ out_desc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];   // [S]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int32_t r0 = boff[b], nb = boff[b + 1] - r0;
+  const int kk = min(k, nb);
+  const int fresh = S - k;                               // new rows per round (k <= S / 2)
+  int have = 0;                                          // best-so-far keys parked in skeys[0 .. have)
+  for (int base = 0; base < nb || base == 0; base += fresh) {
+    for (int i = tid; i < S - have; i += 256) {
+      const int r = base + i;
+      skeys[have + i] = (i < fresh && r < nb) ? (((unsigned long long)sigma_bits(sigma[r0 + r]) << 32) | (unsigned)r) : ~0ull;
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= S; k2 <<= 1)
+      for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+        for (int e = tid; e < S / 2; e += 256) {
+          const int i = ((e & ~(j2 - 1)) << 1) | (e & (j2 - 1));
+          const int q = i | j2;
+          const bool up = (i & k2) == 0;
+          const unsigned long long x = skeys[i], y = skeys[q];
+          if ((x > y) == up) { skeys[i] = y; skeys[q] = x; }
+        }
+        __syncthreads();
+      }
+    have = k;                                            // the first k sorted keys stay for the next round
+    if (nb == 0) break;
   }
-  hipLaunchKernelGGL(topk_pick_kernel, dim3((unsigned)cdiv((int64_t)B * k, 256)), dim3(256), 0, stream, v1, boff_dev, B,
-                     k, sel_rows, sel_count);
-  HIP_CHECK(hipGetLastError());
-  return EGONN_OK;
+  // ---- selected rows + gathered keypoints / descriptors (padded with -1 / zeros)
+  for (int i = tid; i < k; i += 256) sel_rows[(int64_t)b * k + i] = (i < kk) ? r0 + (int32_t)(skeys[i] & 0xFFFFFFFFu) : -1;
+  if (tid == 0) sel_count[b] = kk;
+  if (out_desc) {
+    for (int64_t t = tid; t < (int64_t)k * dc; t += 256) {
+      const int i = (int)(t / dc), c = (int)(t - (int64_t)i * dc);
+      out_desc[((int64_t)b * k + i) * dc + c] = (i < kk) ? desc[(int64_t)(r0 + (int32_t)(skeys[i] & 0xFFFFFFFFu)) * dc + c] : 0.f;
+    }
+    for (int t = tid; t < k * 3; t += 256) {
+      const int i = t / 3, c = t - i * 3;
+      out_kp[((int64_t)b * k + i) * 3 + c] = (i < kk) ? kp[(int64_t)(r0 + (int32_t)(skeys[i] & 0xFFFFFFFFu)) * 3 + c] : 0.f;
+    }
+  }
 }
-
-__global__ void gather_topk_kernel(const int32_t* __restrict__ sel_rows, int total, const float* __restrict__ kp,
-                                   const float* __restrict__ desc, int dc, float* __restrict__ out_kp,
-                                   float* __restrict__ out_desc) {
-  const int slot = blockIdx.x;
-  if (slot >= total) return;
-  const int32_t r = sel_rows[slot];
-  for (int i = threadIdx.x; i < dc; i += blockDim.x)
-    out_desc[(int64_t)slot * dc + i] = (r >= 0) ? desc[(int64_t)r * dc + i] : 0.f;
-  if (threadIdx.x < 3) out_kp[(int64_t)slot * 3 + threadIdx.x] = (r >= 0) ? kp[(int64_t)r * 3 + threadIdx.x] : 0.f;
-}
-int gather_topk(const int32_t* sel_rows, const int32_t* /*sel_count*/, int B, int k, const float* kp,
-                const float* desc, int dc, float* out_kp, float* out_desc, hipStream_t stream) {
-  hipLaunchKernelGGL(gather_topk_kernel, dim3(B * k), dim3(64), 0, stream, sel_rows, B * k, kp, desc, dc, out_kp,
-                     out_desc);
+int select_topk(const float* sigma, const int32_t* boff_dev, int B, int k, const float* kp, const float* desc, int dc,
+                int32_t* sel_rows, int32_t* sel_count, float* out_kp, float* out_desc, hipStream_t stream) {
+  EGONN_REQUIRE(k >= 1 && k <= 8192, EGONN_ERR_INVALID, "select_keypoints: n_k=%d outside [1, 8192]", k);
+  int S = 2048;
+  while (S < 2 * k) S <<= 1;
+  const size_t lds = (size_t)S * sizeof(unsigned long long);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(256), lds, stream, sigma, boff_dev, k, S, kp, desc, dc, sel_rows,
+                     sel_count, out_kp, out_desc);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }

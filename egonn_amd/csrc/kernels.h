@@ -26,6 +26,7 @@ static constexpr size_t SCONV_SCRATCH_FLOATS = (size_t)2 << 20;   // 8 MB: one p
 // conv.hip -------------------------------------------------------------------------------------
 int sconv_naive(const float* in, const int32_t* nbr, const float* W, const float* scale, const float* shift, int relu,
                 float* out, int64_t n_out, int K, int cin, int cout, hipStream_t stream);
+int conv0_lut_init(Ctx* ctx);      // first-layer lookup table (built once per context)
 int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, const float* scale,
                      const float* shift, int relu, void* out, int out_bf16, hipStream_t stream);
 
@@ -39,10 +40,12 @@ int dense_forward(const float* in, int64_t n, int cin, const float* W, int w_out
 // the same with bf16 feature maps on any of the three row operands (weights and arithmetic stay fp32)
 int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const float* W, int w_out_in, int cout,
                      const float* bias, const float* scale, const float* shift, int act, const void* residual, int res_bf16,
-                     void* out, int out_bf16, hipStream_t stream);
+                     void* out, int out_bf16, hipStream_t stream, const int32_t* n_dev = nullptr);
 int bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps, int c, float* scale,
             float* shift, hipStream_t stream);
-int gather_rows(const float* in, const int32_t* perm, int64_t n, int c, float* out, hipStream_t stream);
+// n_dev (nullable, here and below): device-resident row count (<= n); n then only sizes the grid
+int gather_rows(const float* in, const int32_t* perm, int64_t n, int c, float* out, hipStream_t stream,
+                const int32_t* n_dev = nullptr);
 // per-sample column sums, deterministic two-stage: partial[b][chunk][c]
 static constexpr int SEG_CHUNKS = 32;
 int segment_partial_sums(const float* in, const int32_t* boff, int B, int c, int pow_mode, const float* p,
@@ -60,16 +63,15 @@ int convert_bf16_to_f32(const void* in, int64_t n, float* out, hipStream_t strea
 // GeM: out[b][c] = (mean_b clamp(x,eps)^p)^(1/p) from the pow-mode partial sums
 int gem_finish(const float* partial, const int32_t* boff, int B, int c, const float* p, float* out,
                hipStream_t stream);
-int l2_normalize_rows(float* x, int64_t n, int c, hipStream_t stream);
+int l2_normalize_rows(float* x, int64_t n, int c, hipStream_t stream, const int32_t* n_dev = nullptr);
 int add_act(const float* a, const float* b, int64_t n, int relu, float* out, hipStream_t stream);
 // keypoint positions (reference datasets/quantization.py:60-72, 93-103)
 int keypoint_positions(const uint64_t* keys, int64_t n, int level, int cb, const float* offsets, int mode,
-                       const float* step, int ignore_offsets, float* out, hipStream_t stream);
-// top-k smallest sigma per sample, ascending, ties by row (= Z-order) — eval/evaluate.py:352-361
-int topk_select(Ctx* ctx, const float* sigma, const int32_t* boff_dev, const int32_t* boff_host, int B, int64_t n,
-                int k, int32_t* sel_rows /*[B][k]*/, int32_t* sel_count /*[B]*/, hipStream_t stream);
-int gather_topk(const int32_t* sel_rows, const int32_t* sel_count, int B, int k, const float* kp, const float* desc,
-                int dc, float* out_kp, float* out_desc, hipStream_t stream);
+                       const float* step, int ignore_offsets, float* out, hipStream_t stream, const int32_t* n_dev = nullptr);
+// top-k smallest sigma per sample, ascending, ties by row (= Z-order) — eval/evaluate.py:352-361 — and the gather of the
+// selected keypoints / descriptors, one launch (workgroup = scan); out_kp / out_desc nullable
+int select_topk(const float* sigma, const int32_t* boff_dev, int B, int k, const float* kp, const float* desc, int dc,
+                int32_t* sel_rows /*[B][k]*/, int32_t* sel_count /*[B]*/, float* out_kp, float* out_desc, hipStream_t stream);
 
 // loss.hip ---------------------------------------------------------------------------------------
 size_t triplet_loss_scratch_floats(int n);

@@ -17,10 +17,10 @@ using namespace egonn;
 
 struct egonn_ctx : public Ctx {
   // scratch kept between egonn_forward and its readers
+  hipStream_t plan_stream = nullptr; // stream the current plan was enqueued on (lazy size queries synchronise it)
   void* level_feat[EGONN_NUM_LEVELS] = {};
   int level_ch[EGONN_NUM_LEVELS] = {};
   int level_bf16 = 0;                // precision of level_feat (last forward)
-  int64_t* scan_off_dev = nullptr;   // device copy of the scan offsets (voxelize plans)
   bool from_points = false;
 };
 
@@ -79,7 +79,7 @@ API const char* egonn_last_error(void) { return last_error(); }
 
 API int egonn_debug_set_naive_conv(egonn_ctx* c, int on) {
   EGONN_REQUIRE(c, EGONN_ERR_INVALID, "debug_set_naive_conv: null context");
-  c->conv_variant = (on == 1) ? 3 : (on == 2 ? 1 : 0);
+  c->conv_variant = (on == 1) ? 3 : (on == 2 ? 1 : (on == 4 ? 2 : 0));
   return EGONN_OK;
 }
 
@@ -97,7 +97,8 @@ API int egonn_ctx_create(egonn_ctx** out, int device, int coord_bits) {
   egonn_ctx* c = new egonn_ctx();
   c->device = device;
   c->coord_bits = coord_bits;
-  const size_t hc = sizeof(int32_t) * (32 + (size_t)EGONN_NUM_LEVELS * (EGONN_MAX_BATCH + 1));
+  // pinned staging: counts + flags (32), per-level sample offsets, and the scan offsets of egonn_voxelize (int64)
+  const size_t hc = sizeof(int32_t) * (32 + (size_t)EGONN_NUM_LEVELS * (EGONN_MAX_BATCH + 1)) + sizeof(int64_t) * (EGONN_MAX_BATCH + 2);
   if (hipHostMalloc(reinterpret_cast<void**>(&c->host_counts), hc) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&c->dev_counts), sizeof(int32_t) * 32) != hipSuccess ||
       false ||
@@ -106,7 +107,11 @@ API int egonn_ctx_create(egonn_ctx** out, int device, int coord_bits) {
     delete c;
     return EGONN_ERR_HIP;
   }
-  c->dev_flags = c->dev_counts + 16;   // counts[0..10], flags at [16]: fetched by one copy
+  c->dev_flags = c->dev_counts + 16;   // counts[0..11], flags at [16]: fetched by one copy
+  if (conv0_lut_init(c) != EGONN_OK) {
+    egonn_ctx_destroy(c);
+    return EGONN_ERR_HIP;
+  }
   *out = c;
   return EGONN_OK;
 }
@@ -133,20 +138,89 @@ API int egonn_voxelize(egonn_ctx* c, const float* points, const int64_t* scan_of
   EGONN_REQUIRE(c && points && scan_offsets && step, EGONN_ERR_INVALID, "voxelize: null argument");
   HIP_CHECK(hipSetDevice(c->device));
   for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
-  EGONN_TRY(plan_from_points(c, points, scan_offsets, B, mode, step, (hipStream_t)stream));
-  // keep a device copy of the offsets for egonn_input_index
-  c->scan_off_dev = c->plan_arena.alloc<int64_t>(B + 1);
-  EGONN_REQUIRE(c->scan_off_dev, EGONN_ERR_STATE, "plan arena too small");
-  HIP_CHECK(hipMemcpyAsync(c->scan_off_dev, scan_offsets, sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice,
-                           (hipStream_t)stream));
+  c->plan_stream = (hipStream_t)stream;
+  EGONN_TRY(plan_from_points(c, points, scan_offsets, 0, 0, B, mode, step, (hipStream_t)stream));
   c->from_points = true;
   return EGONN_OK;
+}
+
+API int egonn_ctx_reserve(egonn_ctx* c, int64_t max_points, int batch_size, const int64_t* level_capacity) {
+  EGONN_REQUIRE(c, EGONN_ERR_INVALID, "ctx_reserve: null context");
+  HIP_CHECK(hipSetDevice(c->device));
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
+  return plan_reserve(c, max_points, batch_size, level_capacity);
+}
+
+API int egonn_voxelize_device(egonn_ctx* c, const float* points, int64_t n_rows, const int64_t* scan_offsets_dev, int B,
+                              int mode, const float* step, void* stream) {
+  EGONN_REQUIRE(c && points && scan_offsets_dev && step, EGONN_ERR_INVALID, "voxelize_device: null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
+  c->plan_stream = (hipStream_t)stream;
+  EGONN_TRY(plan_from_points(c, points, scan_offsets_dev, n_rows, 1, B, mode, step, (hipStream_t)stream));
+  c->from_points = true;
+  return EGONN_OK;
+}
+
+API int egonn_level_capacity(egonn_ctx* c, int level, int64_t* cap) {
+  EGONN_REQUIRE(c && c->plan.valid, EGONN_ERR_STATE, "no coordinate plan (call egonn_voxelize / egonn_coords_set first)");
+  EGONN_REQUIRE(level >= 0 && level < EGONN_NUM_LEVELS && cap, EGONN_ERR_INVALID, "level %d out of range", level);
+  *cap = c->plan.cap[level];
+  return EGONN_OK;
+}
+
+// ---- hipGraph capture of a sequence of library calls (thin wrappers, so that a host without a HIP binding can use them)
+struct egonn_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+API int egonn_graph_begin(void* stream) {
+  HIP_CHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return EGONN_OK;
+}
+API int egonn_graph_end(void* stream, egonn_graph** out) {
+  EGONN_REQUIRE(out, EGONN_ERR_INVALID, "graph_end: null out pointer");
+  egonn_graph* g = new egonn_graph();
+  hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g->graph);
+  if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    set_error("graph_end: %s (a captured call allocated or synchronised: reserve the context and run the sequence once "
+              "before capturing)", hipGetErrorString(e));
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return EGONN_ERR_HIP;
+  }
+  *out = g;
+  return EGONN_OK;
+}
+API int egonn_graph_launch(egonn_graph* g, void* stream) {
+  EGONN_REQUIRE(g && g->exec, EGONN_ERR_INVALID, "graph_launch: null graph");
+  HIP_CHECK(hipGraphLaunch(g->exec, (hipStream_t)stream));
+  return EGONN_OK;
+}
+API void egonn_graph_destroy(egonn_graph* g) {
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+}
+
+API int egonn_plan_status(egonn_ctx* c, void* stream) {
+  EGONN_REQUIRE(c && (c->plan.valid || c->plan.built_reserved), EGONN_ERR_STATE,
+                "no coordinate plan (call egonn_voxelize / egonn_coords_set first)");
+  HIP_CHECK(hipSetDevice(c->device));
+  if (c->plan.built_reserved) {          // a replayed graph rebuilt the plan behind the host's back: read the state again
+    c->plan.valid = true;
+    c->plan.exact = false;
+  }
+  return plan_sync(c, (hipStream_t)stream);
 }
 
 API int egonn_coords_set(egonn_ctx* c, const int32_t* coords, int64_t n, int B, void* stream) {
   EGONN_REQUIRE(c && coords, EGONN_ERR_INVALID, "coords_set: null argument");
   HIP_CHECK(hipSetDevice(c->device));
   for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
+  c->plan_stream = (hipStream_t)stream;
   EGONN_TRY(plan_from_coords(c, coords, n, B, (hipStream_t)stream));
   c->from_points = false;
   return EGONN_OK;
@@ -159,6 +233,7 @@ API int egonn_coords_set(egonn_ctx* c, const int32_t* coords, int64_t n, int B, 
 API int egonn_level_count(egonn_ctx* c, int level, int64_t* n) {
   REQUIRE_PLAN(c);
   EGONN_REQUIRE(level >= 0 && level < EGONN_MAX_LEVELS && n, EGONN_ERR_INVALID, "level %d out of range", level);
+  EGONN_TRY(plan_sync(c, c->plan_stream));
   *n = c->plan.lv[level].n;
   return EGONN_OK;
 }
@@ -166,6 +241,7 @@ API int egonn_level_count(egonn_ctx* c, int level, int64_t* n) {
 API int egonn_level_batch_offsets(egonn_ctx* c, int level, int64_t* off) {
   REQUIRE_PLAN(c);
   EGONN_REQUIRE(level >= 0 && level < EGONN_NUM_LEVELS && off, EGONN_ERR_INVALID, "level %d out of range", level);
+  EGONN_TRY(plan_sync(c, c->plan_stream));
   for (int b = 0; b <= c->plan.batch; ++b) off[b] = c->plan.boff_host[level][b];
   return EGONN_OK;
 }
@@ -188,10 +264,11 @@ __global__ void input_index_kernel(const int32_t* __restrict__ perm0, const uint
 API int egonn_input_index(egonn_ctx* c, int64_t* out, void* stream) {
   REQUIRE_PLAN(c);
   HIP_CHECK(hipSetDevice(c->device));
+  EGONN_TRY(plan_sync(c, c->plan_stream));
   const Level& L = c->plan.lv[0];
   if (L.n == 0) return EGONN_OK;
   hipLaunchKernelGGL(input_index_kernel, dim3((unsigned)cdiv(L.n, 256)), dim3(256), 0, (hipStream_t)stream,
-                     c->plan.perm0, L.keys, L.n, 3 * c->plan.coord_bits, c->from_points ? c->scan_off_dev : nullptr,
+                     c->plan.perm0, L.keys, L.n, 3 * c->plan.coord_bits, c->from_points ? c->plan.scan_off : nullptr,
                      out);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
@@ -544,9 +621,10 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
 // ------------------------------------------------------------------------------------------ forward
 namespace {
 
-int run_mlp(const MlpRef& r, const float* x, int64_t n, int act_out, float* hidden, float* out, hipStream_t st) {
-  EGONN_TRY(dense_forward(x, n, r.cin, r.w0, 1, r.mid, r.b0, nullptr, nullptr, ACT_RELU, nullptr, hidden, st));
-  return dense_forward(hidden, n, r.mid, r.w1, 1, r.cout, r.b1, nullptr, nullptr, act_out, nullptr, out, st);
+int run_mlp(const MlpRef& r, const float* x, int64_t n, int act_out, float* hidden, float* out, hipStream_t st,
+            const int32_t* n_dev) {
+  EGONN_TRY(dense_forward_ex(x, 0, n, r.cin, r.w0, 1, r.mid, r.b0, nullptr, nullptr, ACT_RELU, nullptr, 0, hidden, 0, st, n_dev));
+  return dense_forward_ex(hidden, 0, n, r.mid, r.w1, 1, r.cout, r.b1, nullptr, nullptr, act_out, nullptr, 0, out, 0, st, n_dev);
 }
 
 }  // namespace
@@ -560,6 +638,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   hipStream_t st = (hipStream_t)stream;
   Plan& P = c->plan;
   const int B = P.batch;
+  const int32_t* cnt = c->dev_counts;                          // device row counts per level (the kernels clip to them)
   const int bf16 = (flags & EGONN_FLAG_BF16) ? 1 : 0;          // feature maps + sparse-conv weights in bf16 (configs[2])
   const size_t es = bf16 ? 2 : 4;                              // bytes per feature-map element
   const bool do_global = !(flags & EGONN_FLAG_DISABLE_GLOBAL);
@@ -595,11 +674,11 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   EGONN_REQUIRE(var != nullptr, EGONN_ERR_STATE, "work arena too small (" #var ")")
 
   // ---- trunk (models/minkgl.py:136-153)
-  const int64_t n0 = P.lv[0].n;
+  const int64_t n0 = P.cap[0];
   const float* f0 = features;          // voxelize plans: features are already in level-0 row order; NULL = all ones
   if (features && !c->from_points) {
     WALLOC(fg, n0);
-    EGONN_TRY(gather_rows(features, P.perm0, n0, 1, fg, st));
+    EGONN_TRY(gather_rows(features, P.perm0, n0, 1, fg, st, cnt));
     f0 = fg;
   }
   FALLOC(x0, n0 * 32);
@@ -614,12 +693,12 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   for (int i = 1; i <= 7; ++i) {
     const BlockRef& b = m->blk[i];
     const Level& L = P.lv[i];
-    const int64_t n = L.n;
+    const int64_t n = P.cap[i];
     FALLOC(y, n * b.cin);
     char tag[64];
     {
       snprintf(tag, sizeof(tag), "sconv_rg_kernel<%d,%d>/L%d/k2s2", b.cin, b.cin, i);
-      ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, P.lv[i - 1].n, n);
+      ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, P.cap[i - 1], n);
       EGONN_TRY(sconv_map(c, 1, i, x[i - 1], nullptr, bf16 ? m->q_convs[i] : m->p_convs[i], b.cin, b.cin, bf16, m->bn[i].scale,
                           m->bn[i].shift, 1, y, nullptr, nullptr, 0, st));
     }
@@ -645,7 +724,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     if (b.down) {
       FALLOC(rd, n * b.cout);
       EGONN_TRY(dense_forward_ex(y, bf16, n, b.cin, b.down, 0, b.cout, nullptr, b.dn.scale, b.dn.shift, ACT_NONE, nullptr, 0, rd,
-                                 bf16, st));
+                                 bf16, st, cnt + i));
       res = rd;
     }
     FALLOC(xo, n * b.cout);
@@ -657,24 +736,24 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
 
   // ---- global head + decoder + GeM (models/minkgl.py:46-60, 207-225; layers/pooling.py:82-86)
   if (do_global) {
-    FALLOC(g7, P.lv[7].n * GLOBAL_CH);
-    EGONN_TRY(dense_forward_ex(x[7], bf16, P.lv[7].n, 128, m->g1x1[7], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0,
-                               g7, bf16, st));
-    FALLOC(u6, P.lv[6].n * GLOBAL_CH);
+    FALLOC(g7, P.cap[7] * GLOBAL_CH);
+    EGONN_TRY(dense_forward_ex(x[7], bf16, P.cap[7], 128, m->g1x1[7], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0,
+                               g7, bf16, st, cnt + 7));
+    FALLOC(u6, P.cap[6] * GLOBAL_CH);
     EGONN_TRY(sconv_map(c, 2, 6, g7, nullptr, bf16 ? m->q_gt[7] : m->p_gt[7], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u6,
                         nullptr, nullptr, 0, st));
-    FALLOC(g6, P.lv[6].n * GLOBAL_CH);
-    EGONN_TRY(dense_forward_ex(x[6], bf16, P.lv[6].n, 128, m->g1x1[6], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u6, bf16,
-                               g6, bf16, st));
-    FALLOC(u5, P.lv[5].n * GLOBAL_CH);
+    FALLOC(g6, P.cap[6] * GLOBAL_CH);
+    EGONN_TRY(dense_forward_ex(x[6], bf16, P.cap[6], 128, m->g1x1[6], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u6, bf16,
+                               g6, bf16, st, cnt + 6));
+    FALLOC(u5, P.cap[5] * GLOBAL_CH);
     EGONN_TRY(sconv_map(c, 2, 5, g6, nullptr, bf16 ? m->q_gt[6] : m->p_gt[6], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u5,
                         nullptr, nullptr, 0, st));
-    WALLOC(g5, P.lv[5].n * GLOBAL_CH);
-    EGONN_TRY(dense_forward_ex(x[5], bf16, P.lv[5].n, 128, m->g1x1[5], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u5, bf16,
-                               g5, 0, st));
-    WALLOC(gh, P.lv[5].n * m->gdec.mid);
-    WALLOC(gd, P.lv[5].n * GLOBAL_DIM);
-    EGONN_TRY(run_mlp(m->gdec, g5, P.lv[5].n, ACT_NONE, gh, gd, st));
+    WALLOC(g5, P.cap[5] * GLOBAL_CH);
+    EGONN_TRY(dense_forward_ex(x[5], bf16, P.cap[5], 128, m->g1x1[5], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u5, bf16,
+                               g5, 0, st, cnt + 5));
+    WALLOC(gh, P.cap[5] * m->gdec.mid);
+    WALLOC(gd, P.cap[5] * GLOBAL_DIM);
+    EGONN_TRY(run_mlp(m->gdec, g5, P.cap[5], ACT_NONE, gh, gd, st, cnt + 5));
     WALLOC(gp, (size_t)B * SEG_CHUNKS * GLOBAL_DIM);
     EGONN_TRY(segment_partial_sums(gd, P.lv[5].boff, B, GLOBAL_DIM, 1, m->gem_p, gp, st));
     EGONN_TRY(gem_finish(gp, P.lv[5].boff, B, GLOBAL_DIM, m->gem_p, out_global, st));
@@ -682,25 +761,25 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
 
   // ---- local head, descriptor / keypoint / sigma regressors (models/minkgl.py:287-308)
   if (do_local) {
-    const int64_t n3 = P.lv[3].n, n4 = P.lv[4].n;
+    const int64_t n3 = P.cap[3], n4 = P.cap[4];
     FALLOC(l4, n4 * LOCAL_CH);
     EGONN_TRY(dense_forward_ex(x[4], bf16, n4, 128, m->l1x1[4], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0, l4,
-                               bf16, st));
+                               bf16, st, cnt + 4));
     FALLOC(u3, n3 * LOCAL_CH);
     EGONN_TRY(sconv_map(c, 2, 3, l4, nullptr, bf16 ? m->q_lt[4] : m->p_lt[4], LOCAL_CH, LOCAL_CH, bf16, nullptr, nullptr, 0, u3,
                         nullptr, nullptr, 0, st));
     WALLOC(l3, n3 * LOCAL_CH);
-    EGONN_TRY(dense_forward_ex(x[3], bf16, n3, 64, m->l1x1[3], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u3, bf16, l3, 0, st));
+    EGONN_TRY(dense_forward_ex(x[3], bf16, n3, 64, m->l1x1[3], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u3, bf16, l3, 0, st, cnt + 3));
     WALLOC(dh, n3 * m->ldec.mid);
-    EGONN_TRY(run_mlp(m->ldec, l3, n3, ACT_NONE, dh, out_desc, st));
-    EGONN_TRY(l2_normalize_rows(out_desc, n3, LOCAL_DIM, st));
+    EGONN_TRY(run_mlp(m->ldec, l3, n3, ACT_NONE, dh, out_desc, st, cnt + 3));
+    EGONN_TRY(l2_normalize_rows(out_desc, n3, LOCAL_DIM, st, cnt + 3));
     WALLOC(kh, n3 * m->kp.mid);
     WALLOC(ko, n3 * 3);
-    EGONN_TRY(run_mlp(m->kp, l3, n3, ACT_TANH, kh, ko, st));
+    EGONN_TRY(run_mlp(m->kp, l3, n3, ACT_TANH, kh, ko, st, cnt + 3));
     EGONN_TRY(keypoint_positions(P.lv[3].keys, n3, 3, P.coord_bits, ko, quant_mode, step,
-                                 (flags & EGONN_FLAG_IGNORE_KP_REGRESSOR) ? 1 : 0, out_kp, st));
+                                 (flags & EGONN_FLAG_IGNORE_KP_REGRESSOR) ? 1 : 0, out_kp, st, cnt + 3));
     WALLOC(sh, n3 * m->sg.mid);
-    EGONN_TRY(run_mlp(m->sg, l3, n3, ACT_SOFTPLUS, sh, out_sigma, st));
+    EGONN_TRY(run_mlp(m->sg, l3, n3, ACT_SOFTPLUS, sh, out_sigma, st, cnt + 3));
   }
 #undef WALLOC
 #undef FALLOC
@@ -726,21 +805,18 @@ API int egonn_select_keypoints(egonn_ctx* c, const float* sigma, const float* ke
   EGONN_REQUIRE(sigma && keypoints && descriptors && sel_kp && sel_desc && sel_rows && sel_count, EGONN_ERR_INVALID,
                 "select_keypoints: null argument");
   HIP_CHECK(hipSetDevice(c->device));
-  hipStream_t st = (hipStream_t)stream;
-  const Plan& P = c->plan;
-  const int64_t n3 = P.lv[3].n;
-  // scratch for the sort lives behind whatever the last forward left in the work arena
-  const size_t need = c->work_arena.off + (size_t)(n3 + 64) * 24 + 4096;
-  EGONN_REQUIRE(need <= c->work_arena.cap || c->work_arena.off == 0, EGONN_ERR_STATE,
-                "work arena too small for keypoint selection");
-  if (c->work_arena.off == 0) EGONN_TRY(c->work_arena.ensure(need));
-  const size_t mark = c->work_arena.off;
-  int rc = topk_select(c, sigma, P.lv[3].boff, nullptr, P.batch, n3, n_k, sel_rows, sel_count, st);
-  if (rc == EGONN_OK) rc = gather_topk(sel_rows, sel_count, P.batch, n_k, keypoints, descriptors, LOCAL_DIM, sel_kp, sel_desc, st);
-  c->work_arena.off = mark;
-  return rc;
+  return select_topk(sigma, c->plan.lv[3].boff, c->plan.batch, n_k, keypoints, descriptors, LOCAL_DIM, sel_rows, sel_count,
+                     sel_kp, sel_desc, (hipStream_t)stream);
 }
 
+
+// torch.topk(sigma, n_k, largest=False) per segment (eval/evaluate.py:359) without a plan: row_offsets DEVICE int32 (B+1)
+API int egonn_topk_rows(const float* sigma, const int32_t* row_offsets, int batch_size, int n_k, int32_t* sel_rows,
+                        int32_t* sel_count, void* stream) {
+  EGONN_REQUIRE(sigma && row_offsets && sel_rows && sel_count && batch_size >= 1, EGONN_ERR_INVALID, "topk_rows: bad argument");
+  return select_topk(sigma, row_offsets, batch_size, n_k, nullptr, nullptr, 0, sel_rows, sel_count, nullptr, nullptr,
+                     (hipStream_t)stream);
+}
 
 // ------------------------------------------------------------------------------------------ launch timing (bench.py)
 API int egonn_profile_enable(egonn_ctx* c, int mode, const char* filter) {

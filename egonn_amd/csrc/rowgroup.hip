@@ -16,6 +16,8 @@
 //                   snbr[(g*K + k)*16 + s] = input row + 1 (0 = absent): one coalesced 64-byte line per (g, k).
 // Window slot w owns the WIN/16 groups [w*GPW, (w+1)*GPW); partial windows leave trailing groups empty.  All sizes
 // are read from device memory (row count, per-sample offsets), so the builder needs no host knowledge of N_l.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -99,18 +101,24 @@ __global__ __launch_bounds__(256) void rowgroup_build_kernel(RGArgs a) {
   const int r0 = J.boff[sb] + (w - s_info[1]) * WIN;
   const int rows = min(WIN, J.boff[sb + 1] - r0);
 
-  // ---- presence masks
-  for (int i = tid; i < WIN; i += 256) smask[i] = 0;
-  __syncthreads();
+  // ---- presence masks: one thread per row, the K table entries of a row are independent loads (unrolled)
   const int32_t* src = J.nbr + (int64_t)r0 * K;
-  for (int t = tid; t < rows * K; t += 256) {
-    const int r = t / K, k = t - r * K;
-    if (src[t] >= 0) atomicOr(&smask[r], 1u << k);
-  }
-  __syncthreads();
+  auto row_mask = [&](const int32_t* rp, auto KK) {
+    constexpr int kk = decltype(KK)::value;
+    int32_t v[kk];
+#pragma unroll
+    for (int k = 0; k < kk; ++k) v[k] = rp[k];
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < kk; ++k) m |= (v[k] >= 0 ? 1u : 0u) << k;
+    return m;
+  };
   for (int i = tid; i < WIN; i += 256) {
+    uint32_t m = 0;
+    if (i < rows) m = (K == 27) ? row_mask(src + i * 27, std::integral_constant<int, 27>{}) : row_mask(src + i * 8, std::integral_constant<int, 8>{});
+    smask[i] = m;
     unsigned long long key = ~0ull;
-    if (i < rows) key = ((unsigned long long)(K == 27 ? remap27(smask[i]) : smask[i]) << 16) | (unsigned)i;
+    if (i < rows) key = ((unsigned long long)(K == 27 ? remap27(m) : m) << 16) | (unsigned)i;
     skey[i] = key;
   }
   __syncthreads();
@@ -139,15 +147,23 @@ __global__ __launch_bounds__(256) void rowgroup_build_kernel(RGArgs a) {
     for (int o = 1; o < 16; o <<= 1) m |= __shfl_xor(m, o, 64);
     if ((i & 15) == 0) J.gmask[gbase + (i >> 4)] = m;
   }
-  // ---- sorted table, one 64-byte line per (group, offset)
+  // ---- sorted table, one 64-byte line per (group, offset): thread = sorted slot, K independent loads then K stores
   const int ngr = (rows + 15) >> 4;                     // groups with real rows
-  for (int t = tid; t < ngr * K * 16; t += 256) {
-    const int s = t & 15, gk = t >> 4;
-    const int gl = gk / K, k = gk - gl * K;
-    const unsigned long long key = skey[gl * 16 + s];
-    int32_t v = 0;
-    if (key != ~0ull) v = src[(int)(key & 0xFFFFu) * K + k] + 1;
-    J.snbr[(gbase + gl) * K * 16 + (int64_t)k * 16 + s] = v;
+  auto emit = [&](int i, auto KK) {
+    constexpr int kk = decltype(KK)::value;
+    const unsigned long long key = skey[i];
+    const bool valid = key != ~0ull;
+    const int32_t* rp = src + (int)(key & 0xFFFFu) * kk;
+    int32_t v[kk];
+#pragma unroll
+    for (int k = 0; k < kk; ++k) v[k] = valid ? rp[k] + 1 : 0;
+    int32_t* dst = J.snbr + (gbase + (i >> 4)) * kk * 16 + (i & 15);
+#pragma unroll
+    for (int k = 0; k < kk; ++k) dst[k * 16] = v[k];
+  };
+  for (int i = tid; i < ngr * 16; i += 256) {
+    if (K == 27) emit(i, std::integral_constant<int, 27>{});
+    else emit(i, std::integral_constant<int, 8>{});
   }
 }
 

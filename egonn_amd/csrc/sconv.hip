@@ -112,9 +112,16 @@ struct SconvArgs {
   int K, relu;
 };
 
-template <int CIN, int COUT, bool BF16, int D>
+// KSP > 1 (layers with >= 64 input channels): the KSP waves of a workgroup that share one (group, 32-column) tile each
+// take 1/KSP of the input-channel blocks and the partial accumulators are summed through LDS in fixed order — shorter
+// dependent item chains per wave and KSP x the waves in flight (the tail levels have a few hundred groups: without the
+// split one wave per SIMD walked 40 dependent items while the chip idled).
+template <int CIN, int COUT, bool BF16, int D, int KSP>
 __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
   constexpr int NS = COUT / 32, NCB = CIN / 32;
+  constexpr int NCBL = NCB / KSP;                        // channel blocks per wave
+  constexpr int TPW = 4 / KSP;                           // tiles per workgroup
+  static_assert(NCB % KSP == 0 && 4 % KSP == 0, "bad channel split");
   constexpr int ES = BF16 ? 2 : 4;                       // bytes per feature element
   constexpr int ALD = BF16 ? 1 : 2;                      // b128 loads of A per lane per item
   constexpr int WLD = BF16 ? 2 : 4;                      // b128 loads of W per lane per item
@@ -125,115 +132,24 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
   const int l15 = lane & 15, g4 = lane >> 4;
   const int K = p.K;
   int32_t* const ldsw = lds + wave * ((27 + 1) * 16);
+  f32x4* const red = reinterpret_cast<f32x4*>(lds + 4 * 28 * 16);      // [2 parities][4 waves][2 tiles][64 lanes] (KSP > 1)
 
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wp), 0, (int)p.w_bytes, 0x00020000);
 
   const int ngroups = __builtin_amdgcn_readfirstlane(p.meta[0]);
-  const int ntask = (ngroups * NS + 3) >> 2;             // workgroup tasks (4 wave tasks each)
+  const int ntiles = ngroups * NS;
+  const int ntask = (ntiles + TPW - 1) / TPW;            // workgroup tasks
+  // every XCD (block b runs on XCD b % 8) takes one contiguous eighth of the tasks: its slice of the feature map
+  // (Z-order => spatially compact) and the kernel fit its 4 MB L2.  Measured: interleaving 256-row chunks over the
+  // XCDs instead costs 20-25 % (profiles/r02d_sconv.log) — the gathers miss L2 far more than the balance gains.
   const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3; // gridDim.x is a multiple of 8
   const int cpx = (ntask + 7) >> 3;
-  const int tend = min((xcd + 1) * cpx, ntask);
+  const int sub = wave % KSP;
+  int par = 0;
 
-  for (int t = xcd * cpx + (blockIdx.x >> 3); t < tend; t += nper) {
-    const int task = t * 4 + wave;
-    const int g = task / NS, ns = task - g * NS;
-    if (g >= ngroups) continue;
-    const uint32_t gm = __builtin_amdgcn_readfirstlane(p.gmask[g]);
-    if (!(gm >> 31)) continue;
-
-    // ---- stage the group's neighbour rows (K x 16 ints) + one all-absent row into wave-private LDS
-    {
-      const int4* src = reinterpret_cast<const int4*>(p.snbr + (int64_t)g * K * 16);
-      const int n16 = K * 4;                             // 16-byte pieces
-      int4 v0 = make_int4(0, 0, 0, 0), v1 = make_int4(0, 0, 0, 0);
-      if (lane < n16) v0 = src[lane];
-      if (lane + 64 < n16) v1 = src[lane + 64];
-      reinterpret_cast<int4*>(ldsw)[lane] = v0;          // lanes >= n16 write zeros: row K (all absent) and beyond
-      if (lane + 64 < 28 * 4) reinterpret_cast<int4*>(ldsw)[lane + 64] = v1;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-
-    // ---- item generator (scalar): set bits of the group mask x channel blocks
-    uint32_t mk = gm & 0x07FFFFFFu;
-    const int n_items = __builtin_amdgcn_readfirstlane(__popc(mk) * NCB);
-    int gen_k = 0, gen_cb = 0;
-    // pending item (the one whose loads are issued next): gathered-row byte offset per lane, W offset, validity
-    int32_t pend_idx;                                    // raw LDS value: consumed one step later, so the read latency is hidden
-    uint32_t pend_acb;
-    uint32_t pend_woff, pend_wbad;
-    auto generate = [&]() {                              // branch-free: scalar selects only
-      const bool need = (gen_cb == 0);
-      const bool take = need && (mk != 0);
-      const bool valid = !need || take;                  // items in the middle of a k are always real
-      gen_k = take ? __builtin_ctz(mk | 0x80000000u) : gen_k;
-      mk = take ? (mk & (mk - 1)) : mk;
-      const int krow = valid ? gen_k : K;
-      pend_idx = ldsw[krow * 16 + l15];
-      pend_acb = (uint32_t)(gen_cb * 32 * ES);
-      pend_woff = (uint32_t)(((gen_k * NCB + gen_cb) * NS + ns)) * ITEM_BYTES;
-      pend_wbad = valid ? 0u : 0x80000000u;
-      gen_cb = (valid && gen_cb + 1 < NCB) ? gen_cb + 1 : 0;
-    };
-
-    f32x4 aring[D][ALD];
-    f32x4 wring[D][WLD];
-    auto issue = [&](auto RS) {
-      constexpr int rs = decltype(RS)::value;
-      const uint32_t pend_aoff = (uint32_t)(pend_idx - 1) * (uint32_t)(CIN * ES) + pend_acb + (uint32_t)(g4 * 16);
-      const int wv = (int)((uint32_t)(lane * 16) | pend_wbad);
-      const int ws = __builtin_amdgcn_readfirstlane((int)pend_woff);
-#pragma unroll
-      for (int i = 0; i < WLD; ++i)
-        wring[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv + i * 1024, ws, 0));
-#pragma unroll
-      for (int i = 0; i < ALD; ++i)
-        aring[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(pend_aoff + 64 * i), 0, 0));
-    };
-
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    auto compute = [&](auto RS) {
-      constexpr int rs = decltype(RS)::value;
-      if constexpr (BF16) {
-        const bf16x8_t av = __builtin_bit_cast(bf16x8_t, aring[rs][0]);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wring[rs][nt]), av, acc[nt], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wring[rs][nt * 2 + tt][u], aring[rs][tt][u], acc[nt], 0, 0, 0);
-      }
-    };
-
-    // ---- prologue: D-1 items in flight
-    generate();
-    [&]<int... Is>(std::integer_sequence<int, Is...>) {
-      ((issue(std::integral_constant<int, Is>{}), generate(), __builtin_amdgcn_sched_barrier(0)), ...);
-    }(std::make_integer_sequence<int, D - 1>{});
-    // ---- main loop: straight-line groups of D items (no branch between a load and its wait)
-    const int n_main = n_items / D;
-    for (int it = 0; it < n_main; ++it) {
-      [&]<int... Is>(std::integer_sequence<int, Is...>) {
-        // the scheduling barriers pin the issue order: hipcc otherwise sinks the loads below the MFMAs and interleaves
-        // the loads of different items, and the in-order vmcnt then waits for data that is not needed yet
-        ((issue(std::integral_constant<int, (Is + D - 1) % D>{}), generate(), __builtin_amdgcn_sched_barrier(0),
-          compute(std::integral_constant<int, Is>{}), __builtin_amdgcn_sched_barrier(0)), ...);
-      }(std::make_integer_sequence<int, D>{});
-    }
-    // ---- remainder (< D items, already in flight in slots 0..rem-1)
-    const int rem = n_items - n_main * D;
-    [&]<int... Is>(std::integer_sequence<int, Is...>) {
-      ((Is < rem ? compute(std::integral_constant<int, Is>{}) : (void)0), ...);
-    }(std::make_integer_sequence<int, D - 1>{});
-
-    // ---- epilogue: BN scale/shift (+ReLU), one store per tile; optional per-group column sums
+  // ---- epilogue: BN scale/shift (+ReLU), one store per tile; optional per-group column sums
+  auto epilogue = [&](const f32x4 (&acc)[2], int g, int ns) {
     const int32_t row = p.perm[(int64_t)g * 16 + l15];
     float sums[2][4];
 #pragma unroll
@@ -267,10 +183,10 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          float s = sums[nt][u];
+          float sv = sums[nt][u];
 #pragma unroll
-          for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
-          sums[nt][u] = s;
+          for (int o = 1; o < 16; o <<= 1) sv += __shfl_xor(sv, o, 64);
+          sums[nt][u] = sv;
         }
       if (l15 == 0) {
 #pragma unroll
@@ -279,7 +195,130 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
               (f32x4){sums[nt][0], sums[nt][1], sums[nt][2], sums[nt][3]};
       }
     }
-    __builtin_amdgcn_wave_barrier();                     // the next task overwrites the wave's LDS rows
+  };
+
+  for (int lt = blockIdx.x >> 3; lt < cpx; lt += nper) {
+    const int task = xcd * cpx + lt;
+    const int tile = task * TPW + wave / KSP;
+    const int g = tile / NS, ns = tile - g * NS;
+    uint32_t gm = 0;
+    if (task < ntask && tile < ntiles) gm = __builtin_amdgcn_readfirstlane(p.gmask[g]);
+    const bool active = (gm >> 31) != 0;
+    if constexpr (KSP == 1) {
+      if (!active) continue;                             // no barrier in this configuration: waves are independent
+    }
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+    if (KSP == 1 || active) {
+      // ---- stage the group's neighbour rows (K x 16 ints) + one all-absent row into wave-private LDS
+      {
+        const int4* src = reinterpret_cast<const int4*>(p.snbr + (int64_t)g * K * 16);
+        const int n16 = K * 4;                           // 16-byte pieces
+        int4 v0 = make_int4(0, 0, 0, 0), v1 = make_int4(0, 0, 0, 0);
+        if (lane < n16) v0 = src[lane];
+        if (lane + 64 < n16) v1 = src[lane + 64];
+        reinterpret_cast<int4*>(ldsw)[lane] = v0;        // lanes >= n16 write zeros: row K (all absent) and beyond
+        if (lane + 64 < 28 * 4) reinterpret_cast<int4*>(ldsw)[lane + 64] = v1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+
+      // ---- item generator (scalar): set bits of the group mask x this wave's channel blocks
+      uint32_t mk = gm & 0x07FFFFFFu;
+      const int n_items = __builtin_amdgcn_readfirstlane(__popc(mk) * NCBL);
+      int gen_k = 0, gen_cb = 0;
+      // pending item (the one whose loads are issued next)
+      int32_t pend_idx;                                  // raw LDS value: consumed one step later, so the read latency is hidden
+      uint32_t pend_acb;
+      uint32_t pend_woff, pend_wbad;
+      auto generate = [&]() {                            // branch-free: scalar selects only
+        const bool need = (gen_cb == 0);
+        const bool take = need && (mk != 0);
+        const bool valid = !need || take;                // items in the middle of a k are always real
+        gen_k = take ? __builtin_ctz(mk | 0x80000000u) : gen_k;
+        mk = take ? (mk & (mk - 1)) : mk;
+        const int krow = valid ? gen_k : K;
+        const int cb = sub * NCBL + gen_cb;
+        pend_idx = ldsw[krow * 16 + l15];
+        pend_acb = (uint32_t)(cb * 32 * ES);
+        pend_woff = (uint32_t)(((gen_k * NCB + cb) * NS + ns)) * ITEM_BYTES;
+        pend_wbad = valid ? 0u : 0x80000000u;
+        gen_cb = (valid && gen_cb + 1 < NCBL) ? gen_cb + 1 : 0;
+      };
+
+      f32x4 aring[D][ALD];
+      f32x4 wring[D][WLD];
+      auto issue = [&](auto RS) {
+        constexpr int rs = decltype(RS)::value;
+        const uint32_t pend_aoff = (uint32_t)(pend_idx - 1) * (uint32_t)(CIN * ES) + pend_acb + (uint32_t)(g4 * 16);
+        const int wv = (int)((uint32_t)(lane * 16) | pend_wbad);
+        const int ws = __builtin_amdgcn_readfirstlane((int)pend_woff);
+#pragma unroll
+        for (int i = 0; i < WLD; ++i)
+          wring[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv + i * 1024, ws, 0));
+#pragma unroll
+        for (int i = 0; i < ALD; ++i)
+          aring[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(pend_aoff + 64 * i), 0, 0));
+      };
+      auto compute = [&](auto RS) {
+        constexpr int rs = decltype(RS)::value;
+        if constexpr (BF16) {
+          const bf16x8_t av = __builtin_bit_cast(bf16x8_t, aring[rs][0]);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wring[rs][nt]), av, acc[nt], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wring[rs][nt * 2 + tt][u], aring[rs][tt][u], acc[nt], 0, 0, 0);
+        }
+      };
+
+      // ---- prologue: D-1 items in flight
+      generate();
+      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        ((issue(std::integral_constant<int, Is>{}), generate(), __builtin_amdgcn_sched_barrier(0)), ...);
+      }(std::make_integer_sequence<int, D - 1>{});
+      // ---- main loop: straight-line groups of D items (no branch between a load and its wait)
+      const int n_main = n_items / D;
+      for (int it = 0; it < n_main; ++it) {
+        [&]<int... Is>(std::integer_sequence<int, Is...>) {
+          // the scheduling barriers pin the issue order: hipcc otherwise sinks the loads below the MFMAs and interleaves
+          // the loads of different items, and the in-order vmcnt then waits for data that is not needed yet
+          ((issue(std::integral_constant<int, (Is + D - 1) % D>{}), generate(), __builtin_amdgcn_sched_barrier(0),
+            compute(std::integral_constant<int, Is>{}), __builtin_amdgcn_sched_barrier(0)), ...);
+        }(std::make_integer_sequence<int, D>{});
+      }
+      // ---- remainder (< D items, already in flight in slots 0..rem-1)
+      const int rem = n_items - n_main * D;
+      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        ((Is < rem ? compute(std::integral_constant<int, Is>{}) : (void)0), ...);
+      }(std::make_integer_sequence<int, D - 1>{});
+      __builtin_amdgcn_wave_barrier();                   // the next task overwrites the wave's LDS rows
+      if constexpr (KSP == 1) epilogue(acc, g, ns);
+    }
+
+    if constexpr (KSP > 1) {                             // fixed-order sum of the channel-split partials
+      f32x4* r = red + ((par * 4 + wave) * 2) * 64 + lane;
+      r[0] = acc[0];
+      r[64] = acc[1];
+      __syncthreads();
+      if (sub == 0) {
+#pragma unroll
+        for (int q = 1; q < KSP; ++q) {
+          const f32x4* o = red + ((par * 4 + wave + q) * 2) * 64 + lane;
+          acc[0] += o[0];
+          acc[1] += o[64];
+        }
+      }
+      par ^= 1;
+      if (active && sub == 0) epilogue(acc, g, ns);
+    }
   }
 }
 
@@ -321,16 +360,11 @@ __global__ __launch_bounds__(NW * 64) void sconv_wg_kernel(const SconvArgs p) {
 
   const int ngroups = __builtin_amdgcn_readfirstlane(p.meta[0]);
   const int ntask = ngroups / NW;                        // groups in use are a multiple of 16
-  // chunks of CHK consecutive tasks (= one 1024-row window for NW = 4) go round-robin to the XCDs: neighbours share an
-  // L2, and every XCD gets a sample of the whole cloud (contiguous eighths were unbalanced by up to the density contrast)
-  constexpr int CHK = 64 / NW;
-  const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3; // gridDim.x is a multiple of 8
-  const int nchunks = (ntask + CHK - 1) / CHK;
+  const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3; // gridDim.x is a multiple of 8; one contiguous eighth per XCD
+  const int cpx = (ntask + 7) >> 3;
 
-  for (int lt = blockIdx.x >> 3;; lt += nper) {
-    const int chunk = (lt / CHK) * 8 + xcd;
-    if (chunk >= nchunks) break;
-    const int task = chunk * CHK + lt % CHK;
+  for (int lt = blockIdx.x >> 3; lt < cpx; lt += nper) {
+    const int task = xcd * cpx + lt;
     if (task >= ntask) continue;
     const int g0 = task * NW;
     uint32_t U = 0, own = 0;
@@ -515,16 +549,14 @@ static int launch_wg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
   constexpr int NW = 4;
   constexpr int ES = BF16 ? 2 : 4;
   const size_t lds = 2 * (size_t)(32 * COUT * ES) + NW * 28 * 16 * sizeof(int32_t);
-  static int wg_per_cu = 0;                              // resident workgroups per CU of this instantiation (constant)
-  if (!wg_per_cu) {
+  static bool attr_done = false;                         // per instantiation; idempotent
+  if (!attr_done) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_wg_kernel<CIN, COUT, BF16, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    int nb = 0;
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sconv_wg_kernel<CIN, COUT, BF16, NW>, NW * 64, lds));
-    wg_per_cu = std::max(nb, 1);
+    attr_done = true;
   }
   const int64_t ntask = cdiv(groups_hint, NW);
-  int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), (int64_t)256 * wg_per_cu);
+  int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 16384);
   grid = (grid + 7) / 8 * 8;
   hipEvent_t* pev = prof_kernel_events();
   if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
@@ -538,23 +570,32 @@ static int launch_wg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
 }
 
 // ------------------------------------------------------------------ launcher
-template <int CIN, int COUT, bool BF16>
-static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
+template <int CIN, int COUT, bool BF16, int KSP>
+static int launch_rg_ksp(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
   constexpr int D = BF16 ? 4 : 3;
   constexpr int NS = COUT / 32;
-  const int64_t ntask = cdiv(groups_hint * NS, 4);
-  int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 2048);
+  const size_t lds = 4 * 28 * 16 * sizeof(int32_t) + (KSP > 1 ? 2 * 4 * 2 * 64 * sizeof(f32x4) : 0);
+  const int64_t ntask = cdiv(groups_hint * NS * KSP, 4);
+  // one workgroup per task up to a cap: the hardware dispatcher then balances the uneven tasks (a grid of only the
+  // resident workgroups was 30 % slower: each loops over ~3 tasks and the slowest decides)
+  int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 16384);
   grid = (grid + 7) / 8 * 8;
-  const size_t lds = 4 * 28 * 16 * sizeof(int32_t);
   hipEvent_t* pev = prof_kernel_events();
   if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
-    hipExtLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D>), dim3((unsigned)grid), dim3(256), lds, stream, pev[0], pev[1], 0, a);
+    hipExtLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP>), dim3((unsigned)grid), dim3(256), lds, stream, pev[0], pev[1], 0, a);
     pev[0] = pev[1] = nullptr;
   } else {
-    hipLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP>), dim3((unsigned)grid), dim3(256), lds, stream, a);
   }
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
+}
+template <int CIN, int COUT, bool BF16>
+static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
+  constexpr int NCB = CIN / 32;
+  // the input-channel blocks are always split over the waves of a workgroup (a function of the shape only, so results
+  // never depend on launch sizes): measured faster at every level, 12 % on the 84 k-row 64->64 layer, 40 % on level 4
+  return launch_rg_ksp<CIN, COUT, BF16, (NCB >= 4 ? 4 : NCB)>(a, groups_hint, stream);
 }
 
 bool sconv_rg_supported(int cin, int cout) {
@@ -579,15 +620,16 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
   a.in_bytes = (uint32_t)ib;
   a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * (bf16 ? 2 : 4));
   a.K = rg.K; a.relu = relu ? 1 : 0;
-#define EGONN_RG_CASE(CI, CO)                                                                    \
-  if (cin == CI && cout == CO)                                                                   \
-    return bf16 ? launch_wg<CI, CO, true>(a, groups_hint, stream) : launch_wg<CI, CO, false>(a, groups_hint, stream);
-#define EGONN_RG1_CASE(CI, CO)                                                                   \
-  if (variant == 1 && cin == CI && cout == CO)                                                   \
-    return bf16 ? launch_rg<CI, CO, true>(a, groups_hint, stream) : launch_rg<CI, CO, false>(a, groups_hint, stream);
-  EGONN_RG1_CASE(32, 32)      // per-wave variant (kept for A/B measurements: egonn_debug_set_naive_conv(ctx, 2))
-  EGONN_RG1_CASE(64, 64)
-  EGONN_RG1_CASE(128, 128)
+
+  // Measured (profiles/r02b_sconv.json, batch 16): in fp32 the per-wave kernel wins everywhere (the lock-step of the
+  // cooperative kernel costs more than its saved W traffic when an item is 16-64 MFMAs of 32 cycles); with bf16 maps the
+  // items are load-bound and the cooperative kernel wins on the big layers with >= 64 input or output channels.
+  const bool coop = variant == 2 || (variant == 0 && bf16 && groups_hint >= 2048 && cin * cout >= 32 * 64);
+#define EGONN_RG_CASE(CI, CO)                                                                      \
+  if (cin == CI && cout == CO) {                                                                   \
+    if (coop) return bf16 ? launch_wg<CI, CO, true>(a, groups_hint, stream) : launch_wg<CI, CO, false>(a, groups_hint, stream); \
+    return bf16 ? launch_rg<CI, CO, true>(a, groups_hint, stream) : launch_rg<CI, CO, false>(a, groups_hint, stream);           \
+  }
   EGONN_RG_CASE(32, 32)
   EGONN_RG_CASE(32, 64)
   EGONN_RG_CASE(64, 64)
@@ -604,7 +646,6 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
   EGONN_RG_CASE(128, 32)
   EGONN_RG_CASE(32, 256)
   EGONN_RG_CASE(256, 32)
-#undef EGONN_RG1_CASE
 #undef EGONN_RG_CASE
   set_error("sconv: channel plan %d->%d has no instantiation", cin, cout);
   return EGONN_ERR_INVALID;

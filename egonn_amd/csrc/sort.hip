@@ -21,12 +21,21 @@ static constexpr int SORT_ROUNDS = 8;                        // keys per thread
 static constexpr int SORT_TILE = SORT_BLOCK * SORT_ROUNDS;   // 2048 keys per workgroup (391 tiles for the 800 k points of a batch; 4096 left CUs idle, 1024 is no better)
 static constexpr int SORT_SUPER = 32;                        // tiles per supertile
 
-__global__ __launch_bounds__(SORT_BLOCK) void sort_hist_kernel(const uint64_t* __restrict__ keys, int64_t n,
+// n_dev (nullable): the true element count lives in device memory (capturable plans); n is then the capacity the grid
+// was sized for.
+__device__ static inline int64_t sort_count(int64_t n, const int64_t* __restrict__ n_dev) {
+  if (!n_dev) return n;
+  const int64_t v = *n_dev;
+  return v < n ? v : n;
+}
+__global__ __launch_bounds__(SORT_BLOCK) void sort_hist_kernel(const uint64_t* __restrict__ keys, int64_t n_cap,
+                                                               const int64_t* __restrict__ n_dev,
                                                                int shift, int32_t* __restrict__ tilehist,
                                                                int32_t* __restrict__ superhist,
                                                                int32_t* __restrict__ total) {
   __shared__ int32_t hist[256];
   const int tid = threadIdx.x;
+  const int64_t n = sort_count(n_cap, n_dev);
   hist[tid] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
@@ -46,8 +55,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_hist_kernel(const uint64_t* _
 
 __global__ __launch_bounds__(SORT_BLOCK) void sort_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, int64_t n, int shift, const int32_t* __restrict__ tilehist,
-    const int32_t* __restrict__ superhist, const int32_t* __restrict__ total) {
+    uint32_t* __restrict__ vals_out, int64_t n_cap, const int64_t* __restrict__ n_dev, int shift,
+    const int32_t* __restrict__ tilehist, const int32_t* __restrict__ superhist, const int32_t* __restrict__ total) {
+  const int64_t n = sort_count(n_cap, n_dev);
   __shared__ int32_t whist[SORT_WAVES][256];   // running per-wave digit counts
   __shared__ int32_t dbase[256];               // global base of every digit for this tile
   __shared__ int32_t wsum[SORT_WAVES];
@@ -144,7 +154,7 @@ size_t radix_sort_scratch_bytes(int64_t n) {
 }
 
 int radix_sort_pairs(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
-                     int64_t n, int nbits, hipStream_t stream) {
+                     int64_t n, int nbits, hipStream_t stream, const int64_t* n_dev) {
   EGONN_REQUIRE(n >= 0 && n < (int64_t(1) << 31), EGONN_ERR_INVALID, "radix_sort: n=%lld out of range", (long long)n);
   EGONN_REQUIRE(nbits >= 1 && nbits <= 64, EGONN_ERR_INVALID, "radix_sort: nbits=%d", nbits);
   const int passes = (nbits + 7) / 8;
@@ -170,10 +180,10 @@ int radix_sort_pairs(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* k
     int32_t* superhist = slabs + (int64_t)p * (supers + 1) * 256;
     int32_t* total = superhist + supers * 256;
     const int shift = 8 * p;
-    hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)tiles), dim3(SORT_BLOCK), 0, stream, kb[src], n, shift,
+    hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)tiles), dim3(SORT_BLOCK), 0, stream, kb[src], n, n_dev, shift,
                        tilehist, superhist, total);
     hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)tiles), dim3(SORT_BLOCK), 0, stream, kb[src], vb[src],
-                       kb[src ^ 1], vb[src ^ 1], n, shift, tilehist, superhist, total);
+                       kb[src ^ 1], vb[src ^ 1], n, n_dev, shift, tilehist, superhist, total);
     src ^= 1;
   }
   HIP_CHECK(hipGetLastError());

@@ -308,11 +308,16 @@ class MinkGL(nn.Module):
         return y
 
     def _forward_on_plan(self, ctx: _lib.Context, feats: torch.Tensor, disable_global_head=False,
-                         disable_local_head=False):
+                         disable_local_head=False, outputs=None):
+        """outputs: (global, descriptors, keypoints, sigma) preallocated tensors for a reserved (capturable) plan —
+        the local ones hold `ctx.level_capacity(3)` rows and the call performs no host synchronisation; the returned
+        dict then carries the packed tensors instead of per-sample lists."""
         self._sync_weights()
         dev = ctx.device
         B = ctx.batch_size
         lvl = min(LOCAL_LEVELS)
+        if outputs is not None:
+            return self._forward_reserved(ctx, feats, outputs, disable_global_head, disable_local_head)
         n3 = ctx.level_count(lvl)
         flags = 0
         out_g = out_d = out_k = out_s = None
@@ -349,6 +354,32 @@ class MinkGL(nn.Module):
             y['sigma'] = [out_s[off[b]:off[b + 1]] for b in range(B)]
             self._last_local = (out_d, out_k, out_s)
         return y
+
+    def _flags(self, disable_global_head, disable_local_head):
+        flags = 0
+        if disable_global_head:
+            flags |= _lib.FLAG_DISABLE_GLOBAL
+        if disable_local_head:
+            flags |= _lib.FLAG_DISABLE_LOCAL
+        if self.ignore_keypoint_regressor:
+            flags |= _lib.FLAG_IGNORE_KP_REGRESSOR
+        if self.precision == 'bf16':
+            flags |= _lib.FLAG_BF16
+        elif self.precision != 'fp32':
+            raise ValueError(f"precision {self.precision!r}: 'fp32' or 'bf16'")
+        return flags
+
+    def _forward_reserved(self, ctx, feats, outputs, disable_global_head=False, disable_local_head=False):
+        out_g, out_d, out_k, out_s = outputs
+        q = self.quantizer
+        step = (_lib.C.c_float * 3)(*([float(s) for s in q.step] + [0.0, 0.0])[:3])
+        with torch.cuda.device(ctx.device):
+            _lib.check(ctx.lib.egonn_forward(ctx.h, self._handle.h, _lib._ptr(feats), q.mode, step,
+                                             self._flags(disable_global_head, disable_local_head),
+                                             _lib._ptr(out_g), _lib._ptr(out_d), _lib._ptr(out_k), _lib._ptr(out_s),
+                                             _lib._stream()))
+        self._last_local = (out_d, out_k, out_s)
+        return {'global': out_g, 'descriptors': out_d, 'keypoints': out_k, 'sigma': out_s}
 
     def keypoint_coords(self) -> List[torch.Tensor]:
         """(n_b,4) int32 super-voxel coordinates of the rows of the last forward's local outputs, per sample

@@ -41,8 +41,8 @@ int egonn_ctx_create(egonn_ctx** ctx, int device, int coord_bits);
 void egonn_ctx_destroy(egonn_ctx* ctx);
 const char* egonn_last_error(void);
 /* tests / measurements only: on = 1 routes this context's sparse convolutions through the plain one-thread-per-output
- * HIP kernel (cross-check of the MFMA kernel), on = 2 through the per-wave MFMA variant (A/B timing); 0 = product
- * kernel.  Never set by the product path. */
+ * HIP kernel (cross-check of the MFMA kernels), on = 2 / 4 force the per-wave / the workgroup-cooperative MFMA kernel (A/B
+ * timing); 0 = product choice.  Never set by the product path. */
 int egonn_debug_set_naive_conv(egonn_ctx* ctx, int on);
 
 /* ------------------------------------------------------------------ coordinate plan
@@ -56,6 +56,30 @@ int egonn_debug_set_naive_conv(egonn_ctx* ctx, int on);
  * voxelised batch.  [SYNC] */
 int egonn_voxelize(egonn_ctx* ctx, const float* points, const int64_t* scan_offsets, int batch_size, int quant_mode,
                    const float* step, void* stream);
+/* Capturable plans.  egonn_ctx_reserve fixes the sizes of everything a plan allocates: at most max_points input rows,
+ * exactly batch_size scans, at most level_capacity[l] voxels at level l = 0..7 (HOST, 8 entries; NULL = max_points for every
+ * level).  After it, egonn_voxelize_device builds the plan WITHOUT any host synchronisation or allocation: points (n_rows,3)
+ * f32 device with n_rows <= max_points (rows beyond scan_offsets_dev[B] are ignored), scan_offsets_dev DEVICE int64 (B+1).
+ * The per-level row counts stay in device memory, every kernel of egonn_forward / egonn_select_keypoints clips to them,
+ * so the sequence voxelize_device -> forward -> select_keypoints can be captured into a hipGraph once and replayed on
+ * other batches.  Outputs of a reserved plan are sized by the capacities (out_descriptors: level_capacity[3] rows).
+ * egonn_plan_status [SYNC] copies the sizes and the error state of the latest (replayed) plan to the host: non-zero if a
+ * coordinate left the +-2^(coord_bits-1) range or the batch did not fit the reservation (the outputs are then invalid);
+ * afterwards egonn_level_count / egonn_level_batch_offsets return that batch's true sizes. */
+int egonn_ctx_reserve(egonn_ctx* ctx, int64_t max_points, int batch_size, const int64_t* level_capacity);
+int egonn_voxelize_device(egonn_ctx* ctx, const float* points, int64_t n_rows, const int64_t* scan_offsets_dev,
+                          int batch_size, int quant_mode, const float* step, void* stream);
+int egonn_plan_status(egonn_ctx* ctx, void* stream);
+/* Row capacity of a level of the current plan (= its row count for eager plans).  No sync. */
+int egonn_level_capacity(egonn_ctx* ctx, int level, int64_t* capacity);
+/* hipGraph capture of a sequence of calls on `stream` (hipStreamBeginCapture / EndCapture + Instantiate / hipGraphLaunch):
+ * for hosts without their own HIP binding.  Everything between begin and end must be capturable: a reserved context that
+ * has run the same sequence once (so that no arena grows), no [SYNC] entry point. */
+typedef struct egonn_graph egonn_graph;
+int egonn_graph_begin(void* stream);
+int egonn_graph_end(void* stream, egonn_graph** graph);
+int egonn_graph_launch(egonn_graph* graph, void* stream);
+void egonn_graph_destroy(egonn_graph* graph);
 /* Build the plan from explicit coordinates (N,4) int32 [b,x,y,z] in any row order; duplicate rows collapse onto
  * their first occurrence (ME SparseTensor default).  [SYNC] */
 int egonn_coords_set(egonn_ctx* ctx, const int32_t* coords, int64_t n, int batch_size, void* stream);
@@ -139,6 +163,11 @@ int egonn_forward_level_features(egonn_ctx* ctx, int level, float* out, int chan
 int egonn_select_keypoints(egonn_ctx* ctx, const float* sigma, const float* keypoints, const float* descriptors,
                            int n_k, float* sel_keypoints, float* sel_descriptors, int32_t* sel_rows,
                            int32_t* sel_count, void* stream);
+
+/* The selection alone on explicit segments: row_offsets DEVICE int32 (batch_size+1), sel_rows (batch_size,n_k) global row or
+ * -1, sel_count (batch_size,). */
+int egonn_topk_rows(const float* sigma, const int32_t* row_offsets, int batch_size, int n_k, int32_t* sel_rows,
+                    int32_t* sel_count, void* stream);
 
 /* ------------------------------------------------------------------ batch-hard triplet loss (training, configs[3])
  * replaces BatchHardTripletLossWithMasks.__call__ (models/loss.py:146-172; miner :114-143; the distance / loss /

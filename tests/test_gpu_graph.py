@@ -1,0 +1,188 @@
+"""GPU tests of the capturable pipeline (BASELINE.json configs[2]): reserved plans whose level sizes never reach the
+host, the whole step (voxelise -> forward -> top-128) captured once into a hipGraph and replayed on other batches, bf16
+feature maps at batch 64, and the precision-explicit sparse-convolution operator with its per-group column sums."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import __graft_entry__ as g
+    g.build()
+    import egonn_amd
+    return egonn_amd
+
+
+def _model(gpu, seed, precision="fp32"):
+    mp = gpu.ModelParams(model="egonn", coordinates="cartesian", quantization_step=0.1)
+    m = gpu.model_factory(mp)
+    w = H.seeded_weights(seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    m = m.to("cuda").eval()
+    m.coord_bits = 12
+    m.precision = precision
+    return m
+
+
+def _batch(seeds, n_points):
+    from egonn_amd.synth import lidar_scan
+    scans = [lidar_scan(s, n) for s, n in zip(seeds, n_points)]
+    off = [0]
+    for s in scans:
+        off.append(off[-1] + len(s))
+    return torch.from_numpy(np.concatenate(scans)).cuda(), off
+
+
+KEYS = ("global", "keypoints", "descriptors", "count", "rows")
+
+
+def test_graph_replay_matches_eager_bitwise(gpu):
+    """one captured hipGraph, three different batches (different clouds AND different sizes): every replay equals the
+    eager (size-query) run of the same batch bit for bit; the host never learns the level sizes during a replay."""
+    m = _model(gpu, 51)
+    ex = gpu.DescriptorExtractor(m, n_k=128)
+    batches = [_batch([700, 701, 702, 703], [20000, 15000, 20000, 12000]),
+               _batch([710, 711, 712, 713], [9000, 20000, 20000, 20000]),
+               _batch([720, 721, 722, 723], [20000, 500, 18000, 3])]
+    eager = []
+    for p, o in batches:
+        eager.append({k: v.clone() for k, v in ex.extract_packed(p, o, slot=1).items()})
+    caps = ex.calibrate(batches[0][0], batches[0][1], margin=1.5)
+    gx = ex.graph(batch_size=4, max_points=80000, level_capacity=caps)
+    for rnd in range(2):                       # second round: pure replays
+        for (p, o), want in zip(batches, eager):
+            out = gx.run(p, o)
+            gx.status()
+            for k in KEYS:
+                assert torch.equal(out[k], want[k]), (rnd, k)
+    assert gx.graph is not None
+    # the sizes of the LAST replayed batch are available on request
+    assert gx.ctx.level_count(0) == m.context(1).level_count(0)
+
+
+def test_graph_reports_batches_that_do_not_fit(gpu):
+    m = _model(gpu, 52)
+    ex = gpu.DescriptorExtractor(m, n_k=32)
+    small = _batch([800, 801], [3000, 3000])
+    big = _batch([810, 811], [30000, 30000])
+    caps = ex.calibrate(small[0], small[1], margin=1.2)
+    gx = ex.graph(batch_size=2, max_points=60000, level_capacity=caps)
+    gx.run(*small)
+    gx.status()
+    gx.run(*big)                                # more voxels than reserved: flagged on the device, never out of bounds
+    with pytest.raises(RuntimeError, match="reserve"):
+        gx.status()
+    out = gx.run(*small)                        # the context stays usable
+    gx.status()
+    want = ex.extract_packed(small[0], small[1], slot=1)
+    for k in KEYS:
+        assert torch.equal(out[k], want[k]), k
+    with pytest.raises(ValueError):
+        gx.run(*_batch([1, 2, 3], [10, 10, 10]))   # wrong number of scans
+
+
+def test_config2_bf16_batch64_graph(gpu):
+    """BASELINE configs[2]: bf16 feature maps, batch 64 x 50k points, on-device quantisation, captured forward.
+    Stated tolerance against the fp32 path on the same clouds: global descriptor 1-cos <= 2e-4, selected local
+    descriptors (matched by keypoint row) 1-cos <= 2e-3, at least 85 % of the 128 selected keypoints in common; the
+    integer work (voxel counts per level, sample offsets) is identical; replays are bitwise reproducible."""
+    B = 64
+    p, o = _batch(list(range(2000, 2000 + B)), [50_000] * B)
+    m32 = _model(gpu, 61, "fp32")
+    ex32 = gpu.DescriptorExtractor(m32, n_k=128)
+    ref = {k: v.clone() for k, v in ex32.extract_packed(p, o).items()}
+    counts32 = [m32.context().level_count(l) for l in range(8)]
+    m16 = _model(gpu, 61, "bf16")
+    ex16 = gpu.DescriptorExtractor(m16, n_k=128)
+    caps = ex16.calibrate(p, o, margin=1.2)
+    gx = ex16.graph(batch_size=B, max_points=B * 50_000, level_capacity=caps)
+    out = {k: v.clone() for k, v in gx.run(p, o).items()}
+    gx.status()
+    assert [gx.ctx.level_count(l) for l in range(8)] == counts32
+    out2 = gx.run(p, o)
+    gx.status()
+    for k in KEYS:
+        assert torch.equal(out[k], out2[k]), k
+    g16, g32 = out["global"].cpu().numpy(), ref["global"].cpu().numpy()
+    assert H.cosine_err(g16, g32).max() <= 2e-4
+    assert (out["count"] == 128).all() and (ref["count"] == 128).all()
+    common = []
+    for b in range(B):
+        r16, r32 = out["rows"][b].cpu().numpy(), ref["rows"][b].cpu().numpy()
+        both, i16, i32 = np.intersect1d(r16, r32, return_indices=True)
+        common.append(len(both))
+        d16, d32 = out["descriptors"][b].cpu().numpy()[i16], ref["descriptors"][b].cpu().numpy()[i32]
+        assert H.cosine_err(d16, d32).max() <= 2e-3
+        assert np.abs(out["keypoints"][b].cpu().numpy()[i16] - ref["keypoints"][b].cpu().numpy()[i32]).max() <= 5e-2
+    assert np.mean(common) >= 0.85 * 128, np.mean(common)
+
+
+def test_sparse_conv_precisions_and_group_sums(gpu):
+    """egonn_sparse_conv: fp32 == plain kernel to rounding; bf16 maps within bf16 rounding of the fp32 result computed on
+    the SAME rounded inputs; per-group column sums add up to the per-sample column sums of the stored output."""
+    case = H.load_case("egonn_cart01_b2")
+    ctx = gpu._lib.Context()
+    ctx.coords_set(torch.from_numpy(case["coords"]).cuda(), 2)
+    ref = gpu._lib.Context()
+    ref.coords_set(torch.from_numpy(case["coords"]).cuda(), 2)
+    ref.set_naive_conv(True)
+    torch.manual_seed(5)
+    for kind, lvl, ci, co in [(0, 1, 32, 32), (0, 2, 32, 64), (0, 3, 64, 64), (0, 4, 128, 128), (1, 2, 32, 32),
+                              (1, 5, 128, 128), (2, 3, 64, 64), (2, 5, 128, 128), (0, 5, 256, 256), (2, 4, 128, 256)]:
+        lin = lvl if kind == 0 else (lvl - 1 if kind == 1 else lvl + 1)
+        K = 27 if kind == 0 else 8
+        x = torch.randn(ctx.level_count(lin), ci, device="cuda")
+        w = torch.randn(K, ci, co, device="cuda") / np.sqrt(ci * (9 if K == 27 else 2))
+        sc, sh = torch.rand(co, device="cuda") + 0.5, torch.randn(co, device="cuda") * 0.1
+        want = ref.sparse_conv(kind, lvl, x, w, sc, sh, relu=True)
+        got, sums = ctx.sparse_conv(kind, lvl, x, w, sc, sh, relu=True, group_sums=True)
+        scale = want.abs().max()
+        assert ((got - want).abs().max() / scale) < 2e-5, (kind, lvl, ci, co)
+        # group sums: the groups of sample b are first[b]..first[b+1]
+        ng, first = ctx.map_groups(kind, lvl)
+        off = ctx.level_batch_offsets(lvl)
+        for b in range(2):
+            s_groups = sums[first[b]:first[b + 1]].double().sum(0)
+            s_rows = got[off[b]:off[b + 1]].double().sum(0)
+            assert torch.allclose(s_groups, s_rows, rtol=1e-5, atol=1e-3), (kind, lvl, b)
+        # bf16 maps: inputs and kernel rounded to bf16, fp32 accumulation, output rounded to bf16
+        xb = x.to(torch.bfloat16)
+        wb = w.to(torch.bfloat16).float()
+        want16 = ref.sparse_conv(kind, lvl, xb.float().contiguous(), wb, sc, sh, relu=True)
+        got16 = ctx.sparse_conv(kind, lvl, xb.contiguous(), w, sc, sh, relu=True)
+        assert got16.dtype == torch.bfloat16
+        err = (got16.float() - want16).abs().max() / want16.abs().max()
+        assert err < 6e-3, (kind, lvl, ci, co, float(err))        # one bf16 rounding of the output (2^-8 relative)
+        # both MFMA kernels (per-wave / workgroup-cooperative) agree to summation order in fp32, to one bf16 ulp in bf16
+        for var in (2, 4):
+            ctx.lib.egonn_debug_set_naive_conv(ctx.h, var)
+            v32 = ctx.sparse_conv(kind, lvl, x, w, sc, sh, relu=True)
+            v16 = ctx.sparse_conv(kind, lvl, xb.contiguous(), w, sc, sh, relu=True)
+            assert ((v32 - got).abs().max() / scale) < 2e-5, (var, kind, lvl)
+            assert ((v16.float() - got16.float()).abs().max() / scale) < 8e-3, (var, kind, lvl)
+        ctx.lib.egonn_debug_set_naive_conv(ctx.h, 0)
+
+
+def test_ignore_keypoint_saliency_draws_random_keypoints(gpu):
+    """eval/evaluate.py:354-356: with ignore_keypoint_saliency the n_k keypoints are a random subset, otherwise the n_k
+    lowest sigmas in ascending order (get_keypoints_idxes works on the sigma tensor it is given)."""
+    m = _model(gpu, 53)
+    sig = torch.rand(1000, 1)
+    ex = gpu.DescriptorExtractor(m, n_k=128)
+    idx = ex.get_keypoints_idxes(sig, 128)
+    want = torch.topk(sig.squeeze(1), 128, largest=False).indices
+    assert torch.equal(torch.sort(sig[idx, 0]).values, sig[idx, 0]) and set(idx.tolist()) == set(want.tolist())
+    assert len(ex.get_keypoints_idxes(torch.rand(50, 1), 128)) == 50
+    exr = gpu.DescriptorExtractor(m, n_k=128, ignore_keypoint_saliency=True)
+    r1, r2 = exr.get_keypoints_idxes(sig, 128), exr.get_keypoints_idxes(sig, 128)
+    assert len(set(r1.tolist())) == 128 and set(r1.tolist()) != set(want.tolist()) and not torch.equal(r1, r2)
+    p, o = _batch([900, 901], [8000, 8000])
+    a, b = ex.extract_packed(p, o), exr.extract_packed(p, o, slot=1)
+    assert torch.equal(a["global"], b["global"]) and not torch.equal(a["rows"], b["rows"])
+    assert (b["count"] == 128).all()

@@ -47,10 +47,8 @@ for (kind, lvl, ci, co) in cfgs:
         P = float(ones[:, 0].sum().item())
     want = ref.sparse_conv(kind, lvl, x, w) if (n_out * co * K < 6e8 and not quick) else None
     ng = ctx.map_groups(kind, lvl)[0]
-    variants = [0, 2] if os.environ.get("AB") else [0]
+    variants = [int(v) for v in os.environ["AB"].split(",")] if os.environ.get("AB") else [0]
     for dt, var in [(d, v) for d in (torch.float32, torch.bfloat16) for v in variants]:
-        if var == 2 and (ci, co) not in ((32, 32), (64, 64), (128, 128)):
-            continue
         ctx.lib.egonn_debug_set_naive_conv(ctx.h, var)
         xx = x.to(dt).contiguous()
         got = ctx.sparse_conv(kind, lvl, xx, w)
@@ -69,7 +67,7 @@ for (kind, lvl, ci, co) in cfgs:
         alg = P * ci * es + n_out * co * es + K * ci * co * es + 8 * P
         fl = 2 * P * ci * co
         ctx.lib.egonn_debug_set_naive_conv(ctx.h, 0)
-        rows.append(dict(kind=kind, level=lvl, cin=ci, cout=co, dtype=str(dt).split(".")[-1] + ("/perwave" if var else ""), us=us, pairs=P, n_out=n_out,
+        rows.append(dict(kind=kind, level=lvl, cin=ci, cout=co, dtype=str(dt).split(".")[-1] + ("/v%d" % var if var else ""), us=us, pairs=P, n_out=n_out,
                          groups=ng, alg_MB=alg / 1e6, hbm_frac=alg / (us * 1e-6) / 8e12, tflops=fl / (us * 1e-6) / 1e12, rel_err=err))
         r = rows[-1]
         print(f"kind {kind} L{lvl} {ci:3d}->{co:3d} {r['dtype']:16s}: {us:8.1f} us  alg {r['alg_MB']:7.1f} MB  hbm_frac {r['hbm_frac']:.3f}  "
