@@ -2,23 +2,27 @@
 """bench.py — descriptor-extraction throughput of the MI355X-native EgoNN path.
 
 Metric (BASELINE.json): LiDAR scans/sec (descriptor extraction), 50k-pt clouds @ 0.1 m voxel.
-Workload (BASELINE.json configs[1]): EgoNN inference, synthetic 50k-pt clouds, Cartesian 0.1 m voxels,
+Workload (BASELINE.json configs[1], the default): EgoNN inference, synthetic 50k-pt clouds, Cartesian 0.1 m voxels,
 batch 16 per GPU, fp32 -> 256-d global descriptor + 128 keypoints + 128-d local descriptors.
-A step = one pass of the whole hot path over one batch: voxelise -> forward -> top-128 selection, with the
-points already resident in HBM when the timed region starts.  N>1: one process per GPU, each rank owns its
-own batch (independent scans, no data-path collective) => weak scaling.
+`--dtype bf16 --batch 64` is configs[2] (bf16 feature maps, on-device quantisation, hipGraph-captured step).
+A step = one pass of the whole hot path over one batch: voxelise -> forward -> top-128 selection, with the points
+already resident in HBM when the timed region starts.  N>1: one process per GPU, each rank owns its own batch
+(independent scans, no data-path collective) => weak scaling.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event
-timing inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0 at N=1 only).
+--mode graph (default): the step is captured once into a hipGraph per in-flight slot (reserved plan: the level sizes
+stay on the device) and every timed step is ONE hipGraphLaunch; --mode eager: ~150 launches + one size query per step.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel + a per-layer table,
+every layer against its binding roof) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0 at N=1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -30,6 +34,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense MFMA peaks (MI355X_MICROARCH.md): exact-fp32 / bf16
 
 
 def parse():
@@ -37,23 +42,42 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--batch", type=int, default=16, help="scans per GPU per step (BASELINE configs[1]: 16)")
+    p.add_argument("--batch", type=int, default=16, help="scans per GPU per step (BASELINE configs[1]: 16, configs[2]: 64)")
     p.add_argument("--points", type=int, default=50_000)
     p.add_argument("--voxel", type=float, default=0.1)
     p.add_argument("--cpu-scans", type=int, default=6, help="scans timed on the numpy oracle (fallback only)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work given to the C/OpenMP oracle baseline")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--layer-table", type=str, default="", help="write a per-layer timing table (json) here")
+    p.add_argument("--layer-table", type=str, default="", help="also write the per-layer table (json) here")
     p.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                   help="f32 = BASELINE configs[1] (default, the headline metric); bf16 = configs[2] arithmetic "
-                        "(sparse-conv MFMA operands rounded to bf16, fp32 accumulate, fp32 feature maps)")
-    p.add_argument("--streams", type=int, default=3, help="batches in flight (HIP streams, one egonn_ctx each)")
+                   help="f32 = BASELINE configs[1] (default, the headline metric); bf16 = configs[2]: feature maps and "
+                        "sparse-conv weights bf16 in HBM, fp32 accumulate")
+    p.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    p.add_argument("--streams", type=int, default=3, help="batches in flight (HIP streams, one egonn_ctx / graph each)")
+    p.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median one is reported")
     return p.parse_args()
 
 
 def make_scans(rank: int, batch: int, n_points: int):
     from egonn_amd.synth import lidar_scan
     return [lidar_scan(1000 * rank + i, n_points=n_points) for i in range(batch)]
+
+
+def layer_rows(recs, dtype):
+    """per tagged layer: exclusive duration, algorithmic bytes, flops and the fraction of its BINDING roof."""
+    table = {}
+    for name, t, b, f in recs:
+        e = table.setdefault(name, {"ms": [], "bytes": b, "flops": f})
+        e["ms"].append(t)
+    rows = []
+    for k, v in table.items():
+        us = float(np.mean(v["ms"])) * 1e3
+        t_hbm = v["bytes"] / (HBM_PEAK_GBS * 1e9) * 1e6
+        t_mfma = v["flops"] / (MFMA_PEAK_TFLOPS[dtype] * 1e12) * 1e6
+        rows.append({"layer": k, "us": round(us, 2), "alg_bytes": v["bytes"], "flops": v["flops"],
+                     "hbm_frac": round(t_hbm / us, 4), "mfma_frac": round(t_mfma / us, 4),
+                     "bound": "hbm" if t_hbm >= t_mfma else "mfma", "frac": round(max(t_hbm, t_mfma) / us, 4)})
+    return rows
 
 
 def main():
@@ -95,109 +119,152 @@ def main():
     for s in scans:
         offsets.append(offsets[-1] + len(s))
     points = torch.from_numpy(np.concatenate(scans, axis=0)).to(dev).contiguous()   # resident in HBM
-
+    S = max(1, args.streams)
     ctx = model.context()
 
-    def step():
+    def eager_step():
         return ex.extract_packed(points, offsets)
 
-    # warm-up; the last warm-up step times every tagged launch to find the dominant kernel (largest total time)
-    for i in range(max(args.warmup, 1)):
-        if i == max(args.warmup, 1) - 1:
-            ctx.profile_enable(1)
-            ctx.profile_fetch()
-        out = step()
+    # ---------------- warm-up (eager, one batch in flight); the last step times every tagged launch: per-layer table
+    # (exclusive durations) and the dominant kernel = the sparse-conv instantiation with the largest total time
+    for _ in range(max(args.warmup, 1)):
+        eager_step()
     torch.cuda.synchronize()
-    per_kernel = {}
-    for name, t, b, f in ctx.profile_fetch():
-        per_kernel[name.split("/")[0]] = per_kernel.get(name.split("/")[0], 0.0) + t
-    dominant = max(per_kernel, key=per_kernel.get)
-    ctx.profile_enable(2, dominant + "/")                  # HIP events around the dominant kernel's launches only
-
-    # every in-flight slot needs its arenas grown before the timed region
-    for o in ex.extract_stream(((points, offsets) for _ in range(2 * args.streams)), n_streams=args.streams):
-        out = o
-    torch.cuda.synchronize()
+    ctx.profile_enable(1)
     ctx.profile_fetch()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    outs = []
-    for o in ex.extract_stream(((points, offsets) for _ in range(args.steps)), n_streams=args.streams):
-        outs.append(o)
-        if len(outs) > 2 * args.streams:
-            outs.pop(0)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    recs = ctx.profile_fetch()
-    # the same kernel with ONE batch in flight (after the timed region): rocprofv3 serialises dispatches of different
-    # streams, so its per-kernel average is this "exclusive" duration, not the one measured while three batches
-    # share the CUs
-    excl = []
-    if args.streams > 1:
-        for _ in range(5):
-            step()
-        torch.cuda.synchronize()
-        excl = ctx.profile_fetch()
+    for _ in range(5):
+        eager_step()
+    layers = layer_rows(ctx.profile_fetch(), args.dtype)
     ctx.profile_enable(0)
+    per_kernel = {}
+    for r in layers:
+        if r["layer"].startswith("sconv"):
+            per_kernel[r["layer"].split("/")[0]] = per_kernel.get(r["layer"].split("/")[0], 0.0) + r["us"]
+    dominant = max(per_kernel, key=per_kernel.get)
     n_levels = [ctx.level_count(l) for l in range(8)]
 
-    # ---------------- roofline of the dominant kernel (rank 0's launches)
-    roofline = None
-    if recs:
-        ms = np.array([r[1] for r in recs])
-        by = np.array([r[2] for r in recs])
-        fl = np.array([r[3] for r in recs])
-        achieved = float(by.mean() / (ms.mean() * 1e-3) / 1e9)
-        layers = sorted({r[0].split("/", 1)[1] for r in recs})
-        # HBM bytes per launch from the PMC passes of this same command (separate FETCH_SIZE / WRITE_SIZE passes,
-        # gfx950 correction applied: tools/pmc_traffic.py) — rocprofv3 cannot wrap itself, so the committed summary
-        # of the latest passes is read back; null when the kernel is not in it
-        traffic = None
-        try:
-            with open(os.path.join(REPO, "profiles", "traffic_latest.json")) as f:
-                traffic = json.load(f).get(dominant, {}).get("traffic_bytes_per_launch")
-        except Exception:
-            traffic = None
-        roofline = {"bound": "hbm", "kernel": dominant, "layers": layers,
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "batches_in_flight": args.streams,
-                    "launches": int(len(ms)), "avg_launch_us": round(float(ms.mean()) * 1e3, 2),
-                    "algorithmic_bytes_per_launch": float(by.mean()),
-                    "tflops": round(float(fl.mean() / (ms.mean() * 1e-3) / 1e12), 2)}
-        if excl:
-            ems = np.array([r[1] for r in excl]); eby = np.array([r[2] for r in excl])
-            ea = float(eby.mean() / (ems.mean() * 1e-3) / 1e9)
-            roofline["exclusive"] = {"note": "same kernel, one batch in flight, timed after the timed region; this is "
-                                             "what rocprofv3 --kernel-trace (which serialises streams) reports",
-                                     "avg_launch_us": round(float(ems.mean()) * 1e3, 2), "achieved": round(ea, 1),
-                                     "frac": round(ea / HBM_PEAK_GBS, 4)}
+    # ---------------- host cost of one eager batch (enqueue only) vs its GPU time, one batch in flight
+    torch.cuda.synchronize()
+    h0 = time.perf_counter()
+    eager_step()
+    h1 = time.perf_counter()
+    torch.cuda.synchronize()
+    h2 = time.perf_counter()
+    host = {"eager_enqueue_ms": round((h1 - h0) * 1e3, 3), "eager_latency_ms": round((h2 - h0) * 1e3, 3)}
 
-    # ---------------- optional per-layer table (outside the timed region)
+    # ---------------- the timed step
+    graphs = []
+    if args.mode == "graph":
+        caps = ex.calibrate(points, offsets, margin=1.25)
+        for i in range(S):
+            gx = ex.graph(args.batch, points.shape[0], caps, slot=100 + i)
+            gx.ctx.profile_enable(3, dominant + "/")       # event brackets around the dominant kernel, captured with it
+            gx.run(points, offsets)                        # eager once + capture + first replay; the batch now lives
+            gx.status()                                    # in the graph's own input buffer (resident in HBM)
+            graphs.append(gx)
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        graphs[0].replay()
+        g1 = time.perf_counter()
+        graphs[0].stream.synchronize()
+        g2 = time.perf_counter()
+        host.update({"graph_launch_ms": round((g1 - g0) * 1e3, 3), "graph_latency_ms": round((g2 - g0) * 1e3, 3)})
+
+        def run_steps(k):
+            for i in range(k):
+                graphs[i % S].replay()
+    else:
+        ctx.profile_enable(2, dominant + "/")              # HIP events attached to the dominant kernel's dispatches
+
+        def run_steps(k):
+            for _ in ex.extract_stream(((points, offsets) for _ in range(k)), n_streams=S):
+                pass
+        run_steps(2 * S)                                   # every in-flight slot grows its arenas before timing
+    torch.cuda.synchronize()
+    for c in ([g.ctx for g in graphs] or [ctx]):
+        c.profile_fetch()
+
+    elapsed_all = []
+    for rep in range(max(1, args.repeats)):
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        t1 = time.perf_counter()
+        el = t1 - t0
+        if distributed:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        elapsed_all.append(el)
+    elapsed = float(np.median(elapsed_all))
+
+    # ---------------- roofline of the dominant kernel: launches of the timed region(s)
+    if args.mode == "graph":
+        recs, timing = [], ("HIP event-record nodes captured around the dominant kernel's launches: durations of the last "
+                            "replay of every in-flight graph of the last timed region")
+        for g in graphs:
+            g.status()
+            recs += g.ctx.profile_fetch()
+            g.ctx.profile_enable(0)
+    else:
+        recs, timing = ctx.profile_fetch(), "HIP events attached to every dispatch of the dominant kernel in the timed regions"
+    ctx.profile_enable(2, dominant + "/")
+    for _ in range(5):
+        eager_step()
+    torch.cuda.synchronize()
+    excl = ctx.profile_fetch()                             # same kernel, one batch in flight (what rocprofv3 reports)
+    ctx.profile_enable(0)
+    if not recs:
+        recs, timing = excl, "graph event records unavailable: exclusive eager pass after the timed regions"
+
+    def summarise(rr):
+        ms = np.array([r[1] for r in rr]); by = np.array([r[2] for r in rr]); fl = np.array([r[3] for r in rr])
+        us = float(ms.mean()) * 1e3
+        t_hbm = float(by.mean()) / (HBM_PEAK_GBS * 1e9) * 1e6
+        t_mfma = float(fl.mean()) / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12) * 1e6
+        return us, float(by.mean()), float(fl.mean()), t_hbm, t_mfma
+
+    us, by, fl, t_hbm, t_mfma = summarise(recs)
+    bound = "hbm" if t_hbm >= t_mfma else "mfma"
+    traffic, traffic_src = None, None
+    try:                                                   # HBM bytes per launch: PMC passes of this command (tools/measure.sh)
+        key = dominant.replace(">", "," + ("true" if args.dtype == "bf16" else "false") + ",")
+        with open(os.path.join(REPO, "profiles", "traffic_latest.json")) as f:
+            for k, v in json.load(f).items():
+                if k.replace(" ", "").startswith(key):
+                    traffic = v.get("traffic_bytes_per_launch")
+                    traffic_src = "profiles/traffic_latest.json (separate FETCH_SIZE / WRITE_SIZE rocprofv3 passes of this " \
+                                  "command, gfx950 FETCH_SIZE x2 correction; read back from the committed file, not measured in this run)"
+    except Exception:
+        pass
+    roofline = {
+        "bound": bound, "kernel": dominant,
+        "achieved": round(by / (us * 1e-6) / 1e9, 1) if bound == "hbm" else round(fl / (us * 1e-6) / 1e12, 2),
+        "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFLOPS[args.dtype],
+        "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+        "frac": round(max(t_hbm, t_mfma) / us, 4),
+        "traffic": traffic, "traffic_source": traffic_src,
+        "hbm": {"achieved_GBps": round(by / (us * 1e-6) / 1e9, 1), "frac": round(t_hbm / us, 4)},
+        "mfma": {"achieved_TFLOPs": round(fl / (us * 1e-6) / 1e12, 2), "peak_TFLOPs": MFMA_PEAK_TFLOPS[args.dtype],
+                 "frac": round(t_mfma / us, 4)},
+        "launches": len(recs), "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": by, "flops_per_launch": fl,
+        "timing": timing, "batches_in_flight": S,
+        "layers": sorted(layers, key=lambda r: -r["us"]),
+        "layers_note": "every tagged layer of one step, one batch in flight (exclusive durations, HIP events around the launch); "
+                       "frac = time at the binding roof (max of algorithmic bytes / 8 TB/s and flops / dense MFMA peak) / measured",
+    }
+    if excl:
+        eus, eby, efl, eh, em = summarise(excl)
+        roofline["exclusive"] = {"avg_launch_us": round(eus, 2), "frac": round(max(eh, em) / eus, 4),
+                                 "note": "same kernel, one batch in flight (what rocprofv3 --kernel-trace reports)"}
     if args.layer_table and rank == 0:
-        ctx.profile_enable(1)
-        for _ in range(5):
-            step()
-        table = {}
-        for name, t, b, f in ctx.profile_fetch():
-            e = table.setdefault(name, {"ms": [], "bytes": b, "flops": f})
-            e["ms"].append(t)
-        rows = [{"kernel": k, "avg_us": float(np.mean(v["ms"])) * 1e3, "alg_bytes": v["bytes"], "flops": v["flops"],
-                 "alg_GBps": v["bytes"] / (np.mean(v["ms"]) * 1e-3) / 1e9,
-                 "TFLOPs": v["flops"] / (np.mean(v["ms"]) * 1e-3) / 1e12} for k, v in table.items()]
-        ctx.profile_enable(0)
         with open(args.layer_table, "w") as f:
-            json.dump({"levels": n_levels, "batch": args.batch, "rows": rows}, f, indent=1)
+            json.dump({"levels": n_levels, "batch": args.batch, "dtype": args.dtype, "rows": roofline["layers"]}, f, indent=1)
 
     # ---------------- CPU baseline: the oracle ("port") on a bounded sample of the same workload
     # oracle/egonn_cpu.c = C/OpenMP restatement of the reference path (one scan per forward, like the reference's
@@ -205,31 +272,31 @@ def main():
     # scans until >= --cpu-seconds of CPU work.  (numpy oracle as the fallback if gcc is unavailable.)
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cscans = scans[:16]
         try:
             from oracle import egonn_cpu
             co = egonn_cpu.CpuOracle(sd, args.voxel, native=True)
-            co.compute_embedding(scans[0][:5000], 128)                   # warm-up (thread pool)
+            co.compute_embedding(cscans[0][:5000], 128)                  # warm-up (thread pool)
             cores = os.cpu_count() or 1
             # scans in flight x OpenMP threads per scan: pick the best split of the host cores on a short trial
-            # (128 threads on one 26k-voxel scan scale badly; the reference's DataLoader workers are processes too)
             splits = sorted({(w, max(1, cores // w)) for w in (1, 4, 16) if w <= max(1, cores)})
-            trials = {sp: co.throughput(scans, sp[0], sp[1], 1.0)[0] for sp in splits}
+            trials = {sp: co.throughput(cscans, sp[0], sp[1], 1.0)[0] for sp in splits}
             best = max(trials, key=trials.get)
-            rate, done, secs = co.throughput(scans, best[0], best[1], args.cpu_seconds)
+            rate, done, secs = co.throughput(cscans, best[0], best[1], args.cpu_seconds)
             cpu_baseline = {"value": round(rate, 3), "unit": "scans/s", "cores": int(best[0] * best[1]), "kind": "port",
-                            "sample": f"{done} scans ({done // len(scans)} passes over the {len(scans)} benchmark scans), "
+                            "sample": f"{done} scans ({done // len(cscans)} passes over {len(cscans)} benchmark scans), "
                                       f"C/OpenMP restatement of the reference path (oracle/egonn_cpu.c: voxelise + forward "
-                                      f"+ top-128, one scan per forward, -O3 -march=native), {best[0]} scans in flight x "
+                                      f"+ top-128, one scan per forward, fp32, -O3 -march=native), {best[0]} scans in flight x "
                                       f"{best[1]} OpenMP threads (best of {dict((f'{k[0]}x{k[1]}', round(v, 1)) for k, v in trials.items())} "
                                       f"scans/s on 1 s trials), {secs:.1f} s of CPU work"}
         except Exception as e:                                            # pragma: no cover
             from oracle import egonn_ref as ref
             oracle = ref.EgoNNOracle(sd, ref.CartesianQuantizer(args.voxel))
-            k = min(args.cpu_scans, len(scans))
-            ref.compute_embedding(oracle, scans[0][:5000], 128)
+            k = min(args.cpu_scans, len(cscans))
+            ref.compute_embedding(oracle, cscans[0][:5000], 128)
             c0 = time.perf_counter()
             for i in range(k):
-                ref.compute_embedding(oracle, scans[i], 128)
+                ref.compute_embedding(oracle, cscans[i], 128)
             c1 = time.perf_counter()
             cpu_baseline = {"value": round(k / (c1 - c0), 3), "unit": "scans/s", "cores": os.cpu_count() or 1,
                             "kind": "port", "sample": f"{k} scans on the numpy oracle (C oracle unavailable: {e}), "
@@ -237,6 +304,8 @@ def main():
 
     if rank == 0:
         total_scans = args.batch * world * args.steps
+        cfg = "configs[1]" if (args.dtype == "f32" and args.batch == 16) else \
+              ("configs[2]" if (args.dtype == "bf16" and args.batch == 64 and args.mode == "graph") else "configs[1] variant")
         line = {
             "metric": "LiDAR scans/sec (descriptor extraction), 50k-pt clouds @ 0.1m voxel",
             "value": round(total_scans / elapsed, 2),
@@ -248,14 +317,21 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "f32" else "bf16 (MFMA operands; f32 accumulate and feature maps)",
+            "dtype": "f32" if args.dtype == "f32" else "bf16",
             "data": "synthetic",
-            "config": {"workload": ("configs[1]" if args.dtype == "f32" and args.batch == 16 else "configs[1] variant") +
-                                   ": EgoNN (minkgl) inference, synthetic 50k-pt LiDAR-like clouds, "
-                                   f"Cartesian 0.1 m voxels, batch {args.batch} per GPU, {args.dtype}; step = voxelise + "
-                                   "forward + top-128 keypoints; random-init weights",
+            "config": {"workload": cfg + ": EgoNN (minkgl) inference, synthetic 50k-pt LiDAR-like clouds, "
+                                   f"Cartesian 0.1 m voxels, batch {args.batch} per GPU, {args.dtype}"
+                                   + (" feature maps and sparse-conv weights (fp32 accumulate, fp32 heads/outputs)" if args.dtype == "bf16" else "")
+                                   + "; step = voxelise + forward + top-128 keypoints; random-init weights",
                        "batch_per_gpu": args.batch, "points_per_scan": args.points, "voxel_m": args.voxel,
-                       "voxels_per_level": n_levels, "parallelism": f"scan-sharded x{world} (no collective)", "batches_in_flight": args.streams},
+                       "voxels_per_level": n_levels, "parallelism": f"scan-sharded x{world} (no collective)",
+                       "batches_in_flight": S,
+                       "launch": "one hipGraphLaunch per step (captured voxelise + forward + select; level sizes stay on the device)"
+                                 if args.mode == "graph" else "eager: ~150 launches + one size query per step"},
+            "repeats": {"timed_regions": len(elapsed_all), "reported": "median",
+                        "scans_per_s": [round(total_scans / e, 1) for e in elapsed_all],
+                        "min": round(total_scans / max(elapsed_all), 1), "max": round(total_scans / min(elapsed_all), 1)},
+            "latency": dict(host, note="one batch in flight: host time to enqueue a batch / time until its results are ready"),
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }

@@ -158,13 +158,15 @@ enum ProfKind { PK_CONV0 = 0, PK_K3 = 1, PK_K2S2 = 2, PK_TCONV = 3, PK_OTHER = 4
 struct ProfRec {
   char name[64];
   int kind, level, K, cin, cout;     // enough to evaluate the algorithmic-bytes formula of SURVEY.md §8(d)
-  int64_t n_in, n_out;
+  int es;                            // bytes per feature-map / weight element (4 fp32, 2 bf16)
   hipEvent_t e0, e1;
 };
 struct Profiler {
-  int mode = 0;                       // 0 off, 1 all tagged launches, 2 only launches whose name contains `filter`
+  int mode = 0;                       // 0 off, 1 all tagged launches, 2 only launches whose name contains `filter` (exact
+                                      // dispatch timing), 3 = filtered launches bracketed by event records (capturable)
   char filter[64] = "";
   std::vector<ProfRec> recs;
+  std::vector<ProfRec> graph_recs;    // brackets recorded while a stream capture was active: re-recorded by every replay
   std::vector<hipEvent_t> pool;
   hipEvent_t get();
 };
@@ -202,8 +204,8 @@ struct ProfScope {
   hipStream_t st;
   int idx = -1;
   bool exact = false;
-  ProfScope(Ctx* c, hipStream_t s, const char* name, int kind, int level, int K, int cin, int cout, int64_t n_in,
-            int64_t n_out);
+  bool in_graph = false;
+  ProfScope(Ctx* c, hipStream_t s, const char* name, int kind, int level, int K, int cin, int cout, int es);
   ~ProfScope();
 };
 

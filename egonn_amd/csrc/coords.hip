@@ -56,14 +56,17 @@ hipEvent_t Profiler::get() {
   (void)hipEventCreate(&e);
   return e;
 }
-ProfScope::ProfScope(Ctx* c, hipStream_t s, const char* name, int kind, int level, int K, int cin, int cout,
-                     int64_t n_in, int64_t n_out)
+ProfScope::ProfScope(Ctx* c, hipStream_t s, const char* name, int kind, int level, int K, int cin, int cout, int es)
     : ctx(c), st(s) {
   if (!c || c->prof.mode == 0) return;
-  if (c->prof.mode == 2 && !strstr(name, c->prof.filter)) return;
+  if (c->prof.mode >= 2 && !strstr(name, c->prof.filter)) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cs);
+  in_graph = cs == hipStreamCaptureStatusActive;
+  if (in_graph && c->prof.mode != 3) return;            // only the event-record brackets can live inside a graph
   ProfRec r;
   snprintf(r.name, sizeof(r.name), "%s", name);
-  r.kind = kind; r.level = level; r.K = K; r.cin = cin; r.cout = cout; r.n_in = n_in; r.n_out = n_out;
+  r.kind = kind; r.level = level; r.K = K; r.cin = cin; r.cout = cout; r.es = es;
   r.e0 = c->prof.get();
   r.e1 = c->prof.get();
   exact = c->prof.mode == 2 && (kind == PK_K3 || kind == PK_K2S2);
@@ -73,15 +76,16 @@ ProfScope::ProfScope(Ctx* c, hipStream_t s, const char* name, int kind, int leve
   } else {
     (void)hipEventRecord(r.e0, s);
   }
-  idx = (int)c->prof.recs.size();
-  c->prof.recs.push_back(r);
+  std::vector<ProfRec>& dst = in_graph ? c->prof.graph_recs : c->prof.recs;
+  idx = (int)dst.size();
+  dst.push_back(r);
 }
 ProfScope::~ProfScope() {
   if (idx < 0) return;
   if (exact) {
     prof_kernel_events()[0] = prof_kernel_events()[1] = nullptr;
   } else {
-    (void)hipEventRecord(ctx->prof.recs[idx].e1, st);
+    (void)hipEventRecord((in_graph ? ctx->prof.graph_recs : ctx->prof.recs)[idx].e1, st);
   }
 }
 hipEvent_t* prof_kernel_events() {

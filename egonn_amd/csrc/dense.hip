@@ -5,6 +5,8 @@
 // models/minkgl.py:167-217 ; MinkowskiBatchNorm (nn.BatchNorm1d eval) ; ECALayer layers/eca_block.py:11-36 ;
 // GeM layers/pooling.py:82-86 ; MinkowskiFunctional.normalize models/minkgl.py:223 ;
 // Quantizer.keypoint_position datasets/quantization.py:60-72,93-103 ; torch.topk eval/evaluate.py:359.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -348,28 +350,28 @@ int eca_apply(const float* x, const float* res, const float* partial, const int3
 
 // ECA gate straight from the per-group column sums of the conv2 epilogue (sconv.hip): the groups of sample b are
 // rg.meta[1+b] .. rg.meta[2+b] (a window never straddles two samples), summed in fixed order => deterministic.
-__global__ __launch_bounds__(256) void eca_gate_groups_kernel(const float* __restrict__ psum,
-                                                               const uint32_t* __restrict__ gmask,
-                                                               const int32_t* __restrict__ meta,
-                                                               const int32_t* __restrict__ boff, int c,
-                                                               const float* __restrict__ wconv, int ksize,
-                                                               float* __restrict__ gate) {
-  __shared__ float red[256];
+__global__ __launch_bounds__(1024) void eca_gate_groups_kernel(const float* __restrict__ psum,
+                                                                const uint32_t* __restrict__ gmask,
+                                                                const int32_t* __restrict__ meta,
+                                                                const int32_t* __restrict__ boff, int c,
+                                                                const float* __restrict__ wconv, int ksize,
+                                                                float* __restrict__ gate) {
+  __shared__ float red[1024];
   __shared__ float mean[256];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int g0 = meta[1 + b], g1 = meta[2 + b];
   const int32_t cntr = boff[b + 1] - boff[b];
-  const int nsl = 256 / c, sl = tid / c, ch = tid - sl * c;     // c <= 256, power of two
-  // fixed order per slice; the loads of 8 groups are in flight together (the loop used to walk ~100 dependent loads)
+  const int nsl = 1024 / c, sl = tid / c, ch = tid - sl * c;    // c <= 256, power of two: 4..32 slices of groups
+  // fixed order per slice; the loads of 4 groups are in flight together
   float acc = 0.f;
-  if (sl < nsl) {
+  {
     int g = g0 + sl;
-    for (; g + 7 * nsl < g1; g += 8 * nsl) {
-      float v[8];
+    for (; g + 3 * nsl < g1; g += 4 * nsl) {
+      float v[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (gmask[g + u * nsl] >> 31) ? psum[(int64_t)(g + u * nsl) * c + ch] : 0.f;
+      for (int u = 0; u < 4; ++u) v[u] = (gmask[g + u * nsl] >> 31) ? psum[(int64_t)(g + u * nsl) * c + ch] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += v[u];
+      for (int u = 0; u < 4; ++u) acc += v[u];
     }
     for (; g < g1; g += nsl)
       if (gmask[g] >> 31) acc += psum[(int64_t)g * c + ch];
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256) void eca_gate_groups_kernel(const float* __res
 int eca_gate_groups(const float* psum, const RowGroups& rg, const int32_t* boff, int B, int c, const float* wconv, int ksize,
                     float* gate, hipStream_t stream) {
   EGONN_REQUIRE(c >= 32 && c <= 256 && 256 % c == 0, EGONN_ERR_INVALID, "eca gate: %d channels unsupported", c);
-  hipLaunchKernelGGL(eca_gate_groups_kernel, dim3(B), dim3(256), 0, stream, psum, rg.gmask, rg.meta, boff, c, wconv, ksize,
+  hipLaunchKernelGGL(eca_gate_groups_kernel, dim3(B), dim3(1024), 0, stream, psum, rg.gmask, rg.meta, boff, c, wconv, ksize,
                      gate);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
@@ -468,12 +470,42 @@ int l2_normalize_rows(float* x, int64_t n, int c, hipStream_t stream, const int3
 }
 
 // ------------------------------------------------------------------ keypoint positions
+// Quantizer.keypoint_position (datasets/quantization.py:60-72 polar, 93-103 Cartesian) of one super-voxel
+__device__ static inline void keypoint_position(uint64_t key, int level, int cb, float ox, float oy, float oz, int mode,
+                                                float s0, float s1, float s2, float* __restrict__ out3) {
+  const int cbL = cb - level;
+  const uint64_t mort = key & ((1ull << (3 * cbL)) - 1);
+  const int32_t bias = 1 << (cb - 1);
+  const float cx = (float)(((int32_t)compact1by2(mort) << level) - bias);
+  const float cy = (float)(((int32_t)compact1by2(mort >> 1) << level) - bias);
+  const float cz = (float)(((int32_t)compact1by2(mort >> 2) << level) - bias);
+  const float stride = (float)(1 << level);
+  // (C + 0.5) * q + offset * (stride * q) / 2, evaluated like the reference (no contraction)
+  const float px = __fadd_rn(__fmul_rn(__fadd_rn(cx, 0.5f), s0), __fdiv_rn(__fmul_rn(ox, __fmul_rn(stride, s0)), 2.f));
+  const float py = __fadd_rn(__fmul_rn(__fadd_rn(cy, 0.5f), s1), __fdiv_rn(__fmul_rn(oy, __fmul_rn(stride, s1)), 2.f));
+  const float pz = __fadd_rn(__fmul_rn(__fadd_rn(cz, 0.5f), s2), __fdiv_rn(__fmul_rn(oz, __fmul_rn(stride, s2)), 2.f));
+  if (mode == 0) {
+    out3[0] = px; out3[1] = py; out3[2] = pz;
+  } else {
+    // polar -> cartesian (reference quantization.py:46-53): theta = pi * (deg - 180) / 180
+    const float theta = __fdiv_rn(__fmul_rn(3.14159265358979323846f, __fadd_rn(px, -180.f)), 180.f);
+    out3[0] = cosf(theta) * py;
+    out3[1] = sinf(theta) * py;
+    out3[2] = pz;
+  }
+}
+
 __global__ void keypoint_kernel(const uint64_t* __restrict__ keys, int64_t n, int level, int cb,
                                 const float* __restrict__ offs, int mode, float s0, float s1, float s2, int ignore,
                                 float* __restrict__ out, const int32_t* __restrict__ n_dev) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n_dev) n = min((int64_t)*n_dev, n);
   if (i >= n) return;
+  const float kox = ignore ? 0.f : offs[3 * i + 0], koy = ignore ? 0.f : offs[3 * i + 1],
+              koz = ignore ? 0.f : offs[3 * i + 2];
+  keypoint_position(keys[i], level, cb, kox, koy, koz, mode, s0, s1, s2, out + 3 * i);
+}
+#if 0
   const int cbL = cb - level;
   const uint64_t mort = keys[i] & ((1ull << (3 * cbL)) - 1);
   const int32_t bias = 1 << (cb - 1);
@@ -497,12 +529,143 @@ __global__ void keypoint_kernel(const uint64_t* __restrict__ keys, int64_t n, in
     out[3 * i + 2] = pz;
   }
 }
+#endif
 int keypoint_positions(const uint64_t* keys, int64_t n, int level, int cb, const float* offsets, int mode,
                        const float* step, int ignore_offsets, float* out, hipStream_t stream, const int32_t* n_dev) {
   if (n == 0) return EGONN_OK;
   const float s0 = step[0], s1 = mode ? step[1] : step[0], s2 = mode ? step[2] : step[0];
   hipLaunchKernelGGL(keypoint_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, keys, n, level, cb, offsets,
                      mode, s0, s1, s2, ignore_offsets, out, n_dev);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ the three local heads in one launch
+// DescriptorDecoder (Linear 64->96, ReLU, Linear 96->128, L2 normalise), KeypointRegressor (64->32, ReLU, 32->3, tanh,
+// Quantizer.keypoint_position) and SigmaRegressor (64->32, ReLU, 32->1, softplus) of models/minkgl.py:175-225,287-308
+// read the local feature map ONCE.  A wave owns 16 rows; operands are fed swapped (D^T = W^T X^T), so a lane ends up with
+// four consecutive hidden units of its row — exactly the B fragment of the next layer's MFMA (contraction index
+// 16t + 4g + u), i.e. the MLPs chain in registers.  Weights are read in nn.Linear (out,in) layout, one float4 per lane.
+struct LocalHeadsArgs {
+  const float* x;                                          // (n, 64)
+  const float *dw0, *db0, *dw1, *db1;                      // descriptor decoder: (96,64),(96),(128,96),(128)
+  const float *kw0, *kb0, *kw1, *kb1;                      // keypoint regressor: (32,64),(32),(3,32),(3)
+  const float *sw0, *sb0, *sw1, *sb1;                      // sigma regressor:    (32,64),(32),(1,32),(1)
+  const uint64_t* keys;                                    // level-3 keys (super-voxel coordinates)
+  const int32_t* n_dev;                                    // device row count (nullable)
+  float *out_desc, *out_kp, *out_sigma;
+  int64_t n;
+  int level, cb, mode, ignore_offsets;
+  float s0, s1, s2;
+};
+template <int CIN, int NT>   // out[nt] = sum_k W[16nt + l15][k] * in[k]  for the 16 rows of the wave (swapped operands)
+__device__ static inline void mlp_layer(const float* __restrict__ W, int rows_w, const f32x4* __restrict__ in, int l15, int g4,
+                                        f32x4* __restrict__ out) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int unit = 16 * nt + l15;
+#pragma unroll
+    for (int t = 0; t < CIN / 16; ++t) {
+      f32x4 wf = {0.f, 0.f, 0.f, 0.f};
+      if (unit < rows_w) wf = *reinterpret_cast<const f32x4*>(W + (int64_t)unit * CIN + 16 * t + 4 * g4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], in[t][u], acc, 0, 0, 0);
+    }
+    out[nt] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void local_heads_kernel(const LocalHeadsArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  int64_t n = p.n;
+  if (p.n_dev) n = min((int64_t)*p.n_dev, n);
+  const int64_t ntiles = (n + 15) >> 4;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t row = tile * 16 + l15;
+    const bool ok = row < n;
+    f32x4 x[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      x[t] = ok ? *reinterpret_cast<const f32x4*>(p.x + row * 64 + 16 * t + 4 * g4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // ---- descriptor decoder + L2 normalisation
+    {
+      f32x4 h[6], o[8];
+      mlp_layer<64, 6>(p.dw0, 96, x, l15, g4, h);
+#pragma unroll
+      for (int nt = 0; nt < 6; ++nt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.db0 + 16 * nt + 4 * g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[nt][r] = fmaxf(h[nt][r] + b[r], 0.f);
+      }
+      mlp_layer<96, 8>(p.dw1, 128, h, l15, g4, o);
+      float ss = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.db1 + 16 * nt + 4 * g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[nt][r] += b[r];
+          ss += o[nt][r] * o[nt][r];
+        }
+      }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);      // F.normalize(p=2, dim=1, eps=1e-12)
+      if (ok) {
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+          *reinterpret_cast<f32x4*>(p.out_desc + row * 128 + 16 * nt + 4 * g4) = o[nt] * inv;
+      }
+    }
+    // ---- keypoint regressor -> position of the keypoint in metres
+    {
+      f32x4 h[2], o[1];
+      mlp_layer<64, 2>(p.kw0, 32, x, l15, g4, h);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.kb0 + 16 * nt + 4 * g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[nt][r] = fmaxf(h[nt][r] + b[r], 0.f);
+      }
+      mlp_layer<32, 1>(p.kw1, 3, h, l15, g4, o);
+      if (ok && g4 == 0) {                                   // lane (row, g = 0) holds output units 0..3
+        const float ox = p.ignore_offsets ? 0.f : tanhf(o[0][0] + p.kb1[0]);
+        const float oy = p.ignore_offsets ? 0.f : tanhf(o[0][1] + p.kb1[1]);
+        const float oz = p.ignore_offsets ? 0.f : tanhf(o[0][2] + p.kb1[2]);
+        keypoint_position(p.keys[row], p.level, p.cb, ox, oy, oz, p.mode, p.s0, p.s1, p.s2, p.out_kp + row * 3);
+      }
+    }
+    // ---- sigma regressor
+    {
+      f32x4 h[2], o[1];
+      mlp_layer<64, 2>(p.sw0, 32, x, l15, g4, h);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.sb0 + 16 * nt + 4 * g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[nt][r] = fmaxf(h[nt][r] + b[r], 0.f);
+      }
+      mlp_layer<32, 1>(p.sw1, 1, h, l15, g4, o);
+      if (ok && g4 == 0) p.out_sigma[row] = apply_act(o[0][0] + p.sb1[0], ACT_SOFTPLUS);
+    }
+  }
+}
+int local_heads_forward(const float* x, int64_t n, const int32_t* n_dev, const float* const* w /*12 pointers*/,
+                        const uint64_t* keys, int level, int cb, int mode, const float* step, int ignore_offsets,
+                        float* out_desc, float* out_kp, float* out_sigma, hipStream_t stream) {
+  if (n == 0) return EGONN_OK;
+  LocalHeadsArgs a;
+  a.x = x; a.n = n; a.n_dev = n_dev;
+  a.dw0 = w[0]; a.db0 = w[1]; a.dw1 = w[2]; a.db1 = w[3];
+  a.kw0 = w[4]; a.kb0 = w[5]; a.kw1 = w[6]; a.kb1 = w[7];
+  a.sw0 = w[8]; a.sb0 = w[9]; a.sw1 = w[10]; a.sb1 = w[11];
+  a.keys = keys; a.level = level; a.cb = cb; a.mode = mode; a.ignore_offsets = ignore_offsets;
+  a.s0 = step[0]; a.s1 = mode ? step[1] : step[0]; a.s2 = mode ? step[2] : step[0];
+  a.out_desc = out_desc; a.out_kp = out_kp; a.out_sigma = out_sigma;
+  const int64_t tiles = cdiv(n, 16);
+  const unsigned grid = (unsigned)std::min<int64_t>(cdiv(tiles, 4), 2048);
+  hipLaunchKernelGGL(local_heads_kernel, dim3(grid), dim3(256), 0, stream, a);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
@@ -516,7 +679,7 @@ __device__ static inline uint32_t sigma_bits(float v) {
   const uint32_t u = __float_as_uint(v);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotone float -> uint
 }
-__global__ __launch_bounds__(256) void select_topk_kernel(const float* __restrict__ sigma, const int32_t* __restrict__ boff,
+__global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restrict__ sigma, const int32_t* __restrict__ boff,
                                                            int k, int S, const float* __restrict__ kp,
                                                            const float* __restrict__ desc, int dc,
                                                            int32_t* __restrict__ sel_rows, int32_t* __restrict__ sel_count,
@@ -528,14 +691,14 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const float* __restric
   const int fresh = S - k;                               // new rows per round (k <= S / 2)
   int have = 0;                                          // best-so-far keys parked in skeys[0 .. have)
   for (int base = 0; base < nb || base == 0; base += fresh) {
-    for (int i = tid; i < S - have; i += 256) {
+    for (int i = tid; i < S - have; i += 1024) {
       const int r = base + i;
       skeys[have + i] = (i < fresh && r < nb) ? (((unsigned long long)sigma_bits(sigma[r0 + r]) << 32) | (unsigned)r) : ~0ull;
     }
     __syncthreads();
     for (int k2 = 2; k2 <= S; k2 <<= 1)
       for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-        for (int e = tid; e < S / 2; e += 256) {
+        for (int e = tid; e < S / 2; e += 1024) {
           const int i = ((e & ~(j2 - 1)) << 1) | (e & (j2 - 1));
           const int q = i | j2;
           const bool up = (i & k2) == 0;
@@ -548,14 +711,14 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const float* __restric
     if (nb == 0) break;
   }
   // ---- selected rows + gathered keypoints / descriptors (padded with -1 / zeros)
-  for (int i = tid; i < k; i += 256) sel_rows[(int64_t)b * k + i] = (i < kk) ? r0 + (int32_t)(skeys[i] & 0xFFFFFFFFu) : -1;
+  for (int i = tid; i < k; i += 1024) sel_rows[(int64_t)b * k + i] = (i < kk) ? r0 + (int32_t)(skeys[i] & 0xFFFFFFFFu) : -1;
   if (tid == 0) sel_count[b] = kk;
   if (out_desc) {
-    for (int64_t t = tid; t < (int64_t)k * dc; t += 256) {
+    for (int64_t t = tid; t < (int64_t)k * dc; t += 1024) {
       const int i = (int)(t / dc), c = (int)(t - (int64_t)i * dc);
       out_desc[((int64_t)b * k + i) * dc + c] = (i < kk) ? desc[(int64_t)(r0 + (int32_t)(skeys[i] & 0xFFFFFFFFu)) * dc + c] : 0.f;
     }
-    for (int t = tid; t < k * 3; t += 256) {
+    for (int t = tid; t < k * 3; t += 1024) {
       const int i = t / 3, c = t - i * 3;
       out_kp[((int64_t)b * k + i) * 3 + c] = (i < kk) ? kp[(int64_t)(r0 + (int32_t)(skeys[i] & 0xFFFFFFFFu)) * 3 + c] : 0.f;
     }
@@ -573,7 +736,7 @@ int select_topk(const float* sigma, const int32_t* boff_dev, int B, int k, const
                                   160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(256), lds, stream, sigma, boff_dev, k, S, kp, desc, dc, sel_rows,
+  hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(1024), lds, stream, sigma, boff_dev, k, S, kp, desc, dc, sel_rows,
                      sel_count, out_kp, out_desc);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;

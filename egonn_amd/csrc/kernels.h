@@ -68,6 +68,11 @@ int add_act(const float* a, const float* b, int64_t n, int relu, float* out, hip
 // keypoint positions (reference datasets/quantization.py:60-72, 93-103)
 int keypoint_positions(const uint64_t* keys, int64_t n, int level, int cb, const float* offsets, int mode,
                        const float* step, int ignore_offsets, float* out, hipStream_t stream, const int32_t* n_dev = nullptr);
+// descriptor decoder + L2 norm, keypoint regressor + keypoint_position, sigma regressor (models/minkgl.py:175-225,287-308)
+// in one launch on the (n,64) local feature map; w: dw0,db0,dw1,db1, kw0,kb0,kw1,kb1, sw0,sb0,sw1,sb1 (nn.Linear layouts)
+int local_heads_forward(const float* x, int64_t n, const int32_t* n_dev, const float* const* w, const uint64_t* keys,
+                        int level, int cb, int mode, const float* step, int ignore_offsets, float* out_desc, float* out_kp,
+                        float* out_sigma, hipStream_t stream);
 // top-k smallest sigma per sample, ascending, ties by row (= Z-order) — eval/evaluate.py:352-361 — and the gather of the
 // selected keypoints / descriptors, one launch (workgroup = scan); out_kp / out_desc nullable
 int select_topk(const float* sigma, const int32_t* boff_dev, int B, int k, const float* kp, const float* desc, int dc,

@@ -18,6 +18,7 @@ using namespace egonn;
 struct egonn_ctx : public Ctx {
   // scratch kept between egonn_forward and its readers
   hipStream_t plan_stream = nullptr; // stream the current plan was enqueued on (lazy size queries synchronise it)
+
   void* level_feat[EGONN_NUM_LEVELS] = {};
   int level_ch[EGONN_NUM_LEVELS] = {};
   int level_bf16 = 0;                // precision of level_feat (last forward)
@@ -127,7 +128,9 @@ API void egonn_ctx_destroy(egonn_ctx* c) {
   if (c->dev_counts) (void)hipFree(c->dev_counts);
   if (c->dev_pairs) (void)hipFree(c->dev_pairs);
   if (c->conv0_lut) (void)hipFree(c->conv0_lut);
+
   for (auto& r : c->prof.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto& r : c->prof.graph_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : c->prof.pool) (void)hipEventDestroy(e);
   delete c;
 }
@@ -683,13 +686,32 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   }
   FALLOC(x0, n0 * 32);
   {
-    ProfScope ps(c, st, "conv0_k5_kernel/L0", PK_CONV0, 0, 125, 1, 32, n0, n0);
+    ProfScope ps(c, st, "conv0_k5_kernel/L0", PK_CONV0, 0, 125, 1, 32, (int)es);
     EGONN_TRY(conv0_k5_forward(c, f0, m->conv0, 32, m->bn[0].scale, m->bn[0].shift, 1, x0, bf16, st));
   }
   const void* x[8] = {x0};
   c->level_feat[0] = x0;
   c->level_ch[0] = 32;
   c->level_bf16 = bf16;
+  // ---- local head, descriptor / keypoint / sigma regressors (models/minkgl.py:287-308)
+  auto local_head = [&](hipStream_t st) -> int {
+    const int64_t n3 = P.cap[3], n4 = P.cap[4];
+    FALLOC(l4, n4 * LOCAL_CH);
+    EGONN_TRY(dense_forward_ex(x[4], bf16, n4, 128, m->l1x1[4], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0, l4,
+                               bf16, st, cnt + 4));
+    FALLOC(u3, n3 * LOCAL_CH);
+    EGONN_TRY(sconv_map(c, 2, 3, l4, nullptr, bf16 ? m->q_lt[4] : m->p_lt[4], LOCAL_CH, LOCAL_CH, bf16, nullptr, nullptr, 0, u3,
+                        nullptr, nullptr, 0, st));
+    WALLOC(l3, n3 * LOCAL_CH);
+    EGONN_TRY(dense_forward_ex(x[3], bf16, n3, 64, m->l1x1[3], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u3, bf16, l3, 0, st, cnt + 3));
+    EGONN_REQUIRE(m->ldec.cin == 64 && m->ldec.mid == 96 && m->ldec.cout == 128 && m->kp.mid == 32 && m->sg.mid == 32,
+                  EGONN_ERR_STATE, "local heads: unexpected layer sizes");
+    const float* hw[12] = {m->ldec.w0, m->ldec.b0, m->ldec.w1, m->ldec.b1, m->kp.w0, m->kp.b0, m->kp.w1, m->kp.b1,
+                           m->sg.w0, m->sg.b0, m->sg.w1, m->sg.b1};
+    EGONN_TRY(local_heads_forward(l3, n3, cnt + 3, hw, P.lv[3].keys, 3, P.coord_bits, quant_mode, step,
+                                  (flags & EGONN_FLAG_IGNORE_KP_REGRESSOR) ? 1 : 0, out_desc, out_kp, out_sigma, st));
+    return EGONN_OK;
+  };
   for (int i = 1; i <= 7; ++i) {
     const BlockRef& b = m->blk[i];
     const Level& L = P.lv[i];
@@ -698,7 +720,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     char tag[64];
     {
       snprintf(tag, sizeof(tag), "sconv_rg_kernel<%d,%d>/L%d/k2s2", b.cin, b.cin, i);
-      ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, P.cap[i - 1], n);
+      ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, (int)es);
       EGONN_TRY(sconv_map(c, 1, i, x[i - 1], nullptr, bf16 ? m->q_convs[i] : m->p_convs[i], b.cin, b.cin, bf16, m->bn[i].scale,
                           m->bn[i].shift, 1, y, nullptr, nullptr, 0, st));
     }
@@ -706,7 +728,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     FALLOC(t1, n * b.cout);
     {
       snprintf(tag, sizeof(tag), "sconv_rg_kernel<%d,%d>/L%d/k3.conv1", b.cin, b.cout, i);
-      ProfScope ps(c, st, tag, PK_K3, i, 27, b.cin, b.cout, n, n);
+      ProfScope ps(c, st, tag, PK_K3, i, 27, b.cin, b.cout, (int)es);
       EGONN_TRY(sconv_map(c, 0, i, y, nullptr, bf16 ? m->q_c1[i] : m->p_c1[i], b.cin, b.cout, bf16, b.n1.scale, b.n1.shift, 1, t1,
                           nullptr, nullptr, 0, st));
     }
@@ -714,7 +736,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     WALLOC(psum, (size_t)L.rg27.cap_groups * b.cout);
     {
       snprintf(tag, sizeof(tag), "sconv_rg_kernel<%d,%d>/L%d/k3.conv2", b.cout, b.cout, i);
-      ProfScope ps(c, st, tag, PK_K3, i, 27, b.cout, b.cout, n, n);
+      ProfScope ps(c, st, tag, PK_K3, i, 27, b.cout, b.cout, (int)es);
       EGONN_TRY(sconv_map(c, 0, i, t1, nullptr, bf16 ? m->q_c2[i] : m->p_c2[i], b.cout, b.cout, bf16, b.n2.scale, b.n2.shift, 0, t2,
                           psum, nullptr, 0, st));
     }
@@ -732,7 +754,11 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     x[i] = xo;
     c->level_feat[i] = xo;
     c->level_ch[i] = b.cout;
+    // (measured: forking the local head onto a second stream here — a parallel branch of the captured graph — shortens
+    //  one batch by 4 % but costs 28 % throughput with three graphs in flight: multi-branch graphs launch 4x slower and
+    //  serialise against each other; the overlap comes from the batches in flight instead)
   }
+  if (do_local) EGONN_TRY(local_head(st));
 
   // ---- global head + decoder + GeM (models/minkgl.py:46-60, 207-225; layers/pooling.py:82-86)
   if (do_global) {
@@ -759,28 +785,6 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     EGONN_TRY(gem_finish(gp, P.lv[5].boff, B, GLOBAL_DIM, m->gem_p, out_global, st));
   }
 
-  // ---- local head, descriptor / keypoint / sigma regressors (models/minkgl.py:287-308)
-  if (do_local) {
-    const int64_t n3 = P.cap[3], n4 = P.cap[4];
-    FALLOC(l4, n4 * LOCAL_CH);
-    EGONN_TRY(dense_forward_ex(x[4], bf16, n4, 128, m->l1x1[4], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0, l4,
-                               bf16, st, cnt + 4));
-    FALLOC(u3, n3 * LOCAL_CH);
-    EGONN_TRY(sconv_map(c, 2, 3, l4, nullptr, bf16 ? m->q_lt[4] : m->p_lt[4], LOCAL_CH, LOCAL_CH, bf16, nullptr, nullptr, 0, u3,
-                        nullptr, nullptr, 0, st));
-    WALLOC(l3, n3 * LOCAL_CH);
-    EGONN_TRY(dense_forward_ex(x[3], bf16, n3, 64, m->l1x1[3], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u3, bf16, l3, 0, st, cnt + 3));
-    WALLOC(dh, n3 * m->ldec.mid);
-    EGONN_TRY(run_mlp(m->ldec, l3, n3, ACT_NONE, dh, out_desc, st, cnt + 3));
-    EGONN_TRY(l2_normalize_rows(out_desc, n3, LOCAL_DIM, st, cnt + 3));
-    WALLOC(kh, n3 * m->kp.mid);
-    WALLOC(ko, n3 * 3);
-    EGONN_TRY(run_mlp(m->kp, l3, n3, ACT_TANH, kh, ko, st, cnt + 3));
-    EGONN_TRY(keypoint_positions(P.lv[3].keys, n3, 3, P.coord_bits, ko, quant_mode, step,
-                                 (flags & EGONN_FLAG_IGNORE_KP_REGRESSOR) ? 1 : 0, out_kp, st, cnt + 3));
-    WALLOC(sh, n3 * m->sg.mid);
-    EGONN_TRY(run_mlp(m->sg, l3, n3, ACT_SOFTPLUS, sh, out_sigma, st, cnt + 3));
-  }
 #undef WALLOC
 #undef FALLOC
   return EGONN_OK;
@@ -820,45 +824,59 @@ API int egonn_topk_rows(const float* sigma, const int32_t* row_offsets, int batc
 
 // ------------------------------------------------------------------------------------------ launch timing (bench.py)
 API int egonn_profile_enable(egonn_ctx* c, int mode, const char* filter) {
-  EGONN_REQUIRE(c && mode >= 0 && mode <= 2, EGONN_ERR_INVALID, "profile_enable: bad argument");
+  EGONN_REQUIRE(c && mode >= 0 && mode <= 3, EGONN_ERR_INVALID, "profile_enable: bad argument");
   c->prof.mode = mode;
   snprintf(c->prof.filter, sizeof(c->prof.filter), "%s", filter ? filter : "");
   return EGONN_OK;
 }
 
 // Drains the timing records collected since the last fetch.  [SYNC]  Returns up to `cap` records:
-// names (cap x 64 chars), milliseconds, algorithmic bytes (P*Cin*4 + N_out*Cout*4 + K*Cin*Cout*4 + 8*P) and flops
+// names (cap x 64 chars), milliseconds, algorithmic bytes (P*Cin*e + N_out*Cout*e + K*Cin*Cout*e + 8*P; e = 4 fp32 / 2 bf16) and flops
 // (2*P*Cin*Cout) of every launch; *n = number of records written.
 API int egonn_profile_fetch(egonn_ctx* c, int cap, int* n, char* names, float* ms, double* bytes, double* flops,
                             void* stream) {
   EGONN_REQUIRE(c && n && names && ms && bytes && flops, EGONN_ERR_INVALID, "profile_fetch: null argument");
   HIP_CHECK(hipSetDevice(c->device));
-  if (c->plan.valid) EGONN_TRY(count_map_pairs(c, (hipStream_t)stream));   // [0] = first-layer pairs, [l] = k=3 map of level l
+  Plan& P = c->plan;
+  if (P.valid) {
+    if (P.built_reserved) P.exact = false;      // replays rebuilt the plan: read this batch's sizes
+    EGONN_TRY(plan_sync(c, (hipStream_t)stream));
+    EGONN_TRY(count_map_pairs(c, (hipStream_t)stream));   // [0] = first-layer pairs, [l] = k=3 map of level l
+  }
   HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   unsigned long long pairs[16];
   HIP_CHECK(hipMemcpy(pairs, c->dev_pairs, sizeof(pairs), hipMemcpyDeviceToHost));
   int w = 0;
-  for (auto& r : c->prof.recs) {
+  std::vector<ProfRec> all(c->prof.recs);
+  all.insert(all.end(), c->prof.graph_recs.begin(), c->prof.graph_recs.end());   // the last replay's brackets
+  const size_t n_plain = c->prof.recs.size();
+  size_t ri = 0;
+  for (auto& r : all) {
+    const bool plain = ri++ < n_plain;
     float t = 0.f;
-    HIP_CHECK(hipEventSynchronize(r.e1));
-    HIP_CHECK(hipEventElapsedTime(&t, r.e0, r.e1));
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) {
+      (void)hipGetLastError();
+      if (plain) { c->prof.pool.push_back(r.e0); c->prof.pool.push_back(r.e1); }
+      continue;                                          // an event a replay has not recorded (yet)
+    }
     if (w < cap) {
+      // output rows and map pairs of the launch, from the plan's true sizes
+      const double n_out = (double)P.lv[r.level].n;
       double Pn = 0;
       switch (r.kind) {
         case PK_CONV0: Pn = (double)pairs[0]; break;
         case PK_K3: Pn = (double)pairs[r.level]; break;
-        case PK_K2S2: Pn = (double)r.n_in; break;
-        case PK_TCONV: Pn = (double)r.n_out; break;
-        default: Pn = (double)r.n_in; break;
+        case PK_K2S2: Pn = (double)P.lv[r.level - 1].n; break;      // every input voxel feeds exactly one parent
+        case PK_TCONV: Pn = n_out; break;
+        default: Pn = n_out; break;
       }
       snprintf(names + (size_t)w * 64, 64, "%s", r.name);
       ms[w] = t;
-      bytes[w] = Pn * r.cin * 4.0 + (double)r.n_out * r.cout * 4.0 + (double)r.K * r.cin * r.cout * 4.0 + 8.0 * Pn;
+      bytes[w] = Pn * r.cin * r.es + n_out * r.cout * r.es + (double)r.K * r.cin * r.cout * r.es + 8.0 * Pn;
       flops[w] = 2.0 * Pn * r.cin * r.cout;
       ++w;
     }
-    c->prof.pool.push_back(r.e0);
-    c->prof.pool.push_back(r.e1);
+    if (plain) { c->prof.pool.push_back(r.e0); c->prof.pool.push_back(r.e1); }
   }
   c->prof.recs.clear();
   *n = w;

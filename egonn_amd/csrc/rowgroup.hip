@@ -52,9 +52,12 @@ struct RGArgs {
   int njobs, B, nblocks;
 };
 
-__global__ __launch_bounds__(256) void rowgroup_build_kernel(RGArgs a) {
+static constexpr int RG_THREADS = 1024;                 // 16 waves per window: the per-group passes are latency chains
+static constexpr int RG_WAVES = RG_THREADS / 64;
+__global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
   __shared__ unsigned long long skey[RG_MAX_WIN];
   __shared__ uint32_t smask[RG_MAX_WIN];
+  __shared__ __attribute__((aligned(16))) int32_t stile[RG_WAVES * 27 * 16];
   __shared__ int32_t s_info[4];
   const int tid = threadIdx.x, lane = tid & 63;
   int j = 0;
@@ -101,31 +104,55 @@ __global__ __launch_bounds__(256) void rowgroup_build_kernel(RGArgs a) {
   const int r0 = J.boff[sb] + (w - s_info[1]) * WIN;
   const int rows = min(WIN, J.boff[sb + 1] - r0);
 
-  // ---- presence masks: one thread per row, the K table entries of a row are independent loads (unrolled)
+  // ---- presence masks.  A wave reads whole table rows with consecutive lanes (K = 27: 2 rows per load, lanes 0-26 and
+  // 32-58; K = 8: 8 rows per load) — each load touches 2-4 cache lines instead of 64 — and a ballot IS the mask.
   const int32_t* src = J.nbr + (int64_t)r0 * K;
-  auto row_mask = [&](const int32_t* rp, auto KK) {
-    constexpr int kk = decltype(KK)::value;
-    int32_t v[kk];
+  const int wave = tid >> 6;
+  // (8 loads are issued before the first ballot: a dependent load -> ballot -> LDS chain per row was latency bound)
+  if (K == 27) {
+    const int half = lane >> 5, kk = lane & 31;
+    for (int rb = wave * 16; rb < WIN; rb += 16 * RG_WAVES) {   // waves x 8 loads x 2 rows
+      int32_t v[8];
 #pragma unroll
-    for (int k = 0; k < kk; ++k) v[k] = rp[k];
-    uint32_t m = 0;
+      for (int u = 0; u < 8; ++u) {
+        const int r = rb + 2 * u + half;
+        v[u] = (r < rows && kk < 27) ? src[r * 27 + kk] : -1;
+      }
 #pragma unroll
-    for (int k = 0; k < kk; ++k) m |= (v[k] >= 0 ? 1u : 0u) << k;
-    return m;
-  };
-  for (int i = tid; i < WIN; i += 256) {
-    uint32_t m = 0;
-    if (i < rows) m = (K == 27) ? row_mask(src + i * 27, std::integral_constant<int, 27>{}) : row_mask(src + i * 8, std::integral_constant<int, 8>{});
-    smask[i] = m;
+      for (int u = 0; u < 8; ++u) {
+        const int r = rb + 2 * u + half;
+        const unsigned long long bal = __ballot(v[u] >= 0);
+        if (kk == 0 && r < WIN) smask[r] = (uint32_t)(bal >> (32 * half)) & 0x07FFFFFFu;
+      }
+    }
+  } else {
+    const int sub = lane >> 3, kk = lane & 7;
+    for (int rb = wave * 64; rb < WIN; rb += 64 * RG_WAVES) {   // waves x 8 loads x 8 rows
+      int32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = rb + 8 * u + sub;
+        v[u] = (r < rows) ? src[r * 8 + kk] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = rb + 8 * u + sub;
+        const unsigned long long bal = __ballot(v[u] >= 0);
+        if (kk == 0 && r < WIN) smask[r] = (uint32_t)(bal >> (8 * sub)) & 0xFFu;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < WIN; i += RG_THREADS) {
     unsigned long long key = ~0ull;
-    if (i < rows) key = ((unsigned long long)(K == 27 ? remap27(m) : m) << 16) | (unsigned)i;
+    if (i < rows) key = ((unsigned long long)(K == 27 ? remap27(smask[i]) : smask[i]) << 16) | (unsigned)i;
     skey[i] = key;
   }
   __syncthreads();
   // ---- bitonic sort of the window (ascending; padding keys are all-ones and end up last)
   for (int k2 = 2; k2 <= WIN; k2 <<= 1) {
     for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-      for (int e = tid; e < WIN / 2; e += 256) {
+      for (int e = tid; e < WIN / 2; e += RG_THREADS) {
         const int i = ((e & ~(j2 - 1)) << 1) | (e & (j2 - 1));
         const int p = i | j2;
         const bool up = (i & k2) == 0;
@@ -137,7 +164,7 @@ __global__ __launch_bounds__(256) void rowgroup_build_kernel(RGArgs a) {
   }
   // ---- perm + group masks
   const int64_t gbase = (int64_t)w * GPW;
-  for (int i = tid; i < WIN; i += 256) {                // WIN is a multiple of 256: all lanes stay in the loop
+  for (int i = tid; i < WIN; i += RG_THREADS) {         // WIN is a multiple of 64: whole waves stay in the loop
     const unsigned long long key = skey[i];
     const bool valid = key != ~0ull;
     const int lr = (int)(key & 0xFFFFu);
@@ -147,23 +174,41 @@ __global__ __launch_bounds__(256) void rowgroup_build_kernel(RGArgs a) {
     for (int o = 1; o < 16; o <<= 1) m |= __shfl_xor(m, o, 64);
     if ((i & 15) == 0) J.gmask[gbase + (i >> 4)] = m;
   }
-  // ---- sorted table, one 64-byte line per (group, offset): thread = sorted slot, K independent loads then K stores
+  // ---- sorted table, one 64-byte line per (group, offset).  Per group a wave reads its 16 rows as whole rows (as
+  // above), transposes them through a wave-private LDS tile [k][slot] and writes the group's contiguous K x 64-byte
+  // block with 16-byte stores.
   const int ngr = (rows + 15) >> 4;                     // groups with real rows
-  auto emit = [&](int i, auto KK) {
-    constexpr int kk = decltype(KK)::value;
-    const unsigned long long key = skey[i];
-    const bool valid = key != ~0ull;
-    const int32_t* rp = src + (int)(key & 0xFFFFu) * kk;
-    int32_t v[kk];
+  int32_t* tile = reinterpret_cast<int32_t*>(stile) + wave * (27 * 16);
+  for (int gl = wave; gl < ngr; gl += RG_WAVES) {
+    if (K == 27) {
+      const int half = lane >> 5, kk = lane & 31;
+      unsigned long long key[8];
+      int32_t v[8];
 #pragma unroll
-    for (int k = 0; k < kk; ++k) v[k] = valid ? rp[k] + 1 : 0;
-    int32_t* dst = J.snbr + (gbase + (i >> 4)) * kk * 16 + (i & 15);
+      for (int h = 0; h < 8; ++h) key[h] = skey[gl * 16 + 2 * h + half];
 #pragma unroll
-    for (int k = 0; k < kk; ++k) dst[k * 16] = v[k];
-  };
-  for (int i = tid; i < ngr * 16; i += 256) {
-    if (K == 27) emit(i, std::integral_constant<int, 27>{});
-    else emit(i, std::integral_constant<int, 8>{});
+      for (int h = 0; h < 8; ++h) v[h] = (kk < 27 && key[h] != ~0ull) ? src[(int)(key[h] & 0xFFFFu) * 27 + kk] + 1 : 0;
+#pragma unroll
+      for (int h = 0; h < 8; ++h)
+        if (kk < 27) tile[kk * 16 + 2 * h + half] = v[h];
+    } else {
+      const int sub = lane >> 3, kk = lane & 7;
+      unsigned long long key[2];
+      int32_t v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) key[h] = skey[gl * 16 + 8 * h + sub];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) v[h] = (key[h] != ~0ull) ? src[(int)(key[h] & 0xFFFFu) * 8 + kk] + 1 : 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) tile[kk * 16 + 8 * h + sub] = v[h];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int4* dst = reinterpret_cast<int4*>(J.snbr + (gbase + gl) * K * 16);
+    const int n16 = K * 4;
+    for (int e = lane; e < n16; e += 64) dst[e] = reinterpret_cast<const int4*>(tile)[e];
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -186,7 +231,7 @@ int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream) {
   }
   a.nblocks = nb;
   if (nb == 0) return EGONN_OK;
-  hipLaunchKernelGGL(rowgroup_build_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(rowgroup_build_kernel, dim3((unsigned)nb), dim3(RG_THREADS), 0, stream, a);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }

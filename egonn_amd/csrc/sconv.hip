@@ -116,12 +116,13 @@ struct SconvArgs {
 // take 1/KSP of the input-channel blocks and the partial accumulators are summed through LDS in fixed order — shorter
 // dependent item chains per wave and KSP x the waves in flight (the tail levels have a few hundred groups: without the
 // split one wave per SIMD walked 40 dependent items while the chip idled).
-template <int CIN, int COUT, bool BF16, int D, int KSP>
+template <int CIN, int COUT, bool BF16, int D, int KSC, int KSK>
 __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
   constexpr int NS = COUT / 32, NCB = CIN / 32;
-  constexpr int NCBL = NCB / KSP;                        // channel blocks per wave
+  constexpr int KSP = KSC * KSK;                         // waves per tile: KSC-way channel-block split x KSK-way offset split
+  constexpr int NCBL = NCB / KSC;                        // channel blocks per wave
   constexpr int TPW = 4 / KSP;                           // tiles per workgroup
-  static_assert(NCB % KSP == 0 && 4 % KSP == 0, "bad channel split");
+  static_assert(NCB % KSC == 0 && 4 % KSP == 0, "bad work split");
   constexpr int ES = BF16 ? 2 : 4;                       // bytes per feature element
   constexpr int ALD = BF16 ? 1 : 2;                      // b128 loads of A per lane per item
   constexpr int WLD = BF16 ? 2 : 4;                      // b128 loads of W per lane per item
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
   const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3; // gridDim.x is a multiple of 8
   const int cpx = (ntask + 7) >> 3;
   const int sub = wave % KSP;
+  const int subc = sub % KSC, subk = sub / KSC;          // channel-block share / offset share of this wave
   int par = 0;
 
   // ---- epilogue: BN scale/shift (+ReLU), one store per tile; optional per-group column sums
@@ -226,6 +228,15 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
 
       // ---- item generator (scalar): set bits of the group mask x this wave's channel blocks
       uint32_t mk = gm & 0x07FFFFFFu;
+      if constexpr (KSK > 1) {                           // this wave's share of the offsets: every KSK-th present one
+        uint32_t rest = mk, mine = 0;
+        for (int ord = 0; rest; ++ord) {
+          const uint32_t low = rest & (0u - rest);
+          rest ^= low;
+          if (ord % KSK == subk) mine |= low;
+        }
+        mk = mine;
+      }
       const int n_items = __builtin_amdgcn_readfirstlane(__popc(mk) * NCBL);
       int gen_k = 0, gen_cb = 0;
       // pending item (the one whose loads are issued next)
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
         gen_k = take ? __builtin_ctz(mk | 0x80000000u) : gen_k;
         mk = take ? (mk & (mk - 1)) : mk;
         const int krow = valid ? gen_k : K;
-        const int cb = sub * NCBL + gen_cb;
+        const int cb = subc * NCBL + gen_cb;
         pend_idx = ldsw[krow * 16 + l15];
         pend_acb = (uint32_t)(cb * 32 * ES);
         pend_woff = (uint32_t)(((gen_k * NCB + cb) * NS + ns)) * ITEM_BYTES;
@@ -570,10 +581,10 @@ static int launch_wg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
 }
 
 // ------------------------------------------------------------------ launcher
-template <int CIN, int COUT, bool BF16, int KSP>
+template <int CIN, int COUT, bool BF16, int KSC, int KSK>
 static int launch_rg_ksp(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
   constexpr int D = BF16 ? 4 : 3;
-  constexpr int NS = COUT / 32;
+  constexpr int NS = COUT / 32, KSP = KSC * KSK;
   const size_t lds = 4 * 28 * 16 * sizeof(int32_t) + (KSP > 1 ? 2 * 4 * 2 * 64 * sizeof(f32x4) : 0);
   const int64_t ntask = cdiv(groups_hint * NS * KSP, 4);
   // one workgroup per task up to a cap: the hardware dispatcher then balances the uneven tasks (a grid of only the
@@ -582,10 +593,10 @@ static int launch_rg_ksp(const SconvArgs& a, int64_t groups_hint, hipStream_t st
   grid = (grid + 7) / 8 * 8;
   hipEvent_t* pev = prof_kernel_events();
   if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
-    hipExtLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP>), dim3((unsigned)grid), dim3(256), lds, stream, pev[0], pev[1], 0, a);
+    hipExtLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSC, KSK>), dim3((unsigned)grid), dim3(256), lds, stream, pev[0], pev[1], 0, a);
     pev[0] = pev[1] = nullptr;
   } else {
-    hipLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSC, KSK>), dim3((unsigned)grid), dim3(256), lds, stream, a);
   }
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
@@ -594,8 +605,9 @@ template <int CIN, int COUT, bool BF16>
 static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
   constexpr int NCB = CIN / 32;
   // the input-channel blocks are always split over the waves of a workgroup (a function of the shape only, so results
-  // never depend on launch sizes): measured faster at every level, 12 % on the 84 k-row 64->64 layer, 40 % on level 4
-  return launch_rg_ksp<CIN, COUT, BF16, (NCB >= 4 ? 4 : NCB)>(a, groups_hint, stream);
+  // never depend on launch sizes): measured faster at every level, 12 % on the 84 k-row 64->64 layer, 40 % on level 4.
+  // Splitting the kernel offsets as well (KSK = 2 / 4) measured neutral to 50 % slower (profiles/r02 notes in DESIGN).
+  return launch_rg_ksp<CIN, COUT, BF16, (NCB >= 4 ? 4 : NCB), 1>(a, groups_hint, stream);
 }
 
 bool sconv_rg_supported(int cin, int cout) {

@@ -210,6 +210,11 @@ class GraphExtractor:
             _lib.check(ctx.lib.egonn_graph_launch(self.graph, self.stream.cuda_stream))
         return self.out
 
+    def replay(self):
+        """Replay the captured step on the batch that is already in the static input buffers (no copies)."""
+        _lib.check(self.ctx.lib.egonn_graph_launch(self.graph, self.stream.cuda_stream))
+        return self.out
+
     def status(self):
         """[SYNC] wait for the last run and raise if its batch was out of range / did not fit."""
         with torch.cuda.stream(self.stream):

@@ -281,8 +281,10 @@ int egonn_recall_counts(const int32_t* nn_index, const float* query_positions, c
                         int32_t* out_true_positives, void* stream);
 
 /* ------------------------------------------------------------------ launch timing (bench.py roofline leg)
- * mode 0: off; 1: time every tagged sparse-conv launch; 2: only launches whose tag contains `filter`.
- * Timing = HIP events recorded on the caller's stream around the launch. */
+ * mode 0: off; 1: time every tagged sparse-conv launch (event records around it); 2: only launches whose tag contains
+ * `filter`, with the events attached to the kernel dispatch itself (the kernel's own begin..end, also when other streams
+ * share the GPU); 3: like 2 but as event-record brackets, which a stream capture turns into graph nodes — the records of
+ * a captured sequence are re-recorded by every replay and egonn_profile_fetch returns the LAST replay's durations. */
 int egonn_profile_enable(egonn_ctx* ctx, int mode, const char* filter);
 /* Drain the records collected since the last fetch.  [SYNC]  names: cap x 64 chars.  bytes = the algorithmic
  * bytes of SURVEY.md §8(d) (P*Cin*4 + N_out*Cout*4 + K*Cin*Cout*4 + 8*P), flops = 2*P*Cin*Cout. */

@@ -8,9 +8,9 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py --layer-table $OUT/${TAG}_layers.json > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python bench.py ${BENCH_ARGS:-} --layer-table $OUT/${TAG}_layers.json > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -1 $OUT/${TAG}_bench.json | cut -c1-600
-BENCH="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python $REPO/bench.py ${BENCH_ARGS:-} --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt -- $BENCH > $OUT/${TAG}_kt.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_pf -o pf -- $BENCH > $OUT/${TAG}_pf.log 2>&1
