@@ -116,13 +116,12 @@ struct SconvArgs {
 // take 1/KSP of the input-channel blocks and the partial accumulators are summed through LDS in fixed order — shorter
 // dependent item chains per wave and KSP x the waves in flight (the tail levels have a few hundred groups: without the
 // split one wave per SIMD walked 40 dependent items while the chip idled).
-template <int CIN, int COUT, bool BF16, int D, int KSC, int KSK>
+template <int CIN, int COUT, bool BF16, int D, int KSP>
 __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
   constexpr int NS = COUT / 32, NCB = CIN / 32;
-  constexpr int KSP = KSC * KSK;                         // waves per tile: KSC-way channel-block split x KSK-way offset split
-  constexpr int NCBL = NCB / KSC;                        // channel blocks per wave
+  constexpr int NCBL = NCB / KSP;                        // channel blocks per wave
   constexpr int TPW = 4 / KSP;                           // tiles per workgroup
-  static_assert(NCB % KSC == 0 && 4 % KSP == 0, "bad work split");
+  static_assert(NCB % KSP == 0 && 4 % KSP == 0, "bad channel split");
   constexpr int ES = BF16 ? 2 : 4;                       // bytes per feature element
   constexpr int ALD = BF16 ? 1 : 2;                      // b128 loads of A per lane per item
   constexpr int WLD = BF16 ? 2 : 4;                      // b128 loads of W per lane per item
@@ -147,22 +146,16 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
   const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3; // gridDim.x is a multiple of 8
   const int cpx = (ntask + 7) >> 3;
   const int sub = wave % KSP;
-  const int subc = sub % KSC, subk = sub / KSC;          // channel-block share / offset share of this wave
   int par = 0;
 
   // ---- epilogue: BN scale/shift (+ReLU), one store per tile; optional per-group column sums
-  auto epilogue = [&](const f32x4 (&acc)[2], int g, int ns) {
-    const int32_t row = p.perm[(int64_t)g * 16 + l15];
+  auto epilogue = [&](const f32x4 (&acc)[2], int g, int ns, int32_t row, const f32x4 (&sc)[2], const f32x4 (&sh)[2]) {
     float sums[2][4];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int c0 = ns * 32 + nt * 16 + 4 * g4;
       f32x4 v = acc[nt];
-      if (p.scale) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c0);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + c0);
-        v = v * sc + sh;
-      }
+      if (p.scale) v = v * sc[nt] + sh[nt];
       if (p.relu) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
@@ -203,8 +196,32 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
     const int task = xcd * cpx + lt;
     const int tile = task * TPW + wave / KSP;
     const int g = tile / NS, ns = tile - g * NS;
+    // Everything that does not depend on other loads is requested up front: the group mask, the group's neighbour
+    // rows, the output rows of the epilogue and the BatchNorm vectors (a small launch is a chain of memory latencies —
+    // levels 5-7 ran 20 us per launch for < 2 us of MFMA work when these loads were issued one after the other)
+    const bool tile_ok = task < ntask && tile < ntiles;
     uint32_t gm = 0;
-    if (task < ntask && tile < ntiles) gm = __builtin_amdgcn_readfirstlane(p.gmask[g]);
+    int4 v0 = make_int4(0, 0, 0, 0), v1 = make_int4(0, 0, 0, 0);
+    int32_t orow = -1;
+    f32x4 bsc[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, bsh[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (tile_ok) {
+      const int4* src = reinterpret_cast<const int4*>(p.snbr + (int64_t)g * K * 16);
+      const int n16 = K * 4;                             // 16-byte pieces
+      gm = p.gmask[g];
+      if (lane < n16) v0 = src[lane];
+      if (lane + 64 < n16) v1 = src[lane + 64];
+      if (sub == 0) {
+        orow = p.perm[(int64_t)g * 16 + l15];
+        if (p.scale) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            bsc[nt] = *reinterpret_cast<const f32x4*>(p.scale + ns * 32 + nt * 16 + 4 * g4);
+            bsh[nt] = *reinterpret_cast<const f32x4*>(p.shift + ns * 32 + nt * 16 + 4 * g4);
+          }
+        }
+      }
+    }
+    gm = __builtin_amdgcn_readfirstlane(gm);
     const bool active = (gm >> 31) != 0;
     if constexpr (KSP == 1) {
       if (!active) continue;                             // no barrier in this configuration: waves are independent
@@ -212,13 +229,10 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
     if (KSP == 1 || active) {
-      // ---- stage the group's neighbour rows (K x 16 ints) + one all-absent row into wave-private LDS
+      // ---- the group's neighbour rows (K x 16 ints) + one all-absent row -> wave-private LDS (an inactive group's
+      // table is never indexed: its mask has no offsets)
       {
-        const int4* src = reinterpret_cast<const int4*>(p.snbr + (int64_t)g * K * 16);
-        const int n16 = K * 4;                           // 16-byte pieces
-        int4 v0 = make_int4(0, 0, 0, 0), v1 = make_int4(0, 0, 0, 0);
-        if (lane < n16) v0 = src[lane];
-        if (lane + 64 < n16) v1 = src[lane + 64];
+        if (!active) { v0 = make_int4(0, 0, 0, 0); v1 = make_int4(0, 0, 0, 0); }
         reinterpret_cast<int4*>(ldsw)[lane] = v0;        // lanes >= n16 write zeros: row K (all absent) and beyond
         if (lane + 64 < 28 * 4) reinterpret_cast<int4*>(ldsw)[lane + 64] = v1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -228,15 +242,6 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
 
       // ---- item generator (scalar): set bits of the group mask x this wave's channel blocks
       uint32_t mk = gm & 0x07FFFFFFu;
-      if constexpr (KSK > 1) {                           // this wave's share of the offsets: every KSK-th present one
-        uint32_t rest = mk, mine = 0;
-        for (int ord = 0; rest; ++ord) {
-          const uint32_t low = rest & (0u - rest);
-          rest ^= low;
-          if (ord % KSK == subk) mine |= low;
-        }
-        mk = mine;
-      }
       const int n_items = __builtin_amdgcn_readfirstlane(__popc(mk) * NCBL);
       int gen_k = 0, gen_cb = 0;
       // pending item (the one whose loads are issued next)
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
         gen_k = take ? __builtin_ctz(mk | 0x80000000u) : gen_k;
         mk = take ? (mk & (mk - 1)) : mk;
         const int krow = valid ? gen_k : K;
-        const int cb = subc * NCBL + gen_cb;
+        const int cb = sub * NCBL + gen_cb;
         pend_idx = ldsw[krow * 16 + l15];
         pend_acb = (uint32_t)(cb * 32 * ES);
         pend_woff = (uint32_t)(((gen_k * NCB + cb) * NS + ns)) * ITEM_BYTES;
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
         ((Is < rem ? compute(std::integral_constant<int, Is>{}) : (void)0), ...);
       }(std::make_integer_sequence<int, D - 1>{});
       __builtin_amdgcn_wave_barrier();                   // the next task overwrites the wave's LDS rows
-      if constexpr (KSP == 1) epilogue(acc, g, ns);
+      if constexpr (KSP == 1) epilogue(acc, g, ns, orow, bsc, bsh);
     }
 
     if constexpr (KSP > 1) {                             // fixed-order sum of the channel-split partials
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
         }
       }
       par ^= 1;
-      if (active && sub == 0) epilogue(acc, g, ns);
+      if (active && sub == 0) epilogue(acc, g, ns, orow, bsc, bsh);
     }
   }
 }
@@ -581,10 +586,9 @@ static int launch_wg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
 }
 
 // ------------------------------------------------------------------ launcher
-template <int CIN, int COUT, bool BF16, int KSC, int KSK>
-static int launch_rg_ksp(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
-  constexpr int D = BF16 ? 4 : 3;
-  constexpr int NS = COUT / 32, KSP = KSC * KSK;
+template <int CIN, int COUT, bool BF16, int KSP, int D>
+static int launch_rg_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
+  constexpr int NS = COUT / 32;
   const size_t lds = 4 * 28 * 16 * sizeof(int32_t) + (KSP > 1 ? 2 * 4 * 2 * 64 * sizeof(f32x4) : 0);
   const int64_t ntask = cdiv(groups_hint * NS * KSP, 4);
   // one workgroup per task up to a cap: the hardware dispatcher then balances the uneven tasks (a grid of only the
@@ -593,21 +597,25 @@ static int launch_rg_ksp(const SconvArgs& a, int64_t groups_hint, hipStream_t st
   grid = (grid + 7) / 8 * 8;
   hipEvent_t* pev = prof_kernel_events();
   if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
-    hipExtLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSC, KSK>), dim3((unsigned)grid), dim3(256), lds, stream, pev[0], pev[1], 0, a);
+    hipExtLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP>), dim3((unsigned)grid), dim3(256), lds, stream, pev[0], pev[1], 0, a);
     pev[0] = pev[1] = nullptr;
   } else {
-    hipLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSC, KSK>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP>), dim3((unsigned)grid), dim3(256), lds, stream, a);
   }
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
 template <int CIN, int COUT, bool BF16>
 static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
-  constexpr int NCB = CIN / 32;
+  constexpr int NS = COUT / 32, NCB = CIN / 32;
   // the input-channel blocks are always split over the waves of a workgroup (a function of the shape only, so results
   // never depend on launch sizes): measured faster at every level, 12 % on the 84 k-row 64->64 layer, 40 % on level 4.
-  // Splitting the kernel offsets as well (KSK = 2 / 4) measured neutral to 50 % slower (profiles/r02 notes in DESIGN).
-  return launch_rg_ksp<CIN, COUT, BF16, (NCB >= 4 ? 4 : NCB), 1>(a, groups_hint, stream);
+  // Splitting the kernel offsets as well measured neutral to 50 % slower.
+  constexpr int KSP = NCB >= 4 ? 4 : NCB;
+  // prefetch depth (does not touch the arithmetic): few waves per SIMD => nothing else hides the gather latency, keep
+  // 5 items in flight; a full chip prefers the smaller register footprint
+  if (groups_hint * NS * KSP < 6144) return launch_rg_d<CIN, COUT, BF16, KSP, 6>(a, groups_hint, stream);
+  return launch_rg_d<CIN, COUT, BF16, KSP, BF16 ? 4 : 3>(a, groups_hint, stream);
 }
 
 bool sconv_rg_supported(int cin, int cout) {
