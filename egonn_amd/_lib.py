@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libegonn_hip.so")
 
 QUANT_CARTESIAN, QUANT_POLAR = 0, 1
 FLAG_DISABLE_GLOBAL, FLAG_DISABLE_LOCAL, FLAG_IGNORE_KP_REGRESSOR, FLAG_BF16 = 1, 2, 4, 8
+FLAG_POOL_SPOC, FLAG_POOL_MAC = 16, 32
 
 # every symbol include/egonn_hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p

@@ -109,8 +109,12 @@ __device__ static inline void quantize_point(const QuantParams& qp, float x, flo
     cy = (int32_t)floorf(qp.s0 == 1.0f ? y : __fdiv_rn(y, qp.s0));
     cz = (int32_t)floorf(qp.s0 == 1.0f ? z : __fdiv_rn(z, qp.s0));
   } else {
-    // reference datasets/quantization.py:35-40, evaluated left to right in fp32
-    const float theta = __fadd_rn(180.0f, __fdiv_rn(__fmul_rn(atan2f(y, x), 180.0f), 3.14159265358979323846f));
+    // reference datasets/quantization.py:35-40, evaluated left to right in fp32.  atan2 is taken in fp64 and rounded ONCE
+    // to fp32: a correctly rounded fp32 arc tangent, which is what the CPU libraries (glibc / numpy; torch's sleef to
+    // 1 ulp) return — ocml's fp32 atan2f differs from them by an ulp on ~0.1 % of the points, enough to move a point
+    // across a sector boundary.
+    const float at = (float)atan2((double)y, (double)x);
+    const float theta = __fadd_rn(180.0f, __fdiv_rn(__fmul_rn(at, 180.0f), 3.14159265358979323846f));
     const float dist = sqrtf(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)));
     cx = (int32_t)floorf(__fdiv_rn(theta, qp.s0));
     cy = (int32_t)floorf(__fdiv_rn(dist, qp.s1));

@@ -228,22 +228,22 @@ __global__ __launch_bounds__(256) void segment_partial_kernel(const float* __res
   const int64_t len = e - s;
   const int32_t r0 = s + (int32_t)(len * ch / SEG_CHUNKS), r1 = s + (int32_t)(len * (ch + 1) / SEG_CHUNKS);
   const int tid = threadIdx.x;
-  const float p = pow_mode ? pexp[0] : 1.f;
+  const float p = pow_mode == 1 ? pexp[0] : 1.f;           // pow_mode: 0 = sum, 1 = sum of clamp(x)^p (GeM), 2 = max (MAC)
   // c <= 256: thread -> (row lane, channel); for c < 256 several rows advance in parallel
   const int rl = tid / c, cidx = tid - rl * c, nrl = 256 / c;
-  float acc = 0.f;
+  float acc = pow_mode == 2 ? -INFINITY : 0.f;
   if (rl < nrl) {
     for (int32_t r = r0 + rl; r < r1; r += nrl) {
       float v = in[(int64_t)r * c + cidx];
-      if (pow_mode) v = powf(fmaxf(v, 1e-6f), p);
-      acc += v;
+      if (pow_mode == 1) v = powf(fmaxf(v, 1e-6f), p);
+      acc = pow_mode == 2 ? fmaxf(acc, v) : acc + v;
     }
   }
   red[tid] = acc;
   __syncthreads();
   if (tid < c) {
-    float sum = 0.f;
-    for (int k = 0; k < nrl; ++k) sum += red[k * c + tid];
+    float sum = pow_mode == 2 ? -INFINITY : 0.f;
+    for (int k = 0; k < nrl; ++k) sum = pow_mode == 2 ? fmaxf(sum, red[k * c + tid]) : sum + red[k * c + tid];
     partial[((int64_t)b * SEG_CHUNKS + ch) * c + tid] = sum;
   }
 }
@@ -336,6 +336,7 @@ int convert_bf16_to_f32(const void* in, int64_t n, float* out, hipStream_t strea
 
 int eca_apply(const float* x, const float* res, const float* partial, const int32_t* boff, int B, int64_t n, int c,
               const float* wconv, int ksize, float* out, hipStream_t stream) {
+  EGONN_REQUIRE(c >= 4 && c <= 256 && c % 4 == 0, EGONN_ERR_INVALID, "eca: %d channels unsupported (4..256, multiple of 4)", c);
   if (n == 0) return EGONN_OK;
   // gate lives right behind the partial sums: partial[B*SEG_CHUNKS*c] | gate[B*c]
   float* gate = const_cast<float*>(partial) + (int64_t)B * SEG_CHUNKS * c;
@@ -431,19 +432,34 @@ int add_act(const float* a, const float* b, int64_t n, int relu, float* out, hip
 }
 
 // ------------------------------------------------------------------ GeM finish
+// pexp != NULL: GeM (mean^(1/p)); pexp == NULL: mode 0 = SPoC (mean, MinkowskiGlobalAvgPooling), 2 = MAC (max)
 __global__ void gem_finish_kernel(const float* __restrict__ partial, const int32_t* __restrict__ boff, int c,
-                                  const float* __restrict__ pexp, float* __restrict__ out) {
+                                  const float* __restrict__ pexp, int mode, float* __restrict__ out) {
   const int b = blockIdx.x, t = threadIdx.x;
   if (t >= c) return;
   const int32_t cntr = boff[b + 1] - boff[b];
+  if (mode == 2) {
+    float s = -INFINITY;
+    for (int ch = 0; ch < SEG_CHUNKS; ++ch) s = fmaxf(s, partial[((int64_t)b * SEG_CHUNKS + ch) * c + t]);
+    out[(int64_t)b * c + t] = cntr > 0 ? s : 0.f;
+    return;
+  }
   float s = 0.f;
   for (int ch = 0; ch < SEG_CHUNKS; ++ch) s += partial[((int64_t)b * SEG_CHUNKS + ch) * c + t];
   const float m = cntr > 0 ? s / (float)cntr : 0.f;
-  out[(int64_t)b * c + t] = powf(m, 1.f / pexp[0]);
+  out[(int64_t)b * c + t] = pexp ? powf(m, 1.f / pexp[0]) : m;
 }
 int gem_finish(const float* partial, const int32_t* boff, int B, int c, const float* p, float* out,
                hipStream_t stream) {
-  hipLaunchKernelGGL(gem_finish_kernel, dim3(B), dim3(256), 0, stream, partial, boff, c, p, out);
+  EGONN_REQUIRE(c >= 1 && c <= 256, EGONN_ERR_INVALID, "gem: %d channels unsupported (1..256)", c);
+  hipLaunchKernelGGL(gem_finish_kernel, dim3(B), dim3(256), 0, stream, partial, boff, c, p, 0, out);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+int pool_finish(const float* partial, const int32_t* boff, int B, int c, int mode, float* out, hipStream_t stream) {
+  EGONN_REQUIRE(c >= 1 && c <= 256 && (mode == 0 || mode == 2), EGONN_ERR_INVALID, "pooling: bad arguments");
+  hipLaunchKernelGGL(gem_finish_kernel, dim3(B), dim3(256), 0, stream, partial, boff, c, (const float*)nullptr, mode, out);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }

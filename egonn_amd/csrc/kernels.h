@@ -63,6 +63,8 @@ int convert_bf16_to_f32(const void* in, int64_t n, float* out, hipStream_t strea
 // GeM: out[b][c] = (mean_b clamp(x,eps)^p)^(1/p) from the pow-mode partial sums
 int gem_finish(const float* partial, const int32_t* boff, int B, int c, const float* p, float* out,
                hipStream_t stream);
+// SPoC (mode 0: per-sample mean of the sum-mode partials) / MAC (mode 2: per-sample max of the max-mode partials)
+int pool_finish(const float* partial, const int32_t* boff, int B, int c, int mode, float* out, hipStream_t stream);
 int l2_normalize_rows(float* x, int64_t n, int c, hipStream_t stream, const int32_t* n_dev = nullptr);
 int add_act(const float* a, const float* b, int64_t n, int relu, float* out, hipStream_t stream);
 // keypoint positions (reference datasets/quantization.py:60-72, 93-103)

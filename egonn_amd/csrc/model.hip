@@ -570,7 +570,8 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
   for (int l : {3, 4})
     EGONN_TRY(get_tensor(m, "local_head.conv1x1." + std::to_string(l) + ".kernel", {PLANES[l - 1], LOCAL_CH}, &m->l1x1[l]));
   EGONN_TRY(get_tensor(m, "local_head.tconv.4.kernel", {8, LOCAL_CH, LOCAL_CH}, &m->lt[4]));
-  EGONN_TRY(get_tensor(m, "global_pooling.pooling.p", {1}, &m->gem_p));
+  m->gem_p = nullptr;                  // GeM exponent; MAC / SPoC pooling (layers/pooling.py:46-69) has no parameter
+  if (m->t.count("global_pooling.pooling.p")) EGONN_TRY(get_tensor(m, "global_pooling.pooling.p", {1}, &m->gem_p));
   EGONN_TRY(get_mlp(m, "global_descriptor_decoder", GLOBAL_CH, GLOBAL_DIM + (GLOBAL_CH - GLOBAL_DIM) / 2, GLOBAL_DIM, &m->gdec));
   EGONN_TRY(get_mlp(m, "local_descriptor_decoder", LOCAL_CH, LOCAL_DIM + (LOCAL_CH - LOCAL_DIM) / 2, LOCAL_DIM, &m->ldec));
   EGONN_TRY(get_mlp(m, "local_keypoint_regressor", LOCAL_CH, LOCAL_CH / 2, 3, &m->kp));
@@ -781,8 +782,16 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     WALLOC(gd, P.cap[5] * GLOBAL_DIM);
     EGONN_TRY(run_mlp(m->gdec, g5, P.cap[5], ACT_NONE, gh, gd, st, cnt + 5));
     WALLOC(gp, (size_t)B * SEG_CHUNKS * GLOBAL_DIM);
-    EGONN_TRY(segment_partial_sums(gd, P.lv[5].boff, B, GLOBAL_DIM, 1, m->gem_p, gp, st));
-    EGONN_TRY(gem_finish(gp, P.lv[5].boff, B, GLOBAL_DIM, m->gem_p, out_global, st));
+    // global pooling (layers/pooling.py:13-43): GeM (default, :72-86), SPoC = average (:59-69), MAC = max (:46-56)
+    if (flags & (EGONN_FLAG_POOL_SPOC | EGONN_FLAG_POOL_MAC)) {
+      const int mode = (flags & EGONN_FLAG_POOL_MAC) ? 2 : 0;
+      EGONN_TRY(segment_partial_sums(gd, P.lv[5].boff, B, GLOBAL_DIM, mode, nullptr, gp, st));
+      EGONN_TRY(pool_finish(gp, P.lv[5].boff, B, GLOBAL_DIM, mode, out_global, st));
+    } else {
+      EGONN_REQUIRE(m->gem_p, EGONN_ERR_STATE, "forward: GeM pooling needs the tensor 'global_pooling.pooling.p'");
+      EGONN_TRY(segment_partial_sums(gd, P.lv[5].boff, B, GLOBAL_DIM, 1, m->gem_p, gp, st));
+      EGONN_TRY(gem_finish(gp, P.lv[5].boff, B, GLOBAL_DIM, m->gem_p, out_global, st));
+    }
   }
 
 #undef WALLOC

@@ -71,10 +71,11 @@ def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     pad = torch.zeros((max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = torch.empty((world * max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    if dist.get_backend() == "gloo":
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad)
-        out = torch.cat(parts, dim=0)
+    if dist.get_backend() == "gloo":                      # gloo moves host memory: stage device tensors through the CPU
+        hpad = pad.cpu()
+        parts = [torch.empty_like(hpad) for _ in range(world)]
+        dist.all_gather(parts, hpad)
+        out = torch.cat(parts, dim=0).to(local.device)
     else:
         dist.all_gather_into_tensor(out, pad)
     chunks = []
@@ -108,8 +109,16 @@ class DatabaseBuilder:
                 kps.append(out["keypoints"])
                 descs.append(out["descriptors"])
                 counts.append(out["count"])
-        dim = globals_[0].shape[1] if globals_ else 256
-        dev = globals_[0].device if globals_ else torch.device("cpu")
+        # a rank whose shard is empty (fewer scans than ranks) still joins the collective: on the extractor's device, with
+        # the model's descriptor size
+        model = getattr(self.extractor, "model", None)
+        dim = globals_[0].shape[1] if globals_ else int(getattr(model, "global_descriptor_size", 256))
+        if globals_:
+            dev = globals_[0].device
+        elif model is not None and hasattr(model, "context"):
+            dev = model.context().device
+        else:
+            dev = torch.device(getattr(self.extractor, "device", "cpu"))
         local = torch.cat(globals_, dim=0) if globals_ else torch.zeros((0, dim), device=dev)
         result = {"global": all_gather_rows(local, n_scans), "range": (lo, hi)}
         if keep_local and kps:

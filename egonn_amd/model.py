@@ -169,15 +169,28 @@ class GeM(nn.Module):                   # reference layers/pooling.py:72-86
         self.eps = eps
 
 
+class MAC(nn.Module):                   # reference layers/pooling.py:46-56 (MinkowskiGlobalMaxPooling; no parameters)
+    def __init__(self, input_dim):
+        super().__init__()
+        self.input_dim = self.output_dim = input_dim
+
+
+class SPoC(nn.Module):                  # reference layers/pooling.py:59-69 (MinkowskiGlobalAvgPooling; no parameters)
+    def __init__(self, input_dim):
+        super().__init__()
+        self.input_dim = self.output_dim = input_dim
+
+
 class PoolingWrapper(nn.Module):        # reference layers/pooling.py:13-43
     def __init__(self, pool_method, in_dim, output_dim):
         super().__init__()
-        if pool_method != 'GeM':
+        if pool_method not in ('GeM', 'MAC', 'SPoC'):
             raise NotImplementedError(f'pooling method {pool_method!r}: the MI355X path implements GeM (the egonn '
-                                      f'configuration, models/model_factory.py:73-76)')
+                                      f'configuration, models/model_factory.py:73-76), MAC and SPoC; NetVLAD is unused '
+                                      f'by the egonn configuration')
         assert in_dim == output_dim
         self.pool_method, self.in_dim, self.output_dim = pool_method, in_dim, output_dim
-        self.pooling = GeM(input_dim=in_dim)
+        self.pooling = {'GeM': GeM, 'MAC': MAC, 'SPoC': SPoC}[pool_method](input_dim=in_dim)
 
 
 # ----------------------------------------------------------------------------- the model
@@ -243,7 +256,10 @@ class MinkGL(nn.Module):
 
     def _sync_weights(self):
         """(Re)register weights with the HIP model when any tensor moved or was written to."""
-        sig = tuple((k, v.data_ptr(), v._version) for k, v in self._float_state())
+        # (BatchNorm running statistics are updated by the HIP kernels through raw pointers, which does not bump their
+        #  tensor version; every such update increments num_batches_tracked with a torch op, so its version is part of the
+        #  signature and a train-mode forward always invalidates the folded scale/shift)
+        sig = tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict(keep_vars=True).items())
         if self._handle is not None and sig == self._registered:
             return
         if self._handle is None:
@@ -319,24 +335,14 @@ class MinkGL(nn.Module):
         if outputs is not None:
             return self._forward_reserved(ctx, feats, outputs, disable_global_head, disable_local_head)
         n3 = ctx.level_count(lvl)
-        flags = 0
+        flags = self._flags(disable_global_head, disable_local_head)
         out_g = out_d = out_k = out_s = None
-        if disable_global_head:
-            flags |= _lib.FLAG_DISABLE_GLOBAL
-        else:
+        if not disable_global_head:
             out_g = torch.empty((B, self.global_descriptor_size), dtype=torch.float32, device=dev)
-        if disable_local_head:
-            flags |= _lib.FLAG_DISABLE_LOCAL
-        else:
+        if not disable_local_head:
             out_d = torch.empty((n3, self.local_descriptor_size), dtype=torch.float32, device=dev)
             out_k = torch.empty((n3, 3), dtype=torch.float32, device=dev)
             out_s = torch.empty((n3, 1), dtype=torch.float32, device=dev)
-        if self.ignore_keypoint_regressor:
-            flags |= _lib.FLAG_IGNORE_KP_REGRESSOR
-        if self.precision == 'bf16':
-            flags |= _lib.FLAG_BF16
-        elif self.precision != 'fp32':
-            raise ValueError(f"precision {self.precision!r}: 'fp32' or 'bf16'")
         q = self.quantizer
         step = (_lib.C.c_float * 3)(*([float(s) for s in q.step] + [0.0, 0.0])[:3])
         with torch.cuda.device(dev):
@@ -367,6 +373,7 @@ class MinkGL(nn.Module):
             flags |= _lib.FLAG_BF16
         elif self.precision != 'fp32':
             raise ValueError(f"precision {self.precision!r}: 'fp32' or 'bf16'")
+        flags |= {'GeM': 0, 'SPoC': _lib.FLAG_POOL_SPOC, 'MAC': _lib.FLAG_POOL_MAC}[self.global_pool_method]
         return flags
 
     def _forward_reserved(self, ctx, feats, outputs, disable_global_head=False, disable_local_head=False):

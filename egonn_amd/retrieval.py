@@ -38,12 +38,18 @@ def recall_at_k(map_embeddings: torch.Tensor, query_embeddings: torch.Tensor, ma
     dev = _lib.require_gpu() if not map_embeddings.is_cuda else map_embeddings.device
     lib = _lib.load()
     qe = query_embeddings.to(dev)
-    qp = query_positions.to(device=dev, dtype=torch.float32)
+    # the reference keeps positions in float64 (eval/evaluate.py:66-88); MulRan / KITTI poses are UTM-scale (~4e6 m),
+    # where fp32 resolves 0.25-0.5 m — enough to flip a neighbour at the 5 m / 20 m radius.  A common origin is
+    # subtracted in float64 first, the device then works on metre-scale offsets.
+    mp64 = torch.as_tensor(map_positions).to(dtype=torch.float64, device="cpu")
+    qp64 = torch.as_tensor(query_positions).to(dtype=torch.float64, device="cpu")
+    origin = mp64.mean(dim=0, keepdim=True) if mp64.shape[0] else torch.zeros((1, qp64.shape[1]), dtype=torch.float64)
+    qp = (qp64 - origin).to(device=dev, dtype=torch.float32)
     if query_indexes is not None:
         sel = torch.as_tensor(list(query_indexes), dtype=torch.long, device=dev)
         qe, qp = qe[sel], qp[sel]
     qp = qp.contiguous()
-    mp = map_positions.to(device=dev, dtype=torch.float32).contiguous()
+    mp = (mp64 - origin).to(device=dev, dtype=torch.float32).contiguous()
     idx, _ = knn(qe, map_embeddings.to(dev), k)
     rad = torch.tensor([float(r) for r in radius], dtype=torch.float32, device=dev)
     tp = torch.empty((len(radius), k), dtype=torch.int32, device=dev)

@@ -299,7 +299,8 @@ class GeMFn(Function):
         g = _c(g)
         dx = dp = None
         if fctx.needs_input_grad[0]:
-            coef = g * out.pow(1.0 - pv) / cnt
+            # an empty sample has out = 0: its coefficient is 0, not 0 * inf
+            coef = torch.where(out > 0, g * out.clamp_min(1e-30).pow(1.0 - pv) / cnt, torch.zeros_like(out))
             dx = ctx.gem_backward(level, x, _c(coef), _c(p.detach().reshape(-1).float()))
         if fctx.needs_input_grad[1]:
             T = ctx.segment_sums(level, 1, x, p=_c(p.detach().reshape(-1).float()))    # sum_r t^p ln t

@@ -33,7 +33,9 @@ enum { EGONN_QUANT_CARTESIAN = 0, EGONN_QUANT_POLAR = 1 };
 enum { EGONN_FLAG_DISABLE_GLOBAL = 1, EGONN_FLAG_DISABLE_LOCAL = 2, EGONN_FLAG_IGNORE_KP_REGRESSOR = 4,
        /* BASELINE configs[2]: feature maps and sparse-conv weights are bf16 in HBM (2 bytes per element), products
         * accumulate in fp32 on v_mfma_f32_16x16x32_bf16; the dense heads, pooling and all outputs stay fp32 */
-       EGONN_FLAG_BF16 = 8 };
+       EGONN_FLAG_BF16 = 8,
+       /* global pooling of PoolingWrapper (layers/pooling.py:13-43) other than the default GeM: SPoC = average, MAC = max */
+       EGONN_FLAG_POOL_SPOC = 16, EGONN_FLAG_POOL_MAC = 32 };
 
 /* ------------------------------------------------------------------ lifecycle / errors */
 /* coord_bits in [10,16]: voxel coordinates must lie in [-2^(coord_bits-1), 2^(coord_bits-1)). */

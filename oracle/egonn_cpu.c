@@ -1,7 +1,8 @@
 /* ORACLE — TEST INFRASTRUCTURE ONLY.  Never linked into, loaded by, or called from the product path (egonn_amd/).
  *
- * C / OpenMP restatement of the reference's EgoNN descriptor extraction for ONE scan, Cartesian quantiser
- * (the configuration of BASELINE.json configs[1]): quantise -> MinkGL.forward (eval mode) -> top-n_k keypoints.
+ * C / OpenMP restatement of the reference's EgoNN descriptor extraction for ONE scan, Cartesian quantiser (the
+ * configuration of BASELINE.json configs[1]) or polar quantiser (the reference's shipped configuration,
+ * models/egonn.txt:3-5): quantise -> MinkGL.forward (eval mode) -> top-n_k keypoints.
  * It is the CPU baseline bench.py times next to the GPU path ("the build's own CPU oracle
  * (C++/OpenMP restatement, same graph, same clouds, fp32)") and a second, independently written checker: it is
  * validated against the numpy oracle (oracle/egonn_ref.py) and the reference-graph fixtures in tests/test_oracle.py.
@@ -213,10 +214,15 @@ static int cmp_sig(const void* a, const void* b) {
 /* One scan.  Outputs (caller allocated): out_global[256]; out_n3; for the first min(n3, n_k) selected keypoints in
  * ascending-sigma order: sel_coords[n_k][3] (super-voxel coordinate), sel_kp[n_k][3], sel_desc[n_k][128],
  * sel_sigma[n_k]; level_counts[8].  Returns the number of selected keypoints, < 0 on error. */
-int egonn_cpu_compute_embedding(const float* points, int64_t n_points, float quant_step, const float* const* weights,
-                                int n_weights, int n_k, float* out_global, int32_t* level_counts, int32_t* sel_coords,
-                                float* sel_kp, float* sel_desc, float* sel_sigma, int n_threads) {
-  if (n_points <= 0 || n_weights < 1) return -1;
+/* mode 0: CartesianQuantizer(step[0]) (datasets/quantization.py:79-103); mode 1: PolarQuantizer(step[0..2]) = sector in
+ * degrees, ring and z in metres (datasets/quantization.py:29-72; the shipped configuration, models/egonn.txt:3-5). */
+int egonn_cpu_compute_embedding_q(const float* points, int64_t n_points, int mode, const float* step,
+                                  const float* const* weights, int n_weights, int n_k, float* out_global,
+                                  int32_t* level_counts, int32_t* sel_coords, float* sel_kp, float* sel_desc,
+                                  float* sel_sigma, int n_threads) {
+  if (n_points <= 0 || n_weights < 1 || (mode != 0 && mode != 1)) return -1;
+  const float quant_step = step[0];
+  const float qs[3] = {step[0], mode ? step[1] : step[0], mode ? step[2] : step[0]};
 #ifdef _OPENMP
   if (n_threads > 0) omp_set_num_threads(n_threads);     /* per calling thread: several scans may run side by side */
 #endif
@@ -225,8 +231,14 @@ int egonn_cpu_compute_embedding(const float* points, int64_t n_points, float qua
   /* ---- quantise: floor(p / q) (fp32 division, as torch.floor(pc / q)), unique voxels */
   uint64_t* k0 = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n_points);
   for (int64_t i = 0; i < n_points; ++i) {
-    const int32_t x = (int32_t)floorf(points[3 * i] / quant_step), y = (int32_t)floorf(points[3 * i + 1] / quant_step),
-                  z = (int32_t)floorf(points[3 * i + 2] / quant_step);
+    float a = points[3 * i], b = points[3 * i + 1];
+    const float c = points[3 * i + 2];
+    if (mode) {   /* theta = 180 + atan2(y, x) * 180 / pi (degrees, evaluated left to right in fp32); dist = sqrt(x^2 + y^2) */
+      const float px = a, py = b;
+      a = 180.0f + (atan2f(py, px) * 180.0f) / 3.14159265358979323846f;
+      b = sqrtf(px * px + py * py);
+    }
+    const int32_t x = (int32_t)floorf(a / qs[0]), y = (int32_t)floorf(b / qs[1]), z = (int32_t)floorf(c / qs[2]);
     k0[i] = pack(x, y, z);
   }
   level_from_keys(&lv[0], k0, (int)n_points);
@@ -381,12 +393,19 @@ int egonn_cpu_compute_embedding(const float* points, int64_t n_points, float qua
       for (int c = 0; c < 128; ++c) nrm += desc[(size_t)r * 128 + c] * desc[(size_t)r * 128 + c];
       nrm = fmaxf(sqrtf(nrm), 1e-12f);
       for (int c = 0; c < 128; ++c) sel_desc[(size_t)q * 128 + c] = desc[(size_t)r * 128 + c] / nrm;
+      float pos[3];
       for (int a = 0; a < 3; ++a) {
         const int32_t cc = lv[3].c[3 * r + a];
         sel_coords[3 * q + a] = cc;
         /* (C + 0.5) q + tanh(offset) * (stride q) / 2,  stride = 8 */
-        sel_kp[3 * q + a] = ((float)cc + 0.5f) * quant_step + tanhf(kp[(size_t)r * 3 + a]) * (8.f * quant_step) / 2.f;
+        pos[a] = ((float)cc + 0.5f) * qs[a] + tanhf(kp[(size_t)r * 3 + a]) * (8.f * qs[a]) / 2.f;
       }
+      if (mode) {   /* PolarQuantizer.to_cartesian: theta = pi (deg - 180) / 180 */
+        const float theta = 3.14159265358979323846f * (pos[0] - 180.0f) / 180.0f, rr = pos[1];
+        pos[0] = cosf(theta) * rr;
+        pos[1] = sinf(theta) * rr;
+      }
+      for (int a = 0; a < 3; ++a) sel_kp[3 * q + a] = pos[a];
       sel_sigma[q] = sg[r];
     }
     free(order);
@@ -401,6 +420,14 @@ int egonn_cpu_compute_embedding(const float* points, int64_t n_points, float qua
     if (feats[l]) free(feats[l]);
   }
   return (W.i == n_weights) ? n_sel : -2;      /* -2: the weight list was not consumed exactly */
+}
+
+int egonn_cpu_compute_embedding(const float* points, int64_t n_points, float quant_step, const float* const* weights,
+                                int n_weights, int n_k, float* out_global, int32_t* level_counts, int32_t* sel_coords,
+                                float* sel_kp, float* sel_desc, float* sel_sigma, int n_threads) {
+  const float step[3] = {quant_step, quant_step, quant_step};
+  return egonn_cpu_compute_embedding_q(points, n_points, 0, step, weights, n_weights, n_k, out_global, level_counts,
+                                       sel_coords, sel_kp, sel_desc, sel_sigma, n_threads);
 }
 
 int egonn_cpu_num_threads(void) {

@@ -60,14 +60,17 @@ def build(native: bool = False, force: bool = False) -> str:
 
 
 class CpuOracle:
-    def __init__(self, state_dict: Dict[str, np.ndarray], quant_step: float, native: bool = False):
+    def __init__(self, state_dict: Dict[str, np.ndarray], quant_step, native: bool = False):
+        """quant_step: a float (CartesianQuantizer) or three floats (PolarQuantizer: degrees, metres, metres)."""
         self.lib = C.CDLL(build(native))
         P = C.POINTER(C.c_float)
-        self.lib.egonn_cpu_compute_embedding.restype = C.c_int
-        self.lib.egonn_cpu_compute_embedding.argtypes = [P, C.c_int64, C.c_float, C.POINTER(P), C.c_int, C.c_int, P,
-                                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), P, P, P, C.c_int]
+        self.lib.egonn_cpu_compute_embedding_q.restype = C.c_int
+        self.lib.egonn_cpu_compute_embedding_q.argtypes = [P, C.c_int64, C.c_int, P, C.POINTER(P), C.c_int, C.c_int, P,
+                                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32), P, P, P, C.c_int]
         self.lib.egonn_cpu_num_threads.restype = C.c_int
-        self.q = float(quant_step)
+        steps = [float(v) for v in np.atleast_1d(np.asarray(quant_step, dtype=np.float64))]
+        self.mode = 1 if len(steps) == 3 else 0
+        self.step = (C.c_float * 3)(*(steps + steps[-1:] * 2)[:3])
         keys = weight_order()
         self._keep = [np.ascontiguousarray(np.asarray(state_dict[k], dtype=np.float32)) for k in keys]
         self._ptrs = (P * len(keys))(*[a.ctypes.data_as(P) for a in self._keep])
@@ -99,7 +102,7 @@ class CpuOracle:
         kp = np.zeros((n_k, 3), np.float32)
         de = np.zeros((n_k, 128), np.float32)
         sg = np.zeros(n_k, np.float32)
-        m = self.lib.egonn_cpu_compute_embedding(pc.ctypes.data_as(P), len(pc), self.q, self._ptrs, self._n, n_k,
+        m = self.lib.egonn_cpu_compute_embedding_q(pc.ctypes.data_as(P), len(pc), self.mode, self.step, self._ptrs, self._n, n_k,
                                                  g.ctypes.data_as(P), cnt.ctypes.data_as(C.POINTER(C.c_int32)),
                                                  sc.ctypes.data_as(C.POINTER(C.c_int32)), kp.ctypes.data_as(P),
                                                  de.ctypes.data_as(P), sg.ctypes.data_as(P), int(n_threads))

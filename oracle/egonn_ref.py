@@ -284,6 +284,17 @@ def compute_embedding(oracle: EgoNNOracle, pc: np.ndarray, n_k: int = 128):
     return y["global"], y["keypoints"][0][idx], y["descriptors"][0][idx], y["keypoint_coords"][0][idx]
 
 
+def compute_embedding_with_sigma(oracle: EgoNNOracle, pc: np.ndarray, n_k: int = 128):
+    """compute_embedding plus the (ascending) sigmas of the selected keypoints: tests use the gaps between them to tell a
+    legitimate swap of two near-equal saliencies from a wrong selection."""
+    coords, _ = oracle.quantizer(pc)
+    bc = ops.batched_coordinates([coords])
+    y = oracle.forward(bc, np.ones((len(bc), 1), dtype=F32))
+    idx = select_keypoints(y["sigma"][0], y["keypoint_coords"][0], n_k)
+    return (y["global"], y["keypoints"][0][idx], y["descriptors"][0][idx], y["keypoint_coords"][0][idx],
+            y["sigma"][0][idx].reshape(-1))
+
+
 # ----------------------------------------------------------------------------- MinkLoc / MinkLoc3D (MinkFPN + GeM)
 class MinkLocOracle:
     """reference models/minkfpn.py:65-93 (MinkFPN.forward) + GeM, as used by models/minkloc.py:44-61 and

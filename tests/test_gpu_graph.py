@@ -186,3 +186,33 @@ def test_ignore_keypoint_saliency_draws_random_keypoints(gpu):
     a, b = ex.extract_packed(p, o), exr.extract_packed(p, o, slot=1)
     assert torch.equal(a["global"], b["global"]) and not torch.equal(a["rows"], b["rows"])
     assert (b["count"] == 128).all()
+
+
+def test_mac_and_spoc_pooling(gpu):
+    """PoolingWrapper 'MAC' / 'SPoC' (layers/pooling.py:46-69): per-scan max / mean of the decoded global feature rows;
+    everything in front of the pooling is the GeM model's (the GeM exponent is the only parameter that differs)."""
+    from egonn_amd import model as M
+    w = H.seeded_weights(71)
+    outs = {}
+    for method in ("GeM", "MAC", "SPoC"):
+        mp = gpu.ModelParams(model="egonn", coordinates="cartesian", quantization_step=0.2)
+        q = mp.quantizer
+        gl = [M.PLANES[i - 1] for i in M.GLOBAL_LEVELS]
+        ll = [M.PLANES[i - 1] for i in M.LOCAL_LEVELS]
+        m = M.MinkGL(M.MinkTrunk(in_channels=1, planes=M.PLANES, conv0_kernel_size=5),
+                     local_head=M.MinkHead(M.LOCAL_LEVELS, ll, M.LOCAL_CH), local_descriptor_size=M.LOCAL_DIM, local_normalize=True,
+                     global_head=M.MinkHead(M.GLOBAL_LEVELS, gl, M.GLOBAL_CH), global_descriptor_size=M.GLOBAL_DIM,
+                     global_pool_method=method, global_normalize=False, quantizer=q)
+        sd = {k: torch.from_numpy(v) for k, v in w.items() if k in m.state_dict()}
+        assert ("global_pooling.pooling.p" in m.state_dict()) == (method == "GeM")
+        m.load_state_dict(sd)
+        m = m.to("cuda").eval()
+        p, o = _batch([930, 931, 932], [9000, 7000, 4000])
+        ctx = m.context()
+        ctx.voxelize(p, o, q.mode, q.step)
+        outs[method] = m._forward_on_plan(ctx, None)["global"].cpu().numpy()
+    g, mx, av = outs["GeM"], outs["MAC"], outs["SPoC"]
+    assert np.isfinite(mx).all() and np.isfinite(av).all()
+    assert (mx >= av - 1e-6).all()                     # max >= mean, per scan and channel
+    # GeM with p = 3 on clamped rows lies between the mean of the clamped rows and their max
+    assert (g <= np.maximum(mx, 1e-6) + 1e-5).all() and (g >= np.maximum(av, 0) - 1e-5).all()

@@ -43,6 +43,16 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+def _gap_ok(sig, tol=2e-4):
+    """positions of an ascending sigma list whose value is separated from both neighbours by more than the forward
+    tolerance: there the selection order must match exactly (elsewhere fp32 noise may swap near-equal saliencies)."""
+    sig = np.asarray(sig, dtype=np.float64).reshape(-1)
+    if len(sig) < 2:
+        return np.ones(len(sig), bool)
+    d = np.diff(sig) > tol * np.maximum(1.0, np.abs(sig[1:]))
+    return np.r_[True, d] & np.r_[d, True]
+
+
 # ------------------------------------------------------------------------------------ voxeliser (a1, a2)
 @pytest.mark.parametrize("name", H.CASES)
 def test_quantizer_matches_reference(gpu, name):
@@ -60,9 +70,10 @@ def test_quantizer_matches_reference(gpu, name):
             perm = H.join_perm(c4, g4)
             assert np.array_equal(coords[perm], g_c)
             assert np.array_equal(idx[perm], g_i)            # first point of every voxel
-        else:                                                # transcendental: bin-edge points may move
-            a, g = set(map(tuple, coords.tolist())), set(map(tuple, g_c.tolist()))
-            assert len(a ^ g) <= max(2, len(g) // 1000)
+        else:                                                # atan2 in fp64 rounded once: the same bins as the reference
+            perm = H.join_perm(c4, g4)
+            assert np.array_equal(coords[perm], g_c)
+            assert np.array_equal(idx[perm], g_i)
         # Z-order output is sorted by construction and duplicate-free
         assert len(np.unique(H.rowkey(c4))) == len(c4)
 
@@ -401,16 +412,25 @@ def test_full_size_properties_batch16(gpu):
         assert n == int(out1["count"][b]) == 128
         assert H.cosine_err(_np(solo["descriptors"][0]), _np(d1[b])).max() < 1e-4
         np.testing.assert_allclose(_np(solo["keypoints"][0]), _np(k1[b]), atol=2e-3)
-    # sampled oracle check of one full-size scan (the oracle needs a few seconds for it)
-    oracle = ref.EgoNNOracle(w, ref.CartesianQuantizer(0.1))
-    pc = _np(scans[3])
-    g_ref, kp_ref, desc_ref, kc_ref = ref.compute_embedding(oracle, pc, 128)
-    assert H.cosine_err(_np(g1[[3]]), g_ref).max() < 1e-4
-    rows = _np(out1["rows"][3]).astype(np.int64)
-    got_c = c3[rows]
-    same = np.all(got_c[:, 1:] == kc_ref[:, 1:], axis=1)
-    assert same.mean() > 0.9                                    # near-tie swaps only
-    assert H.cosine_err(_np(d1[3])[same], desc_ref[same]).max() < 1e-4
+    # oracle check of 4 of the 16 full-size scans (C/OpenMP restatement: a second or two each; one of them also on the
+    # numpy restatement, which is the independent implementation)
+    from oracle import egonn_cpu
+    co = egonn_cpu.CpuOracle(w, 0.1)
+    off3 = ctx.level_batch_offsets(3)
+    for b in (3, 0, 9, 15):
+        pc = _np(scans[b])
+        g_ref, kp_ref, desc_ref, kc_ref, sig_ref, _ = co.compute_embedding(pc, 128)
+        if b == 3:
+            g_np, kp_np, desc_np, kc_np, sig_np = ref.compute_embedding_with_sigma(ref.EgoNNOracle(w, ref.CartesianQuantizer(0.1)), pc, 128)
+            assert H.cosine_err(g_np, g_ref).max() < 1e-5 and np.allclose(sig_np, sig_ref, rtol=1e-3, atol=1e-5)
+        assert H.cosine_err(_np(g1[[b]]), g_ref).max() < 1e-4
+        rows = _np(out1["rows"][b]).astype(np.int64)
+        got_c = c3[rows]
+        same = np.all(got_c[:, 1:] == kc_ref, axis=1)
+        assert (same | ~_gap_ok(sig_ref)).all(), b                # every swap is a near-tie of the saliencies
+        assert same.sum() >= 64
+        assert H.cosine_err(_np(d1[b])[same], desc_ref[same]).max() < 1e-4
+        np.testing.assert_allclose(_np(k1[b])[same], kp_ref[same], atol=2e-3)
 
 
 def test_streamed_batches_equal_sequential(gpu):
@@ -504,15 +524,16 @@ def test_config0_kitti_shaped_scan(gpu, coordinates, step):
     ex = gpu.DescriptorExtractor(m, n_k=128)
     g, kp, desc = ex.compute_embedding(torch.from_numpy(pc))
     q = ref.PolarQuantizer(step) if coordinates == "polar" else ref.CartesianQuantizer(step)
-    g_ref, kp_ref, desc_ref, kc_ref = ref.compute_embedding(ref.EgoNNOracle(w, q), pc, 128)
-    # polar bins can differ for points on a bin edge (atan2 ulp), which perturbs the descriptor slightly
-    tol = 1e-4 if coordinates == "cartesian" else 5e-4
-    assert H.cosine_err(g, g_ref).max() < tol
+    g_ref, kp_ref, desc_ref, kc_ref, sig_ref = ref.compute_embedding_with_sigma(ref.EgoNNOracle(w, q), pc, 128)
+    # voxel sets: the polar quantiser takes atan2 in fp64 rounded once to fp32, like the CPU libraries -> identical bins
+    c_gpu = _np(m.quantizer(torch.from_numpy(pc))[0])
+    c_ref = q(pc)[0]
+    assert set(map(tuple, c_gpu.tolist())) == set(map(tuple, np.asarray(c_ref).tolist()))
+    assert H.cosine_err(g, g_ref).max() < 1e-4                 # the north-star bar, Cartesian and polar
     assert kp.shape == kp_ref.shape == (128, 3)
-    if coordinates == "cartesian":
-        same = np.isclose(kp.numpy(), kp_ref, atol=2e-3).all(axis=1)
-        assert same.mean() > 0.9
-        assert H.cosine_err(desc.numpy()[same], desc_ref[same]).max() < 1e-4
+    same = np.isclose(kp.numpy(), kp_ref, atol=2e-3 if coordinates == "cartesian" else 2e-2).all(axis=1)
+    assert (same | ~_gap_ok(sig_ref)).all()                    # every swap is a near-tie of the saliencies
+    assert H.cosine_err(desc.numpy()[same], desc_ref[same]).max() < 1e-4
 
 
 def test_config4_database_build_mulran_shaped(gpu):
@@ -676,18 +697,22 @@ def _fuzz_cloud(rng, kind, n):
     return p
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(18))
 def test_fuzz_single_scan_vs_c_oracle(gpu, seed):
     """randomised clouds / voxel sizes / sizes through compute_embedding vs the independent C/OpenMP restatement:
     level sizes exact, global descriptor 1-cos <= 1e-4, the selected keypoints (where sigma gaps exceed the forward
-    tolerance), their positions and descriptors."""
+    tolerance), their positions and descriptors.  Seeds 12-17 use the polar quantiser (the reference's shipped
+    configuration, models/egonn.txt:3-5)."""
     from oracle import egonn_cpu
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([150, 900, 4000, 12000, 30000]))
+    polar = seed >= 12
     q = float(rng.choice([0.1, 0.2, 0.35, 0.5]))
+    if polar:
+        q = [float(rng.choice([0.5, 1.0, 2.0])), float(rng.choice([0.2, 0.3, 0.5])), float(rng.choice([0.2, 0.4]))]
     pc = _fuzz_cloud(rng, seed % 4, n)
     w = H.seeded_weights(50 + seed)
-    mp = gpu.ModelParams(model="egonn", coordinates="cartesian", quantization_step=q)
+    mp = gpu.ModelParams(model="egonn", coordinates="polar" if polar else "cartesian", quantization_step=q)
     m = gpu.model_factory(mp)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
     m = m.to("cuda").eval()
@@ -706,5 +731,6 @@ def test_fuzz_single_scan_vs_c_oracle(gpu, seed):
     same = np.all(got_c == c0, axis=1)
     assert (same | ~gap_ok).all()
     if same.any():
-        assert np.allclose(_np(out["keypoints"][0, :k])[same], kp0[same], atol=2e-3 + 1e-4 * 8 * q)
+        qmax = max(q) if polar else q
+        assert np.allclose(_np(out["keypoints"][0, :k])[same], kp0[same], atol=(2e-2 if polar else 2e-3) + 1e-4 * 8 * qmax)
         assert H.cosine_err(_np(out["descriptors"][0, :k])[same], de0[same]).max() <= 1e-4

@@ -214,3 +214,23 @@ def test_c_openmp_oracle_matches_numpy_oracle_and_fixture():
     assert np.array_equal(coords, c2[:, 1:])
     assert np.allclose(kp, kp2, atol=2e-4) and H.cosine_err(desc, desc2).max() <= 1e-5
     assert H.cosine_err(g, g2).max() <= 1e-6
+
+
+def test_c_oracle_polar_matches_reference_fixture():
+    """oracle/egonn_cpu.c with the polar quantiser (the reference's shipped configuration, models/egonn.txt:3-5) against the
+    fixture produced by the reference's own graph code, and against the numpy restatement."""
+    from oracle import egonn_cpu, egonn_ref as ref
+    case = H.load_case("egonn_polar_b1")
+    w = H.seeded_weights(int(case["weight_seed"]))
+    pc = case["points_0"]
+    step = [float(v) for v in case["quantization_step"]]
+    g, kp, de, sc, sg, cnt = egonn_cpu.CpuOracle(w, step).compute_embedding(pc, 128)
+    assert H.cosine_err(g, case["global"]).max() < 1e-6
+    assert cnt[0] == len(case["quant_coords_0"])
+    want = {tuple(c): i for i, c in enumerate(case["topk_coords_0"][:, 1:].tolist())}
+    gap = np.r_[True, np.diff(case["topk_sigma_0"]) > 1e-5] & np.r_[np.diff(case["topk_sigma_0"]) > 1e-5, True]
+    same = np.array([want.get(tuple(c), -1) == i for i, c in enumerate(sc.tolist())])
+    assert (same | ~gap).all()
+    g2, kp2, de2, kc2, sg2 = ref.compute_embedding_with_sigma(ref.EgoNNOracle(w, ref.PolarQuantizer(step)), pc, 128)
+    assert np.array_equal(sc, kc2[:, 1:]) and np.allclose(kp, kp2, atol=1e-4) and np.allclose(sg, sg2, rtol=1e-4, atol=1e-6)
+    assert H.cosine_err(de, de2).max() < 1e-6
