@@ -59,6 +59,9 @@ _SIGS = [
     ("egonn_topk_rows", C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     ("egonn_triplet_loss_scratch_floats", C.c_int64, [C.c_int]),
     ("egonn_triplet_loss", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
+    ("egonn_nn_search", C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, _P, _P, _P]),
+    ("egonn_matrix_min", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
+    ("egonn_softmax_cross_entropy", C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
     ("egonn_dense", C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     ("egonn_dense_backward_weight", C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, _P, _P, C.c_int64, _P]),
     ("egonn_conv_backward_weight", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P,

@@ -85,6 +85,14 @@ size_t triplet_loss_scratch_floats(int n);
 int triplet_loss_forward(const float* emb, int n, int d, const uint8_t* pos, const uint8_t* neg, float margin,
                          float* out10, int32_t* triplets, float* grad, float* scratch, hipStream_t stream);
 
+// local-head losses (models/loss_utils.py): searches + softmax cross-entropy rows
+int nn_search(const float* a, int64_t n, const float* M, const float* b, int64_t m, float* out_dist, int32_t* out_idx,
+              hipStream_t stream);
+int matrix_min(const float* d, int64_t n, int64_t m, float* row_min, int32_t* row_idx, float* col_min, int32_t* col_idx,
+               hipStream_t stream);
+int softmax_ce(const float* logits, int64_t n, int64_t m, const int32_t* target, float* loss, int32_t* argmax, float* dlogits,
+               hipStream_t stream);
+
 // train.hip --------------------------------------------------------------------------------------
 // dW[k][ci][co] = sum_o in[nbr[o][k]][ci] * dout[o][co]; nbr == nullptr: identity map (K = 1, dense layer)
 int conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int64_t n_out, int K, int cin, int cout,

@@ -194,4 +194,154 @@ int triplet_loss_forward(const float* emb, int n, int d, const uint8_t* pos, con
   return EGONN_OK;
 }
 
+// ------------------------------------------------------------------ local-head losses (models/loss_utils.py)
+// KeypointLoss (:23-95) and CorrespondenceLoss (:108-139), driven per pair of scans by KeypointCorrLoss
+// (models/loss.py:43-92), need three searches that the reference does on dense torch.cdist matrices:
+//   * nearest keypoint of the other scan for every keypoint, both directions (probabilistic chamfer term, the classes of
+//     the correspondence term),
+//   * nearest cloud point for every keypoint (point-to-point term: torch.cdist(kp, pc) is keypoints x 50 k points),
+//   * a row-wise softmax cross-entropy over the (kp1 x kp2) descriptor-similarity matrix.
+// The kernels return indices and (for the CE) the loss rows + d loss / d logits; the differentiable tail that touches only
+// (n,3)/(n,1) tensors stays with the host's autograd (egonn_amd/local_loss.py).
+
+// nearest row of b (m,3) for every row of a (n,3), optionally transformed first: a' = R a + t (M: row-major 4x4, as
+// misc/poses.py:68-76 apply_transform).  Distances in the difference form (exact for coincident points); ties: lowest index.
+__global__ __launch_bounds__(256) void nn_search_kernel(const float* __restrict__ a, int32_t n, const float* __restrict__ M,
+                                                         const float* __restrict__ b, int32_t m,
+                                                         float* __restrict__ out_dist, int32_t* __restrict__ out_idx) {
+  __shared__ float sb[1024 * 3];
+  const int tid = threadIdx.x;
+  const int32_t i = blockIdx.x * 256 + tid;
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (i < n) {
+    const float x = a[3 * i], y = a[3 * i + 1], z = a[3 * i + 2];
+    if (M) {   // pc @ m[:3,:3].T + m[:3,3], accumulated left to right like the matmul
+      px = x * M[0] + y * M[1] + z * M[2] + M[3];
+      py = x * M[4] + y * M[5] + z * M[6] + M[7];
+      pz = x * M[8] + y * M[9] + z * M[10] + M[11];
+    } else {
+      px = x; py = y; pz = z;
+    }
+  }
+  float best = INFINITY;
+  int32_t bi = -1;
+  for (int32_t j0 = 0; j0 < m; j0 += 1024) {
+    const int32_t cnt = min(1024, m - j0);
+    __syncthreads();
+    for (int e = tid; e < cnt * 3; e += 256) sb[e] = b[(int64_t)j0 * 3 + e];
+    __syncthreads();
+    for (int32_t j = 0; j < cnt; ++j) {
+      const float dx = px - sb[3 * j], dy = py - sb[3 * j + 1], dz = pz - sb[3 * j + 2];
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      if (d2 < best) { best = d2; bi = j0 + j; }
+    }
+  }
+  if (i < n) {
+    out_dist[i] = sqrtf(best);
+    out_idx[i] = bi;
+  }
+}
+int nn_search(const float* a, int64_t n, const float* M, const float* b, int64_t m, float* out_dist, int32_t* out_idx,
+              hipStream_t stream) {
+  EGONN_REQUIRE(n >= 0 && m >= 1 && n < (1ll << 31) && m < (1ll << 31), EGONN_ERR_INVALID, "nn_search: bad sizes");
+  if (n == 0) return EGONN_OK;
+  hipLaunchKernelGGL(nn_search_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, a, (int32_t)n, M, b, (int32_t)m,
+                     out_dist, out_idx);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// torch.min(d, dim=1) and torch.min(d, dim=0) of a dense (n,m) matrix (the reference hands KeypointLoss / CorrespondenceLoss a
+// precomputed distance matrix): values + indices, ties: lowest index.  One wave per row; one thread per column.
+__global__ __launch_bounds__(256) void matrix_min_rows_kernel(const float* __restrict__ d, int32_t n, int32_t m,
+                                                               float* __restrict__ vmin, int32_t* __restrict__ imin) {
+  const int lane = threadIdx.x & 63;
+  const int32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  float best = INFINITY;
+  int32_t bi = 0x7FFFFFFF;
+  for (int32_t j = lane; j < m; j += 64) {
+    const float v = d[(int64_t)r * m + j];
+    if (v < best) { best = v; bi = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int32_t oi = __shfl_xor(bi, o, 64);
+    if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { vmin[r] = best; imin[r] = bi; }
+}
+__global__ void matrix_min_cols_kernel(const float* __restrict__ d, int32_t n, int32_t m, float* __restrict__ vmin,
+                                       int32_t* __restrict__ imin) {
+  const int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m) return;
+  float best = INFINITY;
+  int32_t bi = 0;
+  for (int32_t r = 0; r < n; ++r) {
+    const float v = d[(int64_t)r * m + c];
+    if (v < best) { best = v; bi = r; }
+  }
+  vmin[c] = best;
+  imin[c] = bi;
+}
+int matrix_min(const float* d, int64_t n, int64_t m, float* row_min, int32_t* row_idx, float* col_min, int32_t* col_idx,
+               hipStream_t stream) {
+  EGONN_REQUIRE(n >= 1 && m >= 1 && n < (1ll << 31) && m < (1ll << 31), EGONN_ERR_INVALID, "matrix_min: bad sizes");
+  hipLaunchKernelGGL(matrix_min_rows_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream, d, (int32_t)n, (int32_t)m,
+                     row_min, row_idx);
+  hipLaunchKernelGGL(matrix_min_cols_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, stream, d, (int32_t)n, (int32_t)m,
+                     col_min, col_idx);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// Row-wise softmax cross-entropy (torch.nn.CrossEntropyLoss on the similarity matrix, loss_utils.py:127-128): for every
+// row r with target[r] >= 0:  loss[r] = logsumexp(logits[r]) - logits[r][target[r]];  dlogits[r] = softmax(logits[r]) -
+// onehot(target[r]).  Rows with target < 0 (keypoints without a correspondence, :124-125) give 0.  One wave per row,
+// max-shifted exponentials, fixed-order reductions.  argmax[r] (ties: lowest index) serves the 'matching_descriptors' metric.
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, int32_t n, int32_t m,
+                                                          const int32_t* __restrict__ target, float* __restrict__ loss,
+                                                          int32_t* __restrict__ argmax, float* __restrict__ dlogits) {
+  const int lane = threadIdx.x & 63;
+  const int32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const float* row = logits + (int64_t)r * m;
+  const int32_t t = target[r];
+  float mx = -INFINITY;
+  int32_t mi = 0x7FFFFFFF;
+  for (int32_t j = lane; j < m; j += 64) {
+    const float v = row[j];
+    if (v > mx) { mx = v; mi = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(mx, o, 64);
+    const int32_t oi = __shfl_xor(mi, o, 64);
+    if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+  }
+  float se = 0.f;
+  for (int32_t j = lane; j < m; j += 64) se += expf(row[j] - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+  if (lane == 0) {
+    loss[r] = (t >= 0) ? (logf(se) + mx - row[t]) : 0.f;
+    argmax[r] = mi;
+  }
+  if (dlogits) {
+    const float inv = 1.f / se;
+    for (int32_t j = lane; j < m; j += 64)
+      dlogits[(int64_t)r * m + j] = (t >= 0) ? (expf(row[j] - mx) * inv - (j == t ? 1.f : 0.f)) : 0.f;
+  }
+}
+int softmax_ce(const float* logits, int64_t n, int64_t m, const int32_t* target, float* loss, int32_t* argmax, float* dlogits,
+               hipStream_t stream) {
+  EGONN_REQUIRE(n >= 0 && m >= 1 && n < (1ll << 31) && m < (1ll << 31), EGONN_ERR_INVALID, "softmax_ce: bad sizes");
+  if (n == 0) return EGONN_OK;
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, stream, logits, (int32_t)n, (int32_t)m,
+                     target, loss, argmax, dlogits);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
 }  // namespace egonn

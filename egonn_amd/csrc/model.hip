@@ -906,6 +906,23 @@ API int egonn_triplet_loss(const float* embeddings, int n, int d, const uint8_t*
 }
 
 
+// ------------------------------------------------------------------------------------------ local-head losses
+API int egonn_nn_search(const float* a, int64_t n, const float* transform, const float* b, int64_t m, float* out_dist,
+                        int32_t* out_index, void* stream) {
+  EGONN_REQUIRE(a && b && out_dist && out_index, EGONN_ERR_INVALID, "nn_search: null argument");
+  return nn_search(a, n, transform, b, m, out_dist, out_index, (hipStream_t)stream);
+}
+API int egonn_matrix_min(const float* d, int64_t n, int64_t m, float* row_min, int32_t* row_index, float* col_min,
+                         int32_t* col_index, void* stream) {
+  EGONN_REQUIRE(d && row_min && row_index && col_min && col_index, EGONN_ERR_INVALID, "matrix_min: null argument");
+  return matrix_min(d, n, m, row_min, row_index, col_min, col_index, (hipStream_t)stream);
+}
+API int egonn_softmax_cross_entropy(const float* logits, int64_t n, int64_t m, const int32_t* target, float* out_loss,
+                                    int32_t* out_argmax, float* out_dlogits, void* stream) {
+  EGONN_REQUIRE(logits && target && out_loss && out_argmax, EGONN_ERR_INVALID, "softmax_cross_entropy: null argument");
+  return softmax_ce(logits, n, m, target, out_loss, out_argmax, out_dlogits, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------------------------------ training-mode operators
 #define REQUIRE_LEVEL(c, level)                                                                              \
   REQUIRE_PLAN(c);                                                                                           \

@@ -184,6 +184,22 @@ int egonn_triplet_loss(const float* embeddings, int n, int d, const uint8_t* pos
                        const uint8_t* negatives_mask, float margin, float* out_stats, int32_t* out_triplets,
                        float* out_grad, float* scratch, void* stream);
 
+/* ------------------------------------------------------------------ local-head losses (training)
+ * replaces the dense torch.cdist / torch.min / CrossEntropyLoss work of KeypointLoss (models/loss_utils.py:23-95) and
+ * CorrespondenceLoss (:108-139), driven per pair of scans by KeypointCorrLoss (models/loss.py:43-92).  The kernels return
+ * indices, distances and d loss / d logits; the differentiable tail on (n,3)/(n,1) tensors is the host's autograd. */
+/* Nearest row of b (m,3) for every row of a (n,3), a optionally transformed first by the row-major 4x4 `transform`
+ * (misc/poses.py:68-76; device pointer, NULL = none): torch.min(torch.cdist(a', b), dim=1) without the matrix. */
+int egonn_nn_search(const float* a, int64_t n, const float* transform, const float* b, int64_t m, float* out_dist,
+                    int32_t* out_index, void* stream);
+/* torch.min(d, dim=1) and torch.min(d, dim=0) of a dense (n,m) matrix: values and indices (ties: lowest index). */
+int egonn_matrix_min(const float* d, int64_t n, int64_t m, float* row_min, int32_t* row_index, float* col_min,
+                     int32_t* col_index, void* stream);
+/* nn.CrossEntropyLoss rows on (n,m) logits: target (n) int32, < 0 = row ignored.  out_loss (n), out_argmax (n),
+ * out_dlogits (n,m) = softmax - onehot (nullable). */
+int egonn_softmax_cross_entropy(const float* logits, int64_t n, int64_t m, const int32_t* target, float* out_loss,
+                                int32_t* out_argmax, float* out_dlogits, void* stream);
+
 /* ------------------------------------------------------------------ training-mode operators (configs[3])
  * The reference trains through MinkowskiEngine's autograd (training/trainer.py:160-175: model.train(); y = model(batch);
  * loss.backward()).  Backward of a sparse convolution w.r.t. its input is again a sparse convolution on the cached

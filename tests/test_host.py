@@ -5,6 +5,7 @@ import json
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -74,6 +75,27 @@ def test_training_mode_has_no_cpu_path_either(built):
     m = model_factory(ModelParams(model="egonn", coordinates="cartesian", quantization_step=0.1)).train()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m({"coords": torch.zeros((1, 4), dtype=torch.int32), "features": torch.ones((1, 1))})
+
+
+def test_local_losses_have_no_cpu_path_and_fixture_is_complete(built):
+    """the local-head losses (reference models/loss_utils.py) run only on the HIP device; their golden vectors (made by
+    importing the reference, tests/golden/make_golden_losses.py) carry every array the GPU tests read."""
+    import os
+    from egonn_amd import KeypointLoss, CorrespondenceLoss
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "local_losses.npz"))
+    for name in fx["cases"]:
+        for k in ("pc1", "pc2", "kp1", "kp2", "sigma1", "sigma2", "desc1", "desc2", "M", "dist", "loss_keypoint", "loss_correspondence",
+                  "loss_total", "f64_loss_total", "leaf_grad_dist", "grad_kp1", "f64_grad_desc2", "f64_leaf_grad_kp2",
+                  "metric_matching_keypoints", "f64_metric_repeatability"):
+            assert f"{name}_{k}" in fx.files, (name, k)
+        assert fx[f"{name}_dist"].shape == (len(fx[f"{name}_kp1"]), len(fx[f"{name}_kp2"]))
+        assert np.isfinite(fx[f"{name}_loss_total"]) and abs(float(fx[f"{name}_loss_total"]) - float(fx[f"{name}_f64_loss_total"])) < 1e-3
+    if not torch.cuda.is_available():
+        a = {k: torch.from_numpy(fx[f"a_{k}"]) for k in ("pc1", "pc2", "kp1", "kp2", "sigma1", "sigma2", "desc1", "desc2", "dist")}
+        with pytest.raises(RuntimeError, match="HIP device"):
+            KeypointLoss()(a["pc1"], a["kp1"], a["sigma1"], a["pc2"], a["kp2"], a["sigma2"], a["dist"])
+        with pytest.raises(RuntimeError, match="HIP device"):
+            CorrespondenceLoss(beta=2.0)(a["desc1"], a["desc2"], a["dist"])
 
 
 def test_synthetic_generator_is_deterministic():
