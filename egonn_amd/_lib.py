@@ -25,6 +25,8 @@ _SIGS = [
     ("egonn_ctx_destroy", None, [_P]),
     ("egonn_last_error", C.c_char_p, []),
     ("egonn_debug_set_naive_conv", C.c_int, [_P, C.c_int]),
+    ("egonn_debug_set_trace", C.c_int, [_P]),
+    ("egonn_debug_rowgroup_tables", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int64), _P]),
     ("egonn_voxelize", C.c_int, [_P, _P, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     ("egonn_ctx_reserve", C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
     ("egonn_voxelize_device", C.c_int, [_P, _P, C.c_int64, _P, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
@@ -293,6 +295,18 @@ class Context:
         with torch.cuda.device(self.device):
             check(self.lib.egonn_map_groups(self.h, map_kind, level_out, C.byref(n), first, _stream()))
         return n.value, list(first)
+
+    def rowgroup_tables(self, map_kind: int, level_out: int, with_rows: bool = True):
+        """measurement hook: (gmask [groups] int32 view of u32, snbr [groups, K, 16] int32) of a map's row-group tables."""
+        ng, _ = self.map_groups(map_kind, level_out)
+        K = 27 if map_kind == 0 else 8
+        gm = torch.empty(ng, dtype=torch.int32, device=self.device)
+        sn = torch.empty((ng, K, 16), dtype=torch.int32, device=self.device) if with_rows else None
+        n = C.c_int64()
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_debug_rowgroup_tables(self.h, map_kind, level_out, gm.data_ptr(), sn.data_ptr() if with_rows else None,
+                                                       ng, C.byref(n), _stream()))
+        return gm, sn
 
     def set_naive_conv(self, on: bool):
         """tests only: route this context's sparse convolutions through the plain (non-MFMA) kernel."""

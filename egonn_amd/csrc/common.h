@@ -107,7 +107,7 @@ struct RowGroups {
   int win = 0;                // rows per sort window (256 / 512 / 1024); groups per window = win / 16
   int cap_groups = 0;         // groups the arrays can hold (multiple of win / 16)
   int32_t* perm = nullptr;    // [cap_groups][16]      output row of every slot, -1 = padding
-  int32_t* snbr = nullptr;    // [cap_groups][K][16]   input row + 1, 0 = no neighbour
+  int32_t* snbr = nullptr;    // [cap_groups][K][16]   input row, -1 = no neighbour
   uint32_t* gmask = nullptr;  // [cap_groups]          OR of the 16 presence masks; bit 31 = group has real rows
   int32_t* meta = nullptr;    // [0] groups in use, [1 + b] first group of sample b (b = 0..B)
   bool built = false;

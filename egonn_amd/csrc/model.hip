@@ -80,7 +80,7 @@ API const char* egonn_last_error(void) { return last_error(); }
 
 API int egonn_debug_set_naive_conv(egonn_ctx* c, int on) {
   EGONN_REQUIRE(c, EGONN_ERR_INVALID, "debug_set_naive_conv: null context");
-  c->conv_variant = (on == 1) ? 3 : (on == 2 ? 1 : (on == 4 ? 2 : 0));
+  c->conv_variant = (on == 1) ? 3 : (on == 2 ? 1 : (on == 4 ? 2 : (on == 8 ? 4 : (on == 16 ? 5 : (on == 32 ? 6 : (on == 128 ? 9 : 0))))));
   return EGONN_OK;
 }
 
@@ -102,7 +102,6 @@ API int egonn_ctx_create(egonn_ctx** out, int device, int coord_bits) {
   const size_t hc = sizeof(int32_t) * (32 + (size_t)EGONN_NUM_LEVELS * (EGONN_MAX_BATCH + 1)) + sizeof(int64_t) * (EGONN_MAX_BATCH + 2);
   if (hipHostMalloc(reinterpret_cast<void**>(&c->host_counts), hc) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&c->dev_counts), sizeof(int32_t) * 32) != hipSuccess ||
-      false ||
       hipMalloc(reinterpret_cast<void**>(&c->dev_pairs), sizeof(unsigned long long) * 16) != hipSuccess) {
     set_error("ctx_create: allocation failed");
     delete c;
@@ -340,6 +339,34 @@ API int egonn_sparse_conv(egonn_ctx* c, int map_kind, int level_out, const void*
   return sconv_map(c, map_kind, level_out, in, kernel, nullptr, cin, cout, bf16, scale, shift, relu, out, group_sums,
                    op_scratch(c), SCONV_SCRATCH_FLOATS, (hipStream_t)stream);
 }
+// Measurement hook (tools/sconv_trace.py): device buffer the traced conv build (debug variant 128) writes its per-task
+// timestamps into (8 u64 per wave task); null switches it off.
+API int egonn_debug_set_trace(void* buf) {
+  g_sconv_trace = reinterpret_cast<unsigned long long*>(buf);
+  return EGONN_OK;
+}
+
+// Measurement hook (tools/rowgroup_stats.py): device copies of a map's row-group tables.  gmask_out: [groups] u32;
+// snbr_out: [groups][K][16] i32 (nullable).  Returns the number of groups copied (<= capacity_groups).  [SYNC]
+API int egonn_debug_rowgroup_tables(egonn_ctx* c, int map_kind, int level_out, uint32_t* gmask_out, int32_t* snbr_out,
+                                    int64_t capacity_groups, int64_t* n_groups, void* stream) {
+  REQUIRE_PLAN(c);
+  HIP_CHECK(hipSetDevice(c->device));
+  EGONN_REQUIRE(n_groups && gmask_out, EGONN_ERR_INVALID, "rowgroup_tables: null argument");
+  EGONN_TRY(ensure_rowgroups(c, &map_kind, &level_out, 1, (hipStream_t)stream));
+  const Level& V = c->plan.lv[level_out];
+  const RowGroups& rg = map_kind == 0 ? V.rg27 : (map_kind == 1 ? V.rg8 : V.rgT);
+  int32_t ng = 0;
+  HIP_CHECK(hipMemcpyAsync(&ng, rg.meta, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  EGONN_REQUIRE(ng <= capacity_groups, EGONN_ERR_INVALID, "rowgroup_tables: %d groups, room for %lld", ng, (long long)capacity_groups);
+  HIP_CHECK(hipMemcpyAsync(gmask_out, rg.gmask, (size_t)ng * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (snbr_out)
+    HIP_CHECK(hipMemcpyAsync(snbr_out, rg.snbr, (size_t)ng * rg.K * 16 * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  *n_groups = ng;
+  return EGONN_OK;
+}
+
 // Number of row groups (16 output rows each) of a map: rows of the `group_sums` output of egonn_sparse_conv; the groups of
 // sample b are [first_group[b], first_group[b+1]) (HOST copy, B+1 entries).  [SYNC]
 API int egonn_map_groups(egonn_ctx* c, int map_kind, int level_out, int64_t* n_groups, int64_t* first_group, void* stream) {

@@ -13,7 +13,7 @@
 //     benchmark clouds: MFMA work = 1.40-1.49 x the pair count (unsorted 16-row groups: 1.8-2.0 x, dense 27: 3.5-4.3 x);
 //   * per group g:  gmask[g] = OR of the 16 masks (bit 31: group holds at least one real row),
 //                   perm[g*16 + s] = output row of slot s (-1 = padding),
-//                   snbr[(g*K + k)*16 + s] = input row + 1 (0 = absent): one coalesced 64-byte line per (g, k).
+//                   snbr[(g*K + k)*16 + s] = input row (-1 = absent): one coalesced 64-byte line per (g, k).
 // Window slot w owns the WIN/16 groups [w*GPW, (w+1)*GPW); partial windows leave trailing groups empty.  All sizes
 // are read from device memory (row count, per-sample offsets), so the builder needs no host knowledge of N_l.
 #include <type_traits>
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
 #pragma unroll
       for (int h = 0; h < 8; ++h) key[h] = skey[gl * 16 + 2 * h + half];
 #pragma unroll
-      for (int h = 0; h < 8; ++h) v[h] = (kk < 27 && key[h] != ~0ull) ? src[(int)(key[h] & 0xFFFFu) * 27 + kk] + 1 : 0;
+      for (int h = 0; h < 8; ++h) v[h] = (kk < 27 && key[h] != ~0ull) ? src[(int)(key[h] & 0xFFFFu) * 27 + kk] : -1;
 #pragma unroll
       for (int h = 0; h < 8; ++h)
         if (kk < 27) tile[kk * 16 + 2 * h + half] = v[h];
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) key[h] = skey[gl * 16 + 8 * h + sub];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) v[h] = (key[h] != ~0ull) ? src[(int)(key[h] & 0xFFFFu) * 8 + kk] + 1 : 0;
+      for (int h = 0; h < 2; ++h) v[h] = (key[h] != ~0ull) ? src[(int)(key[h] & 0xFFFFu) * 8 + kk] : -1;
 #pragma unroll
       for (int h = 0; h < 2; ++h) tile[kk * 16 + 8 * h + sub] = v[h];
     }

@@ -110,35 +110,44 @@ struct SconvArgs {
   float* psum;               // [groups][COUT] column sums of the stored values (nullable)
   uint32_t in_bytes, w_bytes;
   int K, relu;
+  unsigned long long* trace = nullptr;   // measurement builds only (tools/sconv_trace.py): 8 u64 per wave task
 };
 
 // KSP > 1 (layers with >= 64 input channels): the KSP waves of a workgroup that share one (group, 32-column) tile each
 // take 1/KSP of the input-channel blocks and the partial accumulators are summed through LDS in fixed order — shorter
 // dependent item chains per wave and KSP x the waves in flight (the tail levels have a few hundred groups: without the
 // split one wave per SIMD walked 40 dependent items while the chip idled).
-template <int CIN, int COUT, bool BF16, int D, int KSP>
+// G > 1: a wave owns G CONSECUTIVE groups (sorted by mask => nearly the same offsets present) and walks the union of their
+// offsets; the W fragments of an item are loaded ONCE and feed the MFMAs of all G groups.  With G = 1 four of the six
+// vector loads of an item are W fragments and the CU's single texture-address path is ~75 % busy feeding four SIMDs
+// (6 loads x 16 cycles x 4 waves per 512 MFMA cycles); G = 2 makes it 8 loads per 1024 MFMA cycles.  A group that lacks
+// the offset skips the item's MFMAs (wave-uniform branch; its gather rows are "-1" and cost no memory traffic).  The sum
+// order of every output row is unchanged (ascending k, ascending channel) => results are bitwise identical for every G.
+template <int CIN, int COUT, bool BF16, int D, int KSP, int G>
 __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
   constexpr int NS = COUT / 32, NCB = CIN / 32;
   constexpr int NCBL = NCB / KSP;                        // channel blocks per wave
   constexpr int TPW = 4 / KSP;                           // tiles per workgroup
   static_assert(NCB % KSP == 0 && 4 % KSP == 0, "bad channel split");
   constexpr int ES = BF16 ? 2 : 4;                       // bytes per feature element
-  constexpr int ALD = BF16 ? 1 : 2;                      // b128 loads of A per lane per item
+  constexpr int ALD = BF16 ? 1 : 2;                      // b128 loads of A per lane per item and group
   constexpr int WLD = BF16 ? 2 : 4;                      // b128 loads of W per lane per item
   constexpr uint32_t ITEM_BYTES = 32 * 32 * ES;
+  constexpr int NPIECE = (G * 27 * 4 + 63) / 64;         // 16-byte pieces of the neighbour table per lane
+  constexpr int LDSW = NPIECE * 64 * 4 + 16;             // ints of wave-private LDS (table + one all-absent row)
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, g4 = lane >> 4;
   const int K = p.K;
-  int32_t* const ldsw = lds + wave * ((27 + 1) * 16);
-  f32x4* const red = reinterpret_cast<f32x4*>(lds + 4 * 28 * 16);      // [2 parities][4 waves][2 tiles][64 lanes] (KSP > 1)
+  int32_t* const ldsw = lds + wave * LDSW;
+  f32x4* const red = reinterpret_cast<f32x4*>(lds + 4 * LDSW);         // [2 parities][4 waves][G][2 tiles][64 lanes] (KSP > 1)
 
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wp), 0, (int)p.w_bytes, 0x00020000);
 
-  const int ngroups = __builtin_amdgcn_readfirstlane(p.meta[0]);
-  const int ntiles = ngroups * NS;
+  const int ngroups = __builtin_amdgcn_readfirstlane(p.meta[0]);       // a multiple of 16
+  const int ntiles = (ngroups / G) * NS;
   const int ntask = (ntiles + TPW - 1) / TPW;            // workgroup tasks
   // every XCD (block b runs on XCD b % 8) takes one contiguous eighth of the tasks: its slice of the feature map
   // (Z-order => spatially compact) and the kernel fit its 4 MB L2.  Measured: interleaving 256-row chunks over the
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
   int par = 0;
 
   // ---- epilogue: BN scale/shift (+ReLU), one store per tile; optional per-group column sums
-  auto epilogue = [&](const f32x4 (&acc)[2], int g, int ns, int32_t row, const f32x4 (&sc)[2], const f32x4 (&sh)[2]) {
+  auto epilogue = [&](const f32x4* acc, int g, int ns, int32_t row, const f32x4 (&sc)[2], const f32x4 (&sh)[2]) {
     float sums[2][4];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -195,23 +204,31 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
   for (int lt = blockIdx.x >> 3; lt < cpx; lt += nper) {
     const int task = xcd * cpx + lt;
     const int tile = task * TPW + wave / KSP;
-    const int g = tile / NS, ns = tile - g * NS;
-    // Everything that does not depend on other loads is requested up front: the group mask, the group's neighbour
+    const int sg = tile / NS, ns = tile - sg * NS;
+    const int g0 = sg * G;
+    // Everything that does not depend on other loads is requested up front: the group masks, the groups' neighbour
     // rows, the output rows of the epilogue and the BatchNorm vectors (a small launch is a chain of memory latencies —
     // levels 5-7 ran 20 us per launch for < 2 us of MFMA work when these loads were issued one after the other)
     const bool tile_ok = task < ntask && tile < ntiles;
-    uint32_t gm = 0;
-    int4 v0 = make_int4(0, 0, 0, 0), v1 = make_int4(0, 0, 0, 0);
-    int32_t orow = -1;
+    uint32_t gm[G];
+    int4 piece[NPIECE];
+    int32_t orow[G];
     f32x4 bsc[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, bsh[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int j = 0; j < G; ++j) { gm[j] = 0; orow[j] = -1; }
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) piece[i] = make_int4(-1, -1, -1, -1);
     if (tile_ok) {
-      const int4* src = reinterpret_cast<const int4*>(p.snbr + (int64_t)g * K * 16);
-      const int n16 = K * 4;                             // 16-byte pieces
-      gm = p.gmask[g];
-      if (lane < n16) v0 = src[lane];
-      if (lane + 64 < n16) v1 = src[lane + 64];
+      const int4* src = reinterpret_cast<const int4*>(p.snbr + (int64_t)g0 * K * 16);
+      const int n16 = G * K * 4;                         // 16-byte pieces
+#pragma unroll
+      for (int j = 0; j < G; ++j) gm[j] = p.gmask[g0 + j];
+#pragma unroll
+      for (int i = 0; i < NPIECE; ++i)
+        if (lane + 64 * i < n16) piece[i] = src[lane + 64 * i];
       if (sub == 0) {
-        orow = p.perm[(int64_t)g * 16 + l15];
+#pragma unroll
+        for (int j = 0; j < G; ++j) orow[j] = p.perm[(int64_t)(g0 + j) * 16 + l15];
         if (p.scale) {
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
@@ -221,77 +238,92 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
         }
       }
     }
-    gm = __builtin_amdgcn_readfirstlane(gm);
-    const bool active = (gm >> 31) != 0;
+    uint32_t un = 0;
+#pragma unroll
+    for (int j = 0; j < G; ++j) { gm[j] = __builtin_amdgcn_readfirstlane(gm[j]); un |= gm[j]; }
+    const bool active = (un >> 31) != 0;
     if constexpr (KSP == 1) {
       if (!active) continue;                             // no barrier in this configuration: waves are independent
     }
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[G][2];
+#pragma unroll
+    for (int j = 0; j < G; ++j) acc[j][0] = acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if (KSP == 1 || active) {
-      // ---- the group's neighbour rows (K x 16 ints) + one all-absent row -> wave-private LDS (an inactive group's
-      // table is never indexed: its mask has no offsets)
+      // ---- the groups' neighbour rows (G x K x 16 ints, same order as in memory) + one all-absent row -> wave-private
+      // LDS (an inactive group's rows are all absent)
       {
-        if (!active) { v0 = make_int4(0, 0, 0, 0); v1 = make_int4(0, 0, 0, 0); }
-        reinterpret_cast<int4*>(ldsw)[lane] = v0;        // lanes >= n16 write zeros: row K (all absent) and beyond
-        if (lane + 64 < 28 * 4) reinterpret_cast<int4*>(ldsw)[lane + 64] = v1;
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) reinterpret_cast<int4*>(ldsw)[lane + 64 * i] = piece[i];   // beyond n16: zeros
+        if (lane < 4) reinterpret_cast<int4*>(ldsw)[NPIECE * 64 + lane] = make_int4(-1, -1, -1, -1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
 
-      // ---- item generator (scalar): set bits of the group mask x this wave's channel blocks
-      uint32_t mk = gm & 0x07FFFFFFu;
+      // ---- item generator (scalar): set bits of the union mask x this wave's channel blocks
+      uint32_t mk = un & 0x07FFFFFFu;
       const int n_items = __builtin_amdgcn_readfirstlane(__popc(mk) * NCBL);
       int gen_k = 0, gen_cb = 0;
       // pending item (the one whose loads are issued next)
-      int32_t pend_idx;                                  // raw LDS value: consumed one step later, so the read latency is hidden
+      int32_t pend_idx[G];                               // raw LDS values: consumed one step later, so the read latency is hidden
       uint32_t pend_acb;
       uint32_t pend_woff, pend_wbad;
+      int pend_bit;                                      // offset of the pending item (27 = none: no group has that bit)
       auto generate = [&]() {                            // branch-free: scalar selects only
         const bool need = (gen_cb == 0);
         const bool take = need && (mk != 0);
         const bool valid = !need || take;                // items in the middle of a k are always real
         gen_k = take ? __builtin_ctz(mk | 0x80000000u) : gen_k;
         mk = take ? (mk & (mk - 1)) : mk;
-        const int krow = valid ? gen_k : K;
         const int cb = sub * NCBL + gen_cb;
-        pend_idx = ldsw[krow * 16 + l15];
+#pragma unroll
+        for (int j = 0; j < G; ++j) pend_idx[j] = ldsw[(valid ? (j * K + gen_k) * 16 : NPIECE * 256) + l15];
         pend_acb = (uint32_t)(cb * 32 * ES);
         pend_woff = (uint32_t)(((gen_k * NCB + cb) * NS + ns)) * ITEM_BYTES;
         pend_wbad = valid ? 0u : 0x80000000u;
+        pend_bit = valid ? gen_k : 27;
         gen_cb = (valid && gen_cb + 1 < NCBL) ? gen_cb + 1 : 0;
       };
 
-      f32x4 aring[D][ALD];
+      f32x4 aring[D][G][ALD];
       f32x4 wring[D][WLD];
+      int bitring[D];
       auto issue = [&](auto RS) {
         constexpr int rs = decltype(RS)::value;
-        const uint32_t pend_aoff = (uint32_t)(pend_idx - 1) * (uint32_t)(CIN * ES) + pend_acb + (uint32_t)(g4 * 16);
         const int wv = (int)((uint32_t)(lane * 16) | pend_wbad);
         const int ws = __builtin_amdgcn_readfirstlane((int)pend_woff);
+        bitring[rs] = pend_bit;
 #pragma unroll
         for (int i = 0; i < WLD; ++i)
           wring[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv + i * 1024, ws, 0));
 #pragma unroll
-        for (int i = 0; i < ALD; ++i)
-          aring[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(pend_aoff + 64 * i), 0, 0));
+        for (int j = 0; j < G; ++j) {
+          const uint32_t aoff = (uint32_t)pend_idx[j] * (uint32_t)(CIN * ES) + pend_acb + (uint32_t)(g4 * 16);
+#pragma unroll
+          for (int i = 0; i < ALD; ++i)
+            aring[rs][j][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(aoff + 64 * i), 0, 0));
+        }
       };
       auto compute = [&](auto RS) {
         constexpr int rs = decltype(RS)::value;
-        if constexpr (BF16) {
-          const bf16x8_t av = __builtin_bit_cast(bf16x8_t, aring[rs][0]);
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wring[rs][nt]), av, acc[nt], 0, 0, 0);
-        } else {
+        for (int j = 0; j < G; ++j) {
+          if (G > 1 && !((gm[j] >> bitring[rs]) & 1u)) continue;        // wave-uniform
+          if constexpr (BF16) {
+            const bf16x8_t av = __builtin_bit_cast(bf16x8_t, aring[rs][j][0]);
 #pragma unroll
-          for (int tt = 0; tt < 2; ++tt)
+            for (int nt = 0; nt < 2; ++nt)
+              acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wring[rs][nt]), av, acc[j][nt], 0, 0, 0);
+          } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-              for (int nt = 0; nt < 2; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wring[rs][nt * 2 + tt][u], aring[rs][tt][u], acc[nt], 0, 0, 0);
+              for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                  acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wring[rs][nt * 2 + tt][u], aring[rs][j][tt][u], acc[j][nt], 0, 0, 0);
+          }
         }
       };
 
@@ -316,26 +348,353 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
         ((Is < rem ? compute(std::integral_constant<int, Is>{}) : (void)0), ...);
       }(std::make_integer_sequence<int, D - 1>{});
       __builtin_amdgcn_wave_barrier();                   // the next task overwrites the wave's LDS rows
-      if constexpr (KSP == 1) epilogue(acc, g, ns, orow, bsc, bsh);
+      if constexpr (KSP == 1) {
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+          if (gm[j] >> 31) epilogue(acc[j], g0 + j, ns, orow[j], bsc, bsh);
+      }
     }
 
     if constexpr (KSP > 1) {                             // fixed-order sum of the channel-split partials
-      f32x4* r = red + ((par * 4 + wave) * 2) * 64 + lane;
+      f32x4* r = red + ((par * 4 + wave) * 2 * G) * 64 + lane;
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        r[(2 * j) * 64] = acc[j][0];
+        r[(2 * j + 1) * 64] = acc[j][1];
+      }
+      __syncthreads();
+      if (sub == 0) {
+#pragma unroll
+        for (int q = 1; q < KSP; ++q) {
+          const f32x4* o = red + ((par * 4 + wave + q) * 2 * G) * 64 + lane;
+#pragma unroll
+          for (int j = 0; j < G; ++j) {
+            acc[j][0] += o[(2 * j) * 64];
+            acc[j][1] += o[(2 * j + 1) * 64];
+          }
+        }
+      }
+      par ^= 1;
+      if (active && sub == 0) {
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+          if (gm[j] >> 31) epilogue(acc[j], g0 + j, ns, orow[j], bsc, bsh);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ gather by LDS-DMA (fp32 maps)
+// What the ablation of the kernel above measured (profiles/r02n_sconv_ablation.txt, L1 32->32 fp32, 65 us): with the
+// MFMAs removed and every load hitting one cache line it still ran 57 us; W loads alone cost 15 us, the gathers alone
+// 21-26 us, the same gathers issued as FULL 128-byte lines (8 lanes per row, 8 rows per instruction) 10 us; and the
+// MFMAs alone ran at 2/3 of their rate because ~16 vector instructions of address arithmetic sat between every
+// 16-MFMA block (tools/exp/mfma_mix.hip: vector instructions between MFMA blocks cost MFMA time, scalar ones do not).
+// Here
+//  * the gathered rows go global -> LDS with buffer_load_dwordx4 ... lds in full-line pieces (two 1 KB pieces per item:
+//    rows 0-7 and 8-15; lane L fetches chunk (L&7)^(L>>3) of row L>>3, so the lane-linear LDS image is XOR-swizzled) and
+//    the operand fragments come back with two conflict-free ds_read_b128 (lane (row, g): chunks g and 4+g of its row);
+//  * the feature map is addressed as a STRUCTURED buffer (stride = row bytes): vindex = the neighbour row straight from
+//    the table (-1 = absent -> out of range -> zeros, no memory traffic), voffset = the lane's constant chunk, soffset =
+//    the channel block: the texture-address unit does the multiply-add, the loop has no vector address arithmetic;
+//  * the ring of gathered items lives in LDS, not in VGPRs; W fragments stay in a register ring.
+// The compiler does not know that an LDS-DMA write feeds a later ds_read, and would drain the whole ring (vmcnt(0)) in
+// front of any LDS read it can see; every LDS read inside the item loop is therefore issued from one asm statement per
+// item that carries its own counted s_waitcnt vmcnt and its own lgkmcnt(0).
+// Arithmetic (MFMA order, channel permutation, W packing, epilogue) is identical to sconv_rg_kernel => bitwise equal.
+__device__ static inline float row16_sum(float v) {      // sum over the 16 lanes of a DPP row (= the 16 rows of a tile)
+  int x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));   // row_half_mirror
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
+template <int CIN, int COUT, int D, int KSP, bool TRACE = false>
+__global__ __launch_bounds__(256) void sconv_dma_kernel(const SconvArgs p) {
+  constexpr int NS = COUT / 32, NCB = CIN / 32;
+  constexpr int NCBL = NCB / KSP;
+  constexpr int TPW = 4 / KSP;
+  static_assert(NCB % KSP == 0 && 4 % KSP == 0, "bad channel split");
+  constexpr uint32_t ITEM_BYTES = 32 * 32 * 4;
+  constexpr int TBL = 2 * 256 + 32;                      // ints: 27 x 16 neighbour rows (padded to 512) + an all-absent row; 128-byte multiple
+  constexpr int SLOT = 2048;                             // one gathered item: 16 rows x 128 B
+  constexpr int WAVE_LDS = TBL * 4 + D * SLOT;
+  constexpr int VM_PER_ITEM = 6;                         // 4 W loads + 2 LDS-DMA pieces
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int K = p.K;
+  char* const wl = smem + wave * WAVE_LDS;
+  int32_t* const ldsw = reinterpret_cast<int32_t*>(wl);
+  char* const ring = wl + TBL * 4;
+  typedef __attribute__((address_space(3))) char lds_char;
+  const uint32_t wl_addr = (uint32_t)(uintptr_t)(lds_char*)wl;          // LDS byte address of this wave's region
+  // operand read addresses inside a slot: chunks g and 4+g of row l15 (XOR swizzle, see above)
+  const uint32_t rd0 = wl_addr + TBL * 4 + (uint32_t)(l15 * 128 + ((g4 ^ (l15 & 7)) * 16));
+  const uint32_t rd1 = wl_addr + TBL * 4 + (uint32_t)(l15 * 128 + (((4 + g4) ^ (l15 & 7)) * 16));
+  // neighbour-table read address of this lane's DMA rows (rows L>>3 and 8 + (L>>3))
+  const uint32_t tb0 = wl_addr + (uint32_t)((lane >> 3) * 4);
+  const int dma_chunk = ((lane & 7) ^ (lane >> 3)) * 16;
+  const int w_lane = lane * 16;
+
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), (short)(CIN * 4), (int)(p.in_bytes / (CIN * 4)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wp), 0, (int)p.w_bytes, 0x00020000);
+
+  const int ngroups = __builtin_amdgcn_readfirstlane(p.meta[0]);
+  const int ntiles = ngroups * NS;
+  const int ntask = (ntiles + TPW - 1) / TPW;
+  // one workgroup per task (the hardware dispatcher balances the uneven tasks), contiguous eighth of the tasks per XCD.
+  // A PERSISTENT variant of this kernel (resident workgroups pulling tiles from per-XCD atomic counters, next tables
+  // prefetched, no relaunch) was built and measured: 111 us vs 62 us on L1 32->32 (profiles/r02n_sconv_ablation.txt) —
+  // with all 16 wave slots of a CU live the per-item time rose from 1400 to 1870 cycles: the CU's vector-memory path is the
+  // shared bottleneck and more resident waves only deepen its queue and thrash the 32 KB L1 with W fragments.
+  const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3;
+  const int cpx = (ntask + 7) >> 3;
+  const int sub = wave % KSP;
+
+  auto epilogue = [&](const f32x4* acc, int g, int ns, int32_t row) {
+    float sums[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int c0 = ns * 32 + nt * 16 + 4 * g4;
+      f32x4 v = acc[nt];
+      if (p.scale) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c0);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + c0);
+        v = v * sc + sh;
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+      }
+      if (row >= 0) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (int64_t)row * COUT + c0) = v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sums[nt][u] = row >= 0 ? v[u] : 0.f;
+    }
+    if (p.psum) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sums[nt][u] = row16_sum(sums[nt][u]);
+      if (l15 == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          *reinterpret_cast<f32x4*>(p.psum + (int64_t)g * COUT + ns * 32 + nt * 16 + 4 * g4) =
+              (f32x4){sums[nt][0], sums[nt][1], sums[nt][2], sums[nt][3]};
+      }
+    }
+  };
+
+  for (int lt = blockIdx.x >> 3; lt < cpx; lt += nper) {
+    const int task = xcd * cpx + lt;
+    const int tile = task * TPW + wave / KSP;
+    const int g = tile / NS, ns = tile - g * NS;
+    const bool tile_ok = task < ntask && tile < ntiles;
+    uint32_t gm = 0;
+    int4 v0 = make_int4(-1, -1, -1, -1), v1 = make_int4(-1, -1, -1, -1);
+    int32_t orow = -1;
+    if (tile_ok) {
+      const int4* src = reinterpret_cast<const int4*>(p.snbr + (int64_t)g * K * 16);
+      const int n16 = K * 4;
+      gm = p.gmask[g];
+      if (lane < n16) v0 = src[lane];
+      if (lane + 64 < n16) v1 = src[lane + 64];
+      if (sub == 0) orow = p.perm[(int64_t)g * 16 + l15];
+    }
+    unsigned long long tr[5];
+    if constexpr (TRACE) tr[0] = __builtin_amdgcn_s_memtime();
+    gm = __builtin_amdgcn_readfirstlane(gm);
+    const bool active = (gm >> 31) != 0;
+    if constexpr (KSP == 1) {
+      if (!active) continue;
+    }
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+    if (active) {
+      {
+        reinterpret_cast<int4*>(ldsw)[lane] = v0;
+        reinterpret_cast<int4*>(ldsw)[lane + 64] = v1;   // pieces >= K*4: absent
+        if (lane < 8) reinterpret_cast<int4*>(ldsw)[128 + lane] = make_int4(-1, -1, -1, -1);   // the all-absent row (512..)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      if constexpr (TRACE) tr[1] = __builtin_amdgcn_s_memtime();
+
+      uint32_t mk = gm & 0x07FFFFFFu;
+      const int n_items = __builtin_amdgcn_readfirstlane(__popc(mk) * NCBL);
+      int gen_k = 0, gen_cb = 0;
+      // the item whose loads are issued next: its two neighbour rows (written by the asm below), channel block, W offset
+      int32_t pend_i0 = -1, pend_i1 = -1;
+      int pend_acb = 0, pend_woff = 0;
+      // the item after that (generated: table address known, rows not read yet)
+      uint32_t nxt_tb = tb0 + 512 * 4;
+      int nxt_acb = 0, nxt_woff = 0;
+      auto generate = [&]() {                            // scalar selects only; fills nxt_*
+        const bool need = (gen_cb == 0);
+        const bool take = need && (mk != 0);
+        const bool valid = !need || take;                // items past the end gather the all-absent row and W item 0: never used
+        gen_k = take ? __builtin_ctz(mk | 0x80000000u) : gen_k;
+        mk = take ? (mk & (mk - 1)) : mk;
+        const int cb = sub * NCBL + gen_cb;
+        nxt_tb = tb0 + (uint32_t)((valid ? gen_k * 16 : 512) * 4);
+        nxt_acb = cb * 128;
+        nxt_woff = valid ? (int)((uint32_t)(((gen_k * NCB + cb) * NS + ns)) * ITEM_BYTES) : 0;
+        gen_cb = (valid && gen_cb + 1 < NCBL) ? gen_cb + 1 : 0;
+      };
+
+      f32x4 wring[D][4];
+      auto issue = [&](auto RS) {                        // loads of the pending item; then nxt -> pend (rows arrive by asm)
+        constexpr int rs = decltype(RS)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          wring[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane + i * 1024, pend_woff, 0));
+        __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(ring + rs * SLOT), 16, pend_i0, dma_chunk, pend_acb, 0, 0);
+        __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(ring + rs * SLOT + 1024), 16, pend_i1, dma_chunk, pend_acb, 0, 0);
+      };
+      // one asm per item: wait for the item's DMA pieces, read its operand fragments and the NEXT-to-issue item's rows
+      auto fetch = [&](auto RS, auto VM, f32x4& a0, f32x4& a1) {
+        constexpr int rs = decltype(RS)::value;
+        constexpr int vm = decltype(VM)::value;
+        const uint32_t r0 = rd0, r1 = rd1, tb = nxt_tb;  // (asm operands cannot name captures directly)
+        int32_t i0, i1;
+        asm volatile(
+            "s_waitcnt vmcnt(%6)\n\t"
+            "ds_read_b128 %0, %4 offset:%7\n\t"
+            "ds_read_b128 %1, %5 offset:%7\n\t"
+            "ds_read_b32 %2, %8\n\t"
+            "ds_read_b32 %3, %8 offset:32\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(a0), "=&v"(a1), "=&v"(i0), "=&v"(i1)
+            : "v"(r0), "v"(r1), "n"(vm), "n"(rs * SLOT), "v"(tb)
+            : "memory");
+        pend_i0 = i0; pend_i1 = i1;
+        pend_acb = nxt_acb; pend_woff = nxt_woff;
+      };
+      auto rows_only = [&]() {
+        const uint32_t tb = nxt_tb;
+        int32_t i0, i1;
+        asm volatile(
+            "ds_read_b32 %0, %2\n\t"
+            "ds_read_b32 %1, %2 offset:32\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(i0), "=&v"(i1)
+            : "v"(tb)
+            : "memory");
+        pend_i0 = i0; pend_i1 = i1;
+        pend_acb = nxt_acb; pend_woff = nxt_woff;
+      };
+      auto mfmas = [&](auto RS, const f32x4& a0, const f32x4& a1) {
+        constexpr int rs = decltype(RS)::value;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wring[rs][nt * 2 + tt][u], (tt ? a1 : a0)[u], acc[nt], 0, 0, 0);
+      };
+
+      // ---- prologue: D-1 items in flight
+      generate();
+      rows_only();
+      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        ((issue(std::integral_constant<int, Is>{}), generate(), rows_only(), __builtin_amdgcn_sched_barrier(0)), ...);
+      }(std::make_integer_sequence<int, D - 1>{});
+      if constexpr (TRACE) tr[2] = __builtin_amdgcn_s_memtime();
+      // ---- main loop
+      const int n_main = n_items / D;
+      for (int it = 0; it < n_main; ++it) {
+        [&]<int... Is>(std::integer_sequence<int, Is...>) {
+          (([&] {
+             f32x4 a0, a1;
+             issue(std::integral_constant<int, (Is + D - 1) % D>{});
+             generate();
+             __builtin_amdgcn_sched_barrier(0);
+             fetch(std::integral_constant<int, Is>{}, std::integral_constant<int, VM_PER_ITEM*(D - 1)>{}, a0, a1);
+             mfmas(std::integral_constant<int, Is>{}, a0, a1);
+             __builtin_amdgcn_sched_barrier(0);
+           }()), ...);
+        }(std::make_integer_sequence<int, D>{});
+      }
+      // ---- remainder (< D items, in flight in slots 0..rem-1; nothing more is issued: wait for everything once)
+      const int rem = n_items - n_main * D;
+      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        (([&] {
+           if (Is < rem) {
+             f32x4 a0, a1;
+             fetch(std::integral_constant<int, Is>{}, std::integral_constant<int, 0>{}, a0, a1);
+             mfmas(std::integral_constant<int, Is>{}, a0, a1);
+           }
+         }()), ...);
+      }(std::make_integer_sequence<int, D - 1>{});
+      if constexpr (TRACE) tr[3] = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // items past the end are still landing in the ring
+      __builtin_amdgcn_wave_barrier();
+      if constexpr (KSP == 1) {
+        if (active) epilogue(acc, g, ns, orow);
+      }
+      if constexpr (TRACE) {
+        tr[4] = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && p.trace) {
+          unsigned long long* o = p.trace + ((int64_t)tile * KSP + sub) * 8;
+          uint32_t hwid;
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+          o[0] = tr[0]; o[1] = tr[1]; o[2] = tr[2]; o[3] = tr[3]; o[4] = tr[4];
+          o[5] = (unsigned long long)n_items; o[6] = hwid; o[7] = blockIdx.x;
+        }
+      }
+    }
+
+    if constexpr (KSP > 1) {                             // fixed-order sum of the channel-split partials (ring is drained)
+      f32x4* r = reinterpret_cast<f32x4*>(ring) + lane;
       r[0] = acc[0];
       r[64] = acc[1];
       __syncthreads();
       if (sub == 0) {
 #pragma unroll
         for (int q = 1; q < KSP; ++q) {
-          const f32x4* o = red + ((par * 4 + wave + q) * 2) * 64 + lane;
+          const f32x4* o = reinterpret_cast<const f32x4*>(ring + q * WAVE_LDS) + lane;
           acc[0] += o[0];
           acc[1] += o[64];
         }
       }
-      par ^= 1;
-      if (active && sub == 0) epilogue(acc, g, ns, orow, bsc, bsh);
+      __syncthreads();                                   // the partner waves' next task writes into these slots
+      if (active && sub == 0) epilogue(acc, g, ns, orow);
     }
   }
+}
+
+template <int CIN, int COUT, int KSP, int D, bool TRACE = false>
+static int launch_dma_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
+  constexpr int NS = COUT / 32;
+  const size_t lds = 4 * ((2 * 256 + 32) * 4 + D * 2048);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_dma_kernel<CIN, COUT, D, KSP, TRACE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  const int64_t ntask = cdiv(groups_hint * NS * KSP, 4);
+  int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 16384);
+  grid = (grid + 7) / 8 * 8;
+  hipEvent_t* pev = prof_kernel_events();
+  if (pev[0]) {
+    hipExtLaunchKernelGGL((sconv_dma_kernel<CIN, COUT, D, KSP, TRACE>), dim3((unsigned)grid), dim3(256), lds, stream, pev[0], pev[1], 0, a);
+    pev[0] = pev[1] = nullptr;
+  } else {
+    hipLaunchKernelGGL((sconv_dma_kernel<CIN, COUT, D, KSP, TRACE>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+  }
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
 }
 
 // ------------------------------------------------------------------ workgroup-cooperative variant
@@ -399,7 +758,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_wg_kernel(const SconvArgs p) {
     {
       const int4* src = reinterpret_cast<const int4*>(p.snbr + (int64_t)g * K * 16);
       const int n16 = (own >> 31) ? K * 4 : 0;           // 16-byte pieces; an empty group reads nothing
-      int4 v0 = make_int4(0, 0, 0, 0), v1 = make_int4(0, 0, 0, 0);
+      int4 v0 = make_int4(-1, -1, -1, -1), v1 = make_int4(-1, -1, -1, -1);
       if (lane < n16) v0 = src[lane];
       if (lane + 64 < n16) v1 = src[lane + 64];
       reinterpret_cast<int4*>(ldsw)[lane] = v0;
@@ -447,7 +806,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_wg_kernel(const SconvArgs p) {
         else
           wreg[i] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, wv + i * (NW * 64 * SVEC), ws, 0));
       }
-      const uint32_t aoff = (uint32_t)(pend_idx - 1) * (uint32_t)(CIN * ES) + pend_acb + (uint32_t)(g4 * 16);
+      const uint32_t aoff = (uint32_t)pend_idx * (uint32_t)(CIN * ES) + pend_acb + (uint32_t)(g4 * 16);
 #pragma unroll
       for (int i = 0; i < ALD; ++i)
         aring[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(aoff + 64 * i), 0, 0));
@@ -586,27 +945,36 @@ static int launch_wg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
 }
 
 // ------------------------------------------------------------------ launcher
-template <int CIN, int COUT, bool BF16, int KSP, int D>
+template <int CIN, int COUT, bool BF16, int KSP, int D, int G>
 static int launch_rg_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
   constexpr int NS = COUT / 32;
-  const size_t lds = 4 * 28 * 16 * sizeof(int32_t) + (KSP > 1 ? 2 * 4 * 2 * 64 * sizeof(f32x4) : 0);
-  const int64_t ntask = cdiv(groups_hint * NS * KSP, 4);
+  constexpr int NPIECE = (G * 27 * 4 + 63) / 64;
+  const size_t lds = 4 * (NPIECE * 256 + 16) * sizeof(int32_t) + (KSP > 1 ? 2 * 4 * 2 * G * 64 * sizeof(f32x4) : 0);
+  static bool attr_done = false;                         // per instantiation; idempotent
+  if (!attr_done && lds > 48 * 1024) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  const int64_t ntask = cdiv(cdiv(groups_hint, G) * NS * KSP, 4);
   // one workgroup per task up to a cap: the hardware dispatcher then balances the uneven tasks (a grid of only the
   // resident workgroups was 30 % slower: each loops over ~3 tasks and the slowest decides)
   int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 16384);
   grid = (grid + 7) / 8 * 8;
   hipEvent_t* pev = prof_kernel_events();
   if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
-    hipExtLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP>), dim3((unsigned)grid), dim3(256), lds, stream, pev[0], pev[1], 0, a);
+    hipExtLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G>), dim3((unsigned)grid), dim3(256), lds, stream, pev[0], pev[1], 0, a);
     pev[0] = pev[1] = nullptr;
   } else {
-    hipLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G>), dim3((unsigned)grid), dim3(256), lds, stream, a);
   }
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
+// sel (tests / A-B measurements; every choice gives bitwise-identical results): 0 = product choice, 1 = register-ring
+// kernel, 2 = register-ring kernel with two groups per wave, 3 = LDS-DMA kernel (fp32 maps), 4 = LDS-DMA kernel with a 4-deep ring, 9 = traced build
 template <int CIN, int COUT, bool BF16>
-static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
+static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream, int sel) {
   constexpr int NS = COUT / 32, NCB = CIN / 32;
   // the input-channel blocks are always split over the waves of a workgroup (a function of the shape only, so results
   // never depend on launch sizes): measured faster at every level, 12 % on the 84 k-row 64->64 layer, 40 % on level 4.
@@ -614,9 +982,22 @@ static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
   constexpr int KSP = NCB >= 4 ? 4 : NCB;
   // prefetch depth (does not touch the arithmetic): few waves per SIMD => nothing else hides the gather latency, keep
   // 5 items in flight; a full chip prefers the smaller register footprint
-  if (groups_hint * NS * KSP < 6144) return launch_rg_d<CIN, COUT, BF16, KSP, 6>(a, groups_hint, stream);
-  return launch_rg_d<CIN, COUT, BF16, KSP, BF16 ? 4 : 3>(a, groups_hint, stream);
+  const bool small = groups_hint * NS * KSP < 6144;
+  if constexpr (!BF16) {
+    {
+      if (sel == 3 || (sel == 0 && !small)) return launch_dma_d<CIN, COUT, KSP, 3>(a, groups_hint, stream);
+      if (sel == 4) return launch_dma_d<CIN, COUT, KSP, 4>(a, groups_hint, stream);
+      if constexpr ((CIN == 32 && COUT == 32) || (CIN == 64 && COUT == 64)) {
+        if (sel == 9) return launch_dma_d<CIN, COUT, KSP, 3, true>(a, groups_hint, stream);
+      }
+    }
+  }
+  if (sel == 2 && !small) return launch_rg_d<CIN, COUT, BF16, KSP, BF16 ? 4 : 3, 2>(a, groups_hint, stream);
+  if (small) return launch_rg_d<CIN, COUT, BF16, KSP, 6, 1>(a, groups_hint, stream);
+  return launch_rg_d<CIN, COUT, BF16, KSP, BF16 ? 4 : 3, 1>(a, groups_hint, stream);
 }
+
+unsigned long long* g_sconv_trace = nullptr;              // measurement hook (egonn_debug_set_trace)
 
 bool sconv_rg_supported(int cin, int cout) {
   auto ok = [](int c) { return c == 32 || c == 64 || c == 128 || c == 256; };
@@ -640,15 +1021,17 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
   a.in_bytes = (uint32_t)ib;
   a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * (bf16 ? 2 : 4));
   a.K = rg.K; a.relu = relu ? 1 : 0;
+  a.trace = variant == 9 ? g_sconv_trace : nullptr;
 
   // Measured (profiles/r02b_sconv.json, batch 16): in fp32 the per-wave kernel wins everywhere (the lock-step of the
   // cooperative kernel costs more than its saved W traffic when an item is 16-64 MFMAs of 32 cycles); with bf16 maps the
   // items are load-bound and the cooperative kernel wins on the big layers with >= 64 input or output channels.
+  const int gsel = variant == 1 ? 1 : (variant == 4 ? 2 : (variant == 5 ? 3 : (variant == 6 ? 4 : (variant == 9 ? 9 : 0))));
   const bool coop = variant == 2 || (variant == 0 && bf16 && groups_hint >= 2048 && cin * cout >= 32 * 64);
 #define EGONN_RG_CASE(CI, CO)                                                                      \
   if (cin == CI && cout == CO) {                                                                   \
     if (coop) return bf16 ? launch_wg<CI, CO, true>(a, groups_hint, stream) : launch_wg<CI, CO, false>(a, groups_hint, stream); \
-    return bf16 ? launch_rg<CI, CO, true>(a, groups_hint, stream) : launch_rg<CI, CO, false>(a, groups_hint, stream);           \
+    return bf16 ? launch_rg<CI, CO, true>(a, groups_hint, stream, gsel) : launch_rg<CI, CO, false>(a, groups_hint, stream, gsel); \
   }
   EGONN_RG_CASE(32, 32)
   EGONN_RG_CASE(32, 64)

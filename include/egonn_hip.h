@@ -46,6 +46,11 @@ const char* egonn_last_error(void);
  * HIP kernel (cross-check of the MFMA kernels), on = 2 / 4 force the per-wave / the workgroup-cooperative MFMA kernel (A/B
  * timing); 0 = product choice.  Never set by the product path. */
 int egonn_debug_set_naive_conv(egonn_ctx* ctx, int on);
+/* measurement hook: buffer for the traced sparse-conv build (debug variant 128): 8 u64 per wave task; NULL = off */
+int egonn_debug_set_trace(void* device_buffer);
+/* measurement hook: device copies of a map's row-group tables (gmask [groups], snbr [groups][K][16], nullable).  [SYNC] */
+int egonn_debug_rowgroup_tables(egonn_ctx* ctx, int map_kind, int level_out, uint32_t* gmask_out, int32_t* snbr_out,
+                                int64_t capacity_groups, int64_t* n_groups, void* stream);
 
 /* ------------------------------------------------------------------ coordinate plan
  * replaces ME.utils.sparse_quantize      datasets/quantization.py:42,83   (Cartesian/Polar quantizer __call__)
