@@ -123,12 +123,12 @@ struct SconvArgs {
 // (6 loads x 16 cycles x 4 waves per 512 MFMA cycles); G = 2 makes it 8 loads per 1024 MFMA cycles.  A group that lacks
 // the offset skips the item's MFMAs (wave-uniform branch; its gather rows are "-1" and cost no memory traffic).  The sum
 // order of every output row is unchanged (ascending k, ascending channel) => results are bitwise identical for every G.
-template <int CIN, int COUT, bool BF16, int D, int KSP, int G>
-__global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
+template <int CIN, int COUT, bool BF16, int D, int KSP, int G, int NW>
+__global__ __launch_bounds__(NW * 64) void sconv_rg_kernel(const SconvArgs p) {
   constexpr int NS = COUT / 32, NCB = CIN / 32;
   constexpr int NCBL = NCB / KSP;                        // channel blocks per wave
-  constexpr int TPW = 4 / KSP;                           // tiles per workgroup
-  static_assert(NCB % KSP == 0 && 4 % KSP == 0, "bad channel split");
+  constexpr int TPW = NW / KSP;                          // tiles per workgroup
+  static_assert(NCB % KSP == 0 && NW % KSP == 0, "bad channel split");
   constexpr int ES = BF16 ? 2 : 4;                       // bytes per feature element
   constexpr int ALD = BF16 ? 1 : 2;                      // b128 loads of A per lane per item and group
   constexpr int WLD = BF16 ? 2 : 4;                      // b128 loads of W per lane per item
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
   const int l15 = lane & 15, g4 = lane >> 4;
   const int K = p.K;
   int32_t* const ldsw = lds + wave * LDSW;
-  f32x4* const red = reinterpret_cast<f32x4*>(lds + 4 * LDSW);         // [2 parities][4 waves][G][2 tiles][64 lanes] (KSP > 1)
+  f32x4* const red = reinterpret_cast<f32x4*>(lds + NW * LDSW);        // [2 parities][NW waves][G][2 tiles][64 lanes] (KSP > 1)
 
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wp), 0, (int)p.w_bytes, 0x00020000);
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
     }
 
     if constexpr (KSP > 1) {                             // fixed-order sum of the channel-split partials
-      f32x4* r = red + ((par * 4 + wave) * 2 * G) * 64 + lane;
+      f32x4* r = red + ((par * NW + wave) * 2 * G) * 64 + lane;
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         r[(2 * j) * 64] = acc[j][0];
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void sconv_rg_kernel(const SconvArgs p) {
       if (sub == 0) {
 #pragma unroll
         for (int q = 1; q < KSP; ++q) {
-          const f32x4* o = red + ((par * 4 + wave + q) * 2 * G) * 64 + lane;
+          const f32x4* o = red + ((par * NW + wave + q) * 2 * G) * 64 + lane;
 #pragma unroll
           for (int j = 0; j < G; ++j) {
             acc[j][0] += o[(2 * j) * 64];
@@ -414,12 +414,12 @@ __device__ static inline float row16_sum(float v) {      // sum over the 16 lane
   return v;
 }
 
-template <int CIN, int COUT, int D, int KSP, bool TRACE = false>
-__global__ __launch_bounds__(256) void sconv_dma_kernel(const SconvArgs p) {
+template <int CIN, int COUT, int D, int KSP, int NW, bool TRACE = false>
+__global__ __launch_bounds__(NW * 64) void sconv_dma_kernel(const SconvArgs p) {
   constexpr int NS = COUT / 32, NCB = CIN / 32;
   constexpr int NCBL = NCB / KSP;
-  constexpr int TPW = 4 / KSP;
-  static_assert(NCB % KSP == 0 && 4 % KSP == 0, "bad channel split");
+  constexpr int TPW = NW / KSP;                          // tiles per workgroup
+  static_assert(NCB % KSP == 0 && NW % KSP == 0, "bad channel split");
   constexpr uint32_t ITEM_BYTES = 32 * 32 * 4;
   constexpr int TBL = 2 * 256 + 32;                      // ints: 27 x 16 neighbour rows (padded to 512) + an all-absent row; 128-byte multiple
   constexpr int SLOT = 2048;                             // one gathered item: 16 rows x 128 B
@@ -673,28 +673,40 @@ __global__ __launch_bounds__(256) void sconv_dma_kernel(const SconvArgs p) {
   }
 }
 
+// NW waves per workgroup.  A workgroup keeps ALL its wave slots until its slowest wave has retired (and a retired wave keeps
+// its slot until its last stores are acknowledged): with independent tiles of 2-27 items in one 4-wave workgroup a CU held
+// 9 live waves of 16 (tools/sconv_trace.py).  The waves of a workgroup only have to be together when they split the input
+// channels of one tile (KSP > 1), so a workgroup is exactly those KSP waves; the dispatcher starts > 3000 workgroups/us
+// (tools/exp/dispatch_rate.hip), far more than these launches need.
 template <int CIN, int COUT, int KSP, int D, bool TRACE = false>
-static int launch_dma_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
+static int launch_dma_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stream, int nw_sel = 0) {
   constexpr int NS = COUT / 32;
-  const size_t lds = 4 * ((2 * 256 + 32) * 4 + D * 2048);
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_dma_kernel<CIN, COUT, D, KSP, TRACE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+  auto go = [&](auto NWC) -> int {
+    constexpr int NW = decltype(NWC)::value;
+    const size_t lds = NW * ((2 * 256 + 32) * 4 + D * 2048);
+    static bool attr_done = false;                       // per instantiation (the lambda is instantiated per NW)
+    if (!attr_done) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_dma_kernel<CIN, COUT, D, KSP, NW, TRACE>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done = true;
+    }
+    const int64_t ntask = cdiv(groups_hint * NS * KSP, NW);
+    int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 65536);
+    grid = (grid + 7) / 8 * 8;
+    hipEvent_t* pev = prof_kernel_events();
+    if (pev[0]) {
+      hipExtLaunchKernelGGL((sconv_dma_kernel<CIN, COUT, D, KSP, NW, TRACE>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, pev[0], pev[1], 0, a);
+      pev[0] = pev[1] = nullptr;
+    } else {
+      hipLaunchKernelGGL((sconv_dma_kernel<CIN, COUT, D, KSP, NW, TRACE>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
+    }
+    HIP_CHECK(hipGetLastError());
+    return EGONN_OK;
+  };
+  if constexpr (KSP < 4) {
+    if (nw_sel == 4) return go(std::integral_constant<int, 4>{});
   }
-  const int64_t ntask = cdiv(groups_hint * NS * KSP, 4);
-  int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 16384);
-  grid = (grid + 7) / 8 * 8;
-  hipEvent_t* pev = prof_kernel_events();
-  if (pev[0]) {
-    hipExtLaunchKernelGGL((sconv_dma_kernel<CIN, COUT, D, KSP, TRACE>), dim3((unsigned)grid), dim3(256), lds, stream, pev[0], pev[1], 0, a);
-    pev[0] = pev[1] = nullptr;
-  } else {
-    hipLaunchKernelGGL((sconv_dma_kernel<CIN, COUT, D, KSP, TRACE>), dim3((unsigned)grid), dim3(256), lds, stream, a);
-  }
-  HIP_CHECK(hipGetLastError());
-  return EGONN_OK;
+  return go(std::integral_constant<int, KSP>{});
 }
 
 // ------------------------------------------------------------------ workgroup-cooperative variant
@@ -948,31 +960,32 @@ static int launch_wg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
 template <int CIN, int COUT, bool BF16, int KSP, int D, int G>
 static int launch_rg_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
   constexpr int NS = COUT / 32;
+  constexpr int NW = KSP;                                // a workgroup = the waves that share a tile (see launch_dma_d)
   constexpr int NPIECE = (G * 27 * 4 + 63) / 64;
-  const size_t lds = 4 * (NPIECE * 256 + 16) * sizeof(int32_t) + (KSP > 1 ? 2 * 4 * 2 * G * 64 * sizeof(f32x4) : 0);
+  const size_t lds = NW * (NPIECE * 256 + 16) * sizeof(int32_t) + (KSP > 1 ? 2 * NW * 2 * G * 64 * sizeof(f32x4) : 0);
   static bool attr_done = false;                         // per instantiation; idempotent
   if (!attr_done && lds > 48 * 1024) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G>),
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  const int64_t ntask = cdiv(cdiv(groups_hint, G) * NS * KSP, 4);
+  const int64_t ntask = cdiv(cdiv(groups_hint, G) * NS * KSP, NW);
   // one workgroup per task up to a cap: the hardware dispatcher then balances the uneven tasks (a grid of only the
   // resident workgroups was 30 % slower: each loops over ~3 tasks and the slowest decides)
-  int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 16384);
+  int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 65536);
   grid = (grid + 7) / 8 * 8;
   hipEvent_t* pev = prof_kernel_events();
   if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
-    hipExtLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G>), dim3((unsigned)grid), dim3(256), lds, stream, pev[0], pev[1], 0, a);
+    hipExtLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, pev[0], pev[1], 0, a);
     pev[0] = pev[1] = nullptr;
   } else {
-    hipLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
   }
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
 // sel (tests / A-B measurements; every choice gives bitwise-identical results): 0 = product choice, 1 = register-ring
-// kernel, 2 = register-ring kernel with two groups per wave, 3 = LDS-DMA kernel (fp32 maps), 4 = LDS-DMA kernel with a 4-deep ring, 9 = traced build
+// kernel, 2 = register-ring kernel with two groups per wave, 3 = LDS-DMA kernel (fp32 maps), 4 = LDS-DMA kernel with 4-wave workgroups, 9 = traced build
 template <int CIN, int COUT, bool BF16>
 static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream, int sel) {
   constexpr int NS = COUT / 32, NCB = CIN / 32;
@@ -982,11 +995,11 @@ static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
   constexpr int KSP = NCB >= 4 ? 4 : NCB;
   // prefetch depth (does not touch the arithmetic): few waves per SIMD => nothing else hides the gather latency, keep
   // 5 items in flight; a full chip prefers the smaller register footprint
-  const bool small = groups_hint * NS * KSP < 6144;
+  const bool small = groups_hint * NS * KSP < 6144;     // fewer waves than 6 per SIMD
   if constexpr (!BF16) {
     {
       if (sel == 3 || (sel == 0 && !small)) return launch_dma_d<CIN, COUT, KSP, 3>(a, groups_hint, stream);
-      if (sel == 4) return launch_dma_d<CIN, COUT, KSP, 4>(a, groups_hint, stream);
+      if (sel == 4) return launch_dma_d<CIN, COUT, KSP, 3>(a, groups_hint, stream, 4);
       if constexpr ((CIN == 32 && COUT == 32) || (CIN == 64 && COUT == 64)) {
         if (sel == 9) return launch_dma_d<CIN, COUT, KSP, 3, true>(a, groups_hint, stream);
       }
