@@ -160,12 +160,17 @@ def test_sparse_conv_precisions_and_group_sums(gpu):
         err = (got16.float() - want16).abs().max() / want16.abs().max()
         assert err < 6e-3, (kind, lvl, ci, co, float(err))        # one bf16 rounding of the output (2^-8 relative)
         # both MFMA kernels (per-wave / workgroup-cooperative) agree to summation order in fp32, to one bf16 ulp in bf16
-        for var in (2, 4):
+        per_wave = None
+        for var in (2, 4, 16, 32):
             ctx.lib.egonn_debug_set_naive_conv(ctx.h, var)
-            v32 = ctx.sparse_conv(kind, lvl, x, w, sc, sh, relu=True)
+            v32, s32 = ctx.sparse_conv(kind, lvl, x, w, sc, sh, relu=True, group_sums=True)
             v16 = ctx.sparse_conv(kind, lvl, xb.contiguous(), w, sc, sh, relu=True)
             assert ((v32 - got).abs().max() / scale) < 2e-5, (var, kind, lvl)
             assert ((v16.float() - got16.float()).abs().max() / scale) < 8e-3, (var, kind, lvl)
+            if var == 2:
+                per_wave = (v32, s32)
+            if var in (16, 32):     # the LDS-DMA kernel (KSP-wave / 4-wave workgroups) runs the register-ring kernel's arithmetic
+                assert torch.equal(v32, per_wave[0]) and torch.equal(s32, per_wave[1]), (var, kind, lvl)
         ctx.lib.egonn_debug_set_naive_conv(ctx.h, 0)
 
 
