@@ -574,30 +574,57 @@ struct LocalHeadsArgs {
   int level, cb, mode, ignore_offsets;
   float s0, s1, s2;
 };
+// The six weight matrices (92 KB as MFMA fragments) are staged ONCE per workgroup into LDS in fragment order
+//   frag[(nt * CIN/16 + t) * 64 + lane] = W[16 nt + (lane & 15)][16 t + 4 (lane >> 4) .. +3]      (rows >= rows_w: zeros)
+// so that a wave's B operands are lane-linear ds_read_b128 (conflict-free) instead of 92 KB of dependent global loads per
+// 16-row tile — the first version spent 60 us on 1.4 GFLOP because every wave re-fetched every weight through L1.
+template <int CIN, int NT>
+__device__ static inline void stage_frags(const float* __restrict__ W, int rows_w, f32x4* __restrict__ dst, int tid, int nthreads) {
+  constexpr int T = CIN / 16;
+  for (int i = tid; i < NT * T * 64; i += nthreads) {
+    const int lane = i & 63, ft = i >> 6;
+    const int nt = ft / T, t = ft - nt * T;
+    const int unit = 16 * nt + (lane & 15);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (unit < rows_w) v = *reinterpret_cast<const f32x4*>(W + (int64_t)unit * CIN + 16 * t + 4 * (lane >> 4));
+    dst[i] = v;
+  }
+}
 template <int CIN, int NT>   // out[nt] = sum_k W[16nt + l15][k] * in[k]  for the 16 rows of the wave (swapped operands)
-__device__ static inline void mlp_layer(const float* __restrict__ W, int rows_w, const f32x4* __restrict__ in, int l15, int g4,
+__device__ static inline void mlp_layer(const f32x4* __restrict__ frags, const f32x4* __restrict__ in, int lane,
                                         f32x4* __restrict__ out) {
+  constexpr int T = CIN / 16;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int unit = 16 * nt + l15;
 #pragma unroll
-    for (int t = 0; t < CIN / 16; ++t) {
-      f32x4 wf = {0.f, 0.f, 0.f, 0.f};
-      if (unit < rows_w) wf = *reinterpret_cast<const f32x4*>(W + (int64_t)unit * CIN + 16 * t + 4 * g4);
+    for (int t = 0; t < T; ++t) {
+      const f32x4 wf = frags[(nt * T + t) * 64 + lane];
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], in[t][u], acc, 0, 0, 0);
     }
     out[nt] = acc;
+    __builtin_amdgcn_sched_barrier(0);                   // keep the fragment reads of later tiles from being hoisted (spills)
   }
 }
-__global__ __launch_bounds__(256) void local_heads_kernel(const LocalHeadsArgs p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+constexpr int LH_WAVES = 8;
+constexpr int LH_F_DW0 = 0, LH_F_DW1 = LH_F_DW0 + 6 * 4, LH_F_KW0 = LH_F_DW1 + 8 * 6, LH_F_KW1 = LH_F_KW0 + 2 * 4,
+              LH_F_SW0 = LH_F_KW1 + 1 * 2, LH_F_SW1 = LH_F_SW0 + 2 * 4, LH_FRAGS = LH_F_SW1 + 1 * 2;      // 92 fragments of 1 KB
+__global__ __launch_bounds__(LH_WAVES * 64) void local_heads_kernel(const LocalHeadsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 lh_frags[];      // [LH_FRAGS][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g4 = lane >> 4;
+  stage_frags<64, 6>(p.dw0, 96, lh_frags + LH_F_DW0 * 64, tid, LH_WAVES * 64);
+  stage_frags<96, 8>(p.dw1, 128, lh_frags + LH_F_DW1 * 64, tid, LH_WAVES * 64);
+  stage_frags<64, 2>(p.kw0, 32, lh_frags + LH_F_KW0 * 64, tid, LH_WAVES * 64);
+  stage_frags<32, 1>(p.kw1, 3, lh_frags + LH_F_KW1 * 64, tid, LH_WAVES * 64);
+  stage_frags<64, 2>(p.sw0, 32, lh_frags + LH_F_SW0 * 64, tid, LH_WAVES * 64);
+  stage_frags<32, 1>(p.sw1, 1, lh_frags + LH_F_SW1 * 64, tid, LH_WAVES * 64);
+  __syncthreads();
   int64_t n = p.n;
   if (p.n_dev) n = min((int64_t)*p.n_dev, n);
   const int64_t ntiles = (n + 15) >> 4;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  for (int64_t tile = (int64_t)blockIdx.x * LH_WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * LH_WAVES) {
     const int64_t row = tile * 16 + l15;
     const bool ok = row < n;
     f32x4 x[4];
@@ -607,14 +634,14 @@ __global__ __launch_bounds__(256) void local_heads_kernel(const LocalHeadsArgs p
     // ---- descriptor decoder + L2 normalisation
     {
       f32x4 h[6], o[8];
-      mlp_layer<64, 6>(p.dw0, 96, x, l15, g4, h);
+      mlp_layer<64, 6>(lh_frags + LH_F_DW0 * 64, x, lane, h);
 #pragma unroll
       for (int nt = 0; nt < 6; ++nt) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.db0 + 16 * nt + 4 * g4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[nt][r] = fmaxf(h[nt][r] + b[r], 0.f);
       }
-      mlp_layer<96, 8>(p.dw1, 128, h, l15, g4, o);
+      mlp_layer<96, 8>(lh_frags + LH_F_DW1 * 64, h, lane, o);
       float ss = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
@@ -637,14 +664,14 @@ __global__ __launch_bounds__(256) void local_heads_kernel(const LocalHeadsArgs p
     // ---- keypoint regressor -> position of the keypoint in metres
     {
       f32x4 h[2], o[1];
-      mlp_layer<64, 2>(p.kw0, 32, x, l15, g4, h);
+      mlp_layer<64, 2>(lh_frags + LH_F_KW0 * 64, x, lane, h);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.kb0 + 16 * nt + 4 * g4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[nt][r] = fmaxf(h[nt][r] + b[r], 0.f);
       }
-      mlp_layer<32, 1>(p.kw1, 3, h, l15, g4, o);
+      mlp_layer<32, 1>(lh_frags + LH_F_KW1 * 64, h, lane, o);
       if (ok && g4 == 0) {                                   // lane (row, g = 0) holds output units 0..3
         const float ox = p.ignore_offsets ? 0.f : tanhf(o[0][0] + p.kb1[0]);
         const float oy = p.ignore_offsets ? 0.f : tanhf(o[0][1] + p.kb1[1]);
@@ -655,14 +682,14 @@ __global__ __launch_bounds__(256) void local_heads_kernel(const LocalHeadsArgs p
     // ---- sigma regressor
     {
       f32x4 h[2], o[1];
-      mlp_layer<64, 2>(p.sw0, 32, x, l15, g4, h);
+      mlp_layer<64, 2>(lh_frags + LH_F_SW0 * 64, x, lane, h);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.sb0 + 16 * nt + 4 * g4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[nt][r] = fmaxf(h[nt][r] + b[r], 0.f);
       }
-      mlp_layer<32, 1>(p.sw1, 1, h, l15, g4, o);
+      mlp_layer<32, 1>(lh_frags + LH_F_SW1 * 64, h, lane, o);
       if (ok && g4 == 0) p.out_sigma[row] = apply_act(o[0][0] + p.sb1[0], ACT_SOFTPLUS);
     }
   }
@@ -680,8 +707,14 @@ int local_heads_forward(const float* x, int64_t n, const int32_t* n_dev, const f
   a.s0 = step[0]; a.s1 = mode ? step[1] : step[0]; a.s2 = mode ? step[2] : step[0];
   a.out_desc = out_desc; a.out_kp = out_kp; a.out_sigma = out_sigma;
   const int64_t tiles = cdiv(n, 16);
-  const unsigned grid = (unsigned)std::min<int64_t>(cdiv(tiles, 4), 2048);
-  hipLaunchKernelGGL(local_heads_kernel, dim3(grid), dim3(256), 0, stream, a);
+  const size_t lds = (size_t)LH_FRAGS * 64 * sizeof(f32x4);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&local_heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  const unsigned grid = (unsigned)std::min<int64_t>(cdiv(tiles, LH_WAVES), 256);      // one workgroup per CU holds the weights
+  hipLaunchKernelGGL(local_heads_kernel, dim3(grid), dim3(LH_WAVES * 64), lds, stream, a);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }

@@ -61,3 +61,15 @@ starts = np.sort(t[:, 0] - t0)
 print("  task start times p10/p50/p90/max of span: %.2f %.2f %.2f %.2f" % tuple(np.percentile(starts, [10, 50, 90, 100]) / span))
 if len(sys.argv) > 1:
     np.save(sys.argv[1], t)
+
+# per-CU view (s_memtime is only comparable within a CU)
+xcd = t[:, 7] & 7
+key = (xcd << 20) | (((hw >> 8) & 0xf) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5))
+spans, occ, mf = [], [], []
+for k_ in np.unique(key):
+    tt = t[key == k_]
+    sp = tt[:, 4].max() - tt[:, 0].min()
+    spans.append(sp); occ.append((tt[:, 4] - tt[:, 0]).sum() / sp); mf.append((tt[:, 5] * 16 * 32).sum() / (4 * sp))
+print("  per CU: span cycles p10/50/90/max", np.percentile(spans, [10, 50, 90, 100]).astype(int).tolist(),
+      " live waves (avg over the span) p10/50/90 %.1f %.1f %.1f" % tuple(np.percentile(occ, [10, 50, 90])),
+      " MFMA issue share of the span p10/50/90 %.2f %.2f %.2f" % tuple(np.percentile(mf, [10, 50, 90])))
