@@ -74,18 +74,27 @@ __global__ __launch_bounds__(256) void conv0_k5_kernel(const float* __restrict__
                                                         const float* __restrict__ shift, int relu,
                                                         void* __restrict__ out_v,
                                                         const uint16_t* __restrict__ lut) {
-  __shared__ uint64_t s_m[4][16][27];
+  // 27 neighbour blocks per row + one all-zero mask (slot 27: where the LUT sends the 3 padding offsets, so the lookup has
+  // no compare/select); row stride 29 keeps the 16 rows of a tile on distinct banks
+  constexpr int MS = 29;
+  __shared__ uint64_t s_m[4][16][MS];
   __shared__ int32_t s_s[4][16][27];
   // (local voxel position inside its 4x4x4 block, kernel offset) -> (adjacent-block slot << 6 | bit inside that
-  // block's occupancy mask); 0xFFFF for the 3 padding offsets.  Built once per (persistent) workgroup.
-  __shared__ uint16_t s_lut[64 * 128];
+  // block's occupancy mask); the 3 padding offsets point at the zero mask.  Built once per (persistent) workgroup.
+  // rows padded to 132 entries: the 16 rows of a tile read the same column of 16 different LUT rows, which a 256-byte
+  // row stride put on one bank (16-way conflict on every lookup)
+  constexpr int LUT_STRIDE = 132;
+  __shared__ __attribute__((aligned(8))) uint16_t s_lut[64 * LUT_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g4 = lane >> 4;
   const int32_t nvox = min(__builtin_amdgcn_readfirstlane(counts[0]), cap0);
   const int32_t n2 = min(__builtin_amdgcn_readfirstlane(counts[2]), cap2);
   const int32_t ntiles = (nvox + 15) >> 4;
-  for (int e = tid; e < 64 * 128 / 2; e += 256)       // precomputed table (conv0_lut_host), 16 KB, coalesced
-    reinterpret_cast<uint32_t*>(s_lut)[e] = reinterpret_cast<const uint32_t*>(lut)[e];
+  for (int e = tid; e < 64 * 128 / 2; e += 256) {     // precomputed table (conv0_lut_host), 16 KB, coalesced
+    const int r = e >> 6, c = e & 63;
+    reinterpret_cast<uint32_t*>(s_lut)[r * (LUT_STRIDE / 2) + c] = reinterpret_cast<const uint32_t*>(lut)[e];
+  }
+  if (tid < 64) s_m[tid >> 4][tid & 15][27] = 0ull;
   float breg[2][32];
 #pragma unroll
   for (int q = 0; q < 32; ++q) {
@@ -93,11 +102,11 @@ __global__ __launch_bounds__(256) void conv0_k5_kernel(const float* __restrict__
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) breg[nt][q] = (k < 125) ? W[k * COUT0 + nt * 16 + l15] : 0.f;
   }
-  float sc[2], sh[2];
+  f32x4 sc[2], sh[2];                                    // lane (row, g) stores output channels nt*16 + 4g .. +3 of its row
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
-    sc[nt] = scale ? scale[nt * 16 + l15] : 1.f;
-    sh[nt] = scale ? shift[nt * 16 + l15] : 0.f;
+    sc[nt] = scale ? *reinterpret_cast<const f32x4*>(scale + nt * 16 + 4 * g4) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    sh[nt] = scale ? *reinterpret_cast<const f32x4*>(shift + nt * 16 + 4 * g4) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
   // Software pipeline over the wave's tiles: while tile t is computed, the 27-neighbourhood (mask, first row) of
@@ -150,7 +159,8 @@ __global__ __launch_bounds__(256) void conv0_k5_kernel(const float* __restrict__
     for (int e = 0; e < NE; ++e) {
       const int idx = lane + 64 * e;
       if (idx < 16 * 27) {
-        (&s_m[wave][0][0])[idx] = pm[e];
+        const int row = idx / 27, slot = idx - row * 27;
+        s_m[wave][row][slot] = pm[e];
         (&s_s[wave][0][0])[idx] = ps[e];
       }
     }
@@ -160,43 +170,53 @@ __global__ __launch_bounds__(256) void conv0_k5_kernel(const float* __restrict__
     table_issue(g_nxt);
     row_info(tile + 2 * tstep, g_nn, lk_nn);
     const uint32_t lk = lk_cur;
-    const uint16_t* lrow = s_lut + lk * 128 + 4 * g4;
+    const uint16_t* lrow = s_lut + lk * LUT_STRIDE + 4 * g4;
+    uint2 ent4[8];                                           // the lane's 32 entries: 8 x 4 consecutive ones (one 8-byte read each)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ent4[j] = *reinterpret_cast<const uint2*>(lrow + 16 * j);
     float a[32];
+    const char* mrow = reinterpret_cast<const char*>(&s_m[wave][l15][0]);
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
-      const uint32_t en = lrow[16 * (q >> 2) + (q & 3)];
-      float v = 0.f;
-      if (en != 0xFFFFu) {
-        const uint32_t slot = en >> 6, bit = en & 63;
-        const uint64_t m = s_m[wave][l15][slot];          // rows beyond nvox have all-zero masks
-        if ((m >> bit) & 1) {
-          if constexpr (UNIT) v = 1.f;
-          else v = feat[s_s[wave][l15][slot] + __popcll(m & ((1ull << bit) - 1))];
-        }
+      const uint32_t pair = (q & 2) ? ent4[q >> 2].y : ent4[q >> 2].x;
+      const uint32_t en = (q & 1) ? (pair >> 16) : (pair & 0xFFFFu);       // (byte offset of the block's mask << 6) | bit
+      const uint64_t m = *reinterpret_cast<const uint64_t*>(mrow + (en >> 6));      // rows beyond nvox have all-zero masks
+      const uint32_t hit = (uint32_t)(m >> (en & 63)) & 1u;
+      float v = (float)hit;
+      if constexpr (!UNIT) {
+        v = 0.f;
+        if (hit) v = feat[s_s[wave][l15][en >> 9] + __popcll(m & ((1ull << (en & 63)) - 1))];
       }
       a[q] = v;
     }
+    // operands swapped (D^T = W^T A^T): lane (row = l15, g) ends up with four consecutive output channels of its row
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], breg[0][q], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], breg[1][q], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[0][q], a[q], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[1][q], a[q], acc[1], 0, 0, 0);
     }
+    const int32_t orow = r0 + l15;
+    if (orow < nvox) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int32_t orow = r0 + 4 * g4 + rr;
-      if (orow < nvox) {
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 o = acc[nt] * sc[nt] + sh[nt];
+        if (relu) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          float o = acc[nt][rr] * sc[nt] + sh[nt];
-          if (relu) o = fmaxf(o, 0.f);
-          if constexpr (OUT_BF16) {
-            uint32_t u = __float_as_uint(o);
-            u += 0x7FFFu + ((u >> 16) & 1u);
-            reinterpret_cast<uint16_t*>(out_v)[(int64_t)orow * COUT0 + nt * 16 + l15] = (uint16_t)(u >> 16);
-          } else {
-            reinterpret_cast<float*>(out_v)[(int64_t)orow * COUT0 + nt * 16 + l15] = o;
+          for (int u = 0; u < 4; ++u) o[u] = fmaxf(o[u], 0.f);
+        }
+        if constexpr (OUT_BF16) {
+          uint32_t w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            uint32_t x = __float_as_uint(o[u]);
+            x += 0x7FFFu + ((x >> 16) & 1u);
+            w[u] = x >> 16;
           }
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_v) + (int64_t)orow * COUT0 + nt * 16 + 4 * g4) =
+              make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
+        } else {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out_v) + (int64_t)orow * COUT0 + nt * 16 + 4 * g4) = o;
         }
       }
     }
@@ -206,11 +226,11 @@ __global__ __launch_bounds__(256) void conv0_k5_kernel(const float* __restrict__
   }
 }
 
-// (local voxel position, kernel offset) -> (adjacent-block slot << 6 | bit in that block's mask), 0xFFFF = padding
+// (local voxel position, kernel offset) -> (8 * adjacent-block slot) << 6 | bit in that block's mask
 static void conv0_lut_host(uint16_t* lut) {
   for (int lk = 0; lk < 64; ++lk)
     for (int k = 0; k < 128; ++k) {
-      uint32_t v = 0xFFFFu;
+      uint32_t v = (uint32_t)(27 * 8) << 6;              // padding offsets: the all-zero mask, bit 0
       if (k < 125) {
         const int lx = (lk & 1) | ((lk >> 2) & 2), ly = ((lk >> 1) & 1) | ((lk >> 3) & 2), lz = ((lk >> 2) & 1) | ((lk >> 4) & 2);
         const int nx = lx + k % 5 - 2, ny = ly + (k / 5) % 5 - 2, nz = lz + k / 25 - 2;
@@ -218,7 +238,7 @@ static void conv0_lut_host(uint16_t* lut) {
                          9 * ((nz < 0) ? 0 : (nz > 3 ? 2 : 1));
         const uint32_t ux = (uint32_t)nx & 3, uy = (uint32_t)ny & 3, uz = (uint32_t)nz & 3;
         const uint32_t bit = (ux & 1) | ((uy & 1) << 1) | ((uz & 1) << 2) | ((ux & 2) << 2) | ((uy & 2) << 3) | ((uz & 2) << 4);
-        v = ((uint32_t)slot << 6) | bit;
+        v = ((uint32_t)(slot * 8) << 6) | bit;         // byte offset of the block's mask inside the row's LDS table
       }
       lut[lk * 128 + k] = (uint16_t)v;
     }

@@ -303,9 +303,9 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int k = g + 8 * q;
-        const uint32_t e = s_lut[lk * 128 + k];
-        if (e == 0xFFFFu) continue;
-        const int slot = e >> 6, bit = e & 63;
+        const uint32_t e = s_lut[lk * 128 + k];          // (8 * block slot) << 6 | bit; slot 27 = padding offset
+        const int slot = e >> 9, bit = e & 63;
+        if (slot >= 27) continue;
         const uint64_t m = s_m[r][slot];
         if ((m >> bit) & 1ull) {
           float f = 1.f;
