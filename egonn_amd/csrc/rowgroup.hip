@@ -16,6 +16,7 @@
 //                   snbr[(g*K + k)*16 + s] = input row (-1 = absent): one coalesced 64-byte line per (g, k).
 // Window slot w owns the WIN/16 groups [w*GPW, (w+1)*GPW); partial windows leave trailing groups empty.  All sizes
 // are read from device memory (row count, per-sample offsets), so the builder needs no host knowledge of N_l.
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -50,16 +51,27 @@ struct RGJob {
 struct RGArgs {
   RGJob job[RG_MAX_JOBS];
   int njobs, B, nblocks;
+  unsigned long long* trace;   // measurement hook (egonn_debug_set_trace): 8 s_memtime stamps per window; null = off
 };
 
 static constexpr int RG_THREADS = 1024;                 // 16 waves per window: the per-group passes are latency chains
 static constexpr int RG_WAVES = RG_THREADS / 64;
 __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
+  // The window's slice of the kernel map (WIN x K ints, contiguous in memory: 110 KB for K = 27) is read ONCE, fully
+  // coalesced, into LDS; masks, sort and the transposed emit all work from there.  (The first version read the rows twice
+  // from global memory in 108-byte pieces — the builder was bound by those partial-line requests, 66 us per step.)
+  extern __shared__ __attribute__((aligned(16))) int32_t stbl[];          // [WIN][K]
   __shared__ unsigned long long skey[RG_MAX_WIN];
   __shared__ uint32_t smask[RG_MAX_WIN];
-  __shared__ __attribute__((aligned(16))) int32_t stile[RG_WAVES * 27 * 16];
+  __shared__ uint16_t s_cnt[RG_WAVES][512];              // radix sort: per-wave digit counts -> per-wave offsets (<= 1024)
+  __shared__ uint32_t s_base[512];
+  __shared__ uint32_t s_k[RG_MAX_WIN];
+  __shared__ uint16_t s_i[RG_MAX_WIN];
   __shared__ int32_t s_info[4];
   const int tid = threadIdx.x, lane = tid & 63;
+  unsigned long long* const tr = a.trace ? a.trace + (size_t)blockIdx.x * 8 : nullptr;
+  auto stamp = [&](int i) { if (tr && tid == 0) tr[i] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
   int j = 0;
   while (j + 1 < a.njobs && (int)blockIdx.x >= a.job[j + 1].wbase) ++j;
   const RGJob& J = a.job[j];
@@ -104,64 +116,106 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
   const int r0 = J.boff[sb] + (w - s_info[1]) * WIN;
   const int rows = min(WIN, J.boff[sb + 1] - r0);
 
-  // ---- presence masks.  A wave reads whole table rows with consecutive lanes (K = 27: 2 rows per load, lanes 0-26 and
-  // 32-58; K = 8: 8 rows per load) — each load touches 2-4 cache lines instead of 64 — and a ballot IS the mask.
+  stamp(1);
+  // ---- the window's table -> LDS (coalesced dword loads; rows beyond the sample are never indexed)
   const int32_t* src = J.nbr + (int64_t)r0 * K;
-  const int wave = tid >> 6;
-  // (8 loads are issued before the first ballot: a dependent load -> ballot -> LDS chain per row was latency bound)
-  if (K == 27) {
-    const int half = lane >> 5, kk = lane & 31;
-    for (int rb = wave * 16; rb < WIN; rb += 16 * RG_WAVES) {   // waves x 8 loads x 2 rows
-      int32_t v[8];
+  const int nint = rows * K;
+  for (int i0 = 0; i0 < nint; i0 += 9 * RG_THREADS) {     // 9 independent loads per thread in flight (27 = 3 x 9)
+    int32_t v[9];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = rb + 2 * u + half;
-        v[u] = (r < rows && kk < 27) ? src[r * 27 + kk] : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = rb + 2 * u + half;
-        const unsigned long long bal = __ballot(v[u] >= 0);
-        if (kk == 0 && r < WIN) smask[r] = (uint32_t)(bal >> (32 * half)) & 0x07FFFFFFu;
-      }
+    for (int u = 0; u < 9; ++u) {
+      const int i = i0 + u * RG_THREADS + tid;
+      v[u] = (i < nint) ? src[i] : -1;
     }
-  } else {
-    const int sub = lane >> 3, kk = lane & 7;
-    for (int rb = wave * 64; rb < WIN; rb += 64 * RG_WAVES) {   // waves x 8 loads x 8 rows
-      int32_t v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = rb + 8 * u + sub;
-        v[u] = (r < rows) ? src[r * 8 + kk] : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = rb + 8 * u + sub;
-        const unsigned long long bal = __ballot(v[u] >= 0);
-        if (kk == 0 && r < WIN) smask[r] = (uint32_t)(bal >> (8 * sub)) & 0xFFu;
-      }
+    for (int u = 0; u < 9; ++u) {
+      const int i = i0 + u * RG_THREADS + tid;
+      if (i < nint) stbl[i] = v[u];
     }
   }
   __syncthreads();
+  stamp(2);
+  // ---- presence masks: one row per thread (row stride K = 27 or 8 dwords: 27 is odd => conflict-free)
   for (int i = tid; i < WIN; i += RG_THREADS) {
-    unsigned long long key = ~0ull;
-    if (i < rows) key = ((unsigned long long)(K == 27 ? remap27(smask[i]) : smask[i]) << 16) | (unsigned)i;
-    skey[i] = key;
+    uint32_t m = 0;
+    if (i < rows) {
+      const int32_t* row = stbl + i * K;
+      if (K == 27) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) m |= (uint32_t)(row[k] >= 0) << k;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m |= (uint32_t)(row[k] >= 0) << k;
+      }
+    }
+    smask[i] = m;
   }
   __syncthreads();
-  // ---- bitonic sort of the window (ascending; padding keys are all-ones and end up last)
-  for (int k2 = 2; k2 <= WIN; k2 <<= 1) {
-    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-      for (int e = tid; e < WIN / 2; e += RG_THREADS) {
-        const int i = ((e & ~(j2 - 1)) << 1) | (e & (j2 - 1));
-        const int p = i | j2;
-        const bool up = (i & k2) == 0;
-        const unsigned long long x = skey[i], y = skey[p];
-        if ((x > y) == up) { skey[i] = y; skey[p] = x; }
+  stamp(3);
+  // ---- stable LSD radix sort of the window by the (remapped) mask, 9 bits per pass, one element per thread; ties keep
+  // the row order, padding (mask 0xFFFFFFFF) ends up last.  3 passes for the 27-offset maps, 1 for the 8-slot maps.
+  // (A 55-stage bitonic network through LDS cost 25 800 cycles of a window's 47 600 — tools/rowgroup_trace.py.)
+  static_assert(RG_THREADS == RG_MAX_WIN, "one element per thread");
+  {
+    const int wave = tid >> 6;
+    const bool act = tid < WIN;
+    uint32_t km = 0xFFFFFFFFu;
+    uint32_t idx = (uint32_t)tid;
+    if (tid < rows) km = (K == 27) ? remap27(smask[tid]) : smask[tid];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int npass = (K == 27) ? 3 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+      for (int e = tid; e < RG_WAVES * 512 / 2; e += RG_THREADS) reinterpret_cast<uint32_t*>(&s_cnt[0][0])[e] = 0u;
+      __syncthreads();
+      const uint32_t d = (km >> (9 * pass)) & 511u;
+      unsigned long long peers = __ballot(act);
+#pragma unroll
+      for (int bit = 0; bit < 9; ++bit) {
+        const bool on = (d >> bit) & 1u;
+        const unsigned long long bal = __ballot(on);
+        peers &= on ? bal : ~bal;
+      }
+      const int rank = __popcll(peers & lt), cnt = __popcll(peers);
+      if (act && rank == 0) s_cnt[wave][d] = (uint16_t)cnt;
+      __syncthreads();
+      if (tid < 512) {                                   // digit tid: exclusive prefix over the waves, total of the digit
+        uint32_t run = 0;
+#pragma unroll
+        for (int wv = 0; wv < RG_WAVES; ++wv) {
+          const uint32_t c = s_cnt[wv][tid];
+          s_cnt[wv][tid] = (uint16_t)run;
+          run += c;
+        }
+        s_base[tid] = run;
       }
       __syncthreads();
+      if (tid < 64) {                                    // exclusive scan of the 512 digit totals: 8 per lane
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { v[q] = s_base[8 * lane + q]; sum += v[q]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t up = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += up;
+        }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s_base[8 * lane + q] = run; run += v[q]; }
+      }
+      __syncthreads();
+      if (act) {
+        const uint32_t pos = s_base[d] + s_cnt[wave][d] + (uint32_t)rank;
+        s_k[pos] = km;
+        s_i[pos] = (uint16_t)idx;
+      }
+      __syncthreads();
+      if (act) { km = s_k[tid]; idx = s_i[tid]; }
     }
+    if (act) skey[tid] = (km != 0xFFFFFFFFu) ? (((unsigned long long)km << 16) | idx) : ~0ull;
   }
+  __syncthreads();
+  stamp(4);
   // ---- perm + group masks
   const int64_t gbase = (int64_t)w * GPW;
   for (int i = tid; i < WIN; i += RG_THREADS) {         // WIN is a multiple of 64: whole waves stay in the loop
@@ -174,42 +228,25 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
     for (int o = 1; o < 16; o <<= 1) m |= __shfl_xor(m, o, 64);
     if ((i & 15) == 0) J.gmask[gbase + (i >> 4)] = m;
   }
-  // ---- sorted table, one 64-byte line per (group, offset).  Per group a wave reads its 16 rows as whole rows (as
-  // above), transposes them through a wave-private LDS tile [k][slot] and writes the group's contiguous K x 64-byte
-  // block with 16-byte stores.
+  stamp(5);
+  // ---- sorted table, one 64-byte line per (group, offset): thread = one 16-byte piece (4 consecutive slots of one
+  // offset), its four values gathered from the LDS table (rows are random, the column is fixed: stride-27 rows spread
+  // over the banks), written as the group's contiguous K x 64-byte block
   const int ngr = (rows + 15) >> 4;                     // groups with real rows
-  int32_t* tile = reinterpret_cast<int32_t*>(stile) + wave * (27 * 16);
-  for (int gl = wave; gl < ngr; gl += RG_WAVES) {
-    if (K == 27) {
-      const int half = lane >> 5, kk = lane & 31;
-      unsigned long long key[8];
-      int32_t v[8];
+  const int ppg = K * 4;                                // pieces per group
+  for (int e = tid; e < ngr * ppg; e += RG_THREADS) {
+    const int gl = e / ppg, pc = e - gl * ppg;
+    const int k = pc >> 2, s0 = (pc & 3) * 4;
+    int32_t v[4];
 #pragma unroll
-      for (int h = 0; h < 8; ++h) key[h] = skey[gl * 16 + 2 * h + half];
-#pragma unroll
-      for (int h = 0; h < 8; ++h) v[h] = (kk < 27 && key[h] != ~0ull) ? src[(int)(key[h] & 0xFFFFu) * 27 + kk] : -1;
-#pragma unroll
-      for (int h = 0; h < 8; ++h)
-        if (kk < 27) tile[kk * 16 + 2 * h + half] = v[h];
-    } else {
-      const int sub = lane >> 3, kk = lane & 7;
-      unsigned long long key[2];
-      int32_t v[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) key[h] = skey[gl * 16 + 8 * h + sub];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) v[h] = (key[h] != ~0ull) ? src[(int)(key[h] & 0xFFFFu) * 8 + kk] : -1;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) tile[kk * 16 + 8 * h + sub] = v[h];
+    for (int j2 = 0; j2 < 4; ++j2) {
+      const unsigned long long key = skey[gl * 16 + s0 + j2];
+      v[j2] = (key != ~0ull) ? stbl[(int)(key & 0xFFFFu) * K + k] : -1;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    int4* dst = reinterpret_cast<int4*>(J.snbr + (gbase + gl) * K * 16);
-    const int n16 = K * 4;
-    for (int e = lane; e < n16; e += 64) dst[e] = reinterpret_cast<const int4*>(tile)[e];
-    __builtin_amdgcn_wave_barrier();
+    reinterpret_cast<int4*>(J.snbr + (gbase + gl) * K * 16)[pc] = make_int4(v[0], v[1], v[2], v[3]);
   }
+  stamp(6);
+  if (tr && tid == 0) tr[7] = (unsigned long long)K | ((unsigned long long)rows << 8);
 }
 
 // Builds the row-group tables of `jobs` (all in one launch).  Every job's arrays must hold cap_groups groups.
@@ -230,8 +267,16 @@ int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream) {
     nb += b.rg->cap_groups / (b.rg->win / 16);
   }
   a.nblocks = nb;
+  a.trace = g_sconv_trace;
   if (nb == 0) return EGONN_OK;
-  hipLaunchKernelGGL(rowgroup_build_kernel, dim3((unsigned)nb), dim3(RG_THREADS), 0, stream, a);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgroup_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));   // + 35 KB static
+    attr_done = true;
+  }
+  size_t lds = 0;                                        // the largest window table of the launch
+  for (int j = 0; j < njobs; ++j) lds = std::max(lds, (size_t)jobs[j].rg->win * jobs[j].rg->K * sizeof(int32_t));
+  hipLaunchKernelGGL(rowgroup_build_kernel, dim3((unsigned)nb), dim3(RG_THREADS), lds, stream, a);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }

@@ -52,3 +52,26 @@ for lvl in (1, 2, 3, 4, 5):
         if ors_gr:
             res["greedy_x1(sample)"] = 16.0 * sum(popc(o).sum() for o, _ in ors_gr) / sum(t for _, t in ors_gr)
     print(f"L{lvl}: " + "  ".join(f"{k} {v:.3f}" for k, v in res.items()), flush=True)
+
+# ---- how many of the (remapped, rare-offsets-first) mask bits does the window sort have to honour?
+ORDER = [13, 12, 14, 10, 16, 9, 11, 15, 17, 4, 22, 1, 7, 3, 5, 19, 25, 21, 23, 0, 2, 6, 8, 18, 20, 24, 26]
+def remap(m):
+    r = np.zeros_like(m)
+    for i, o in enumerate(ORDER):
+        r |= ((m >> np.uint32(o)) & np.uint32(1)) << np.uint32(i)
+    return r
+print("padding when the window sort is a stable sort on the top T bits of the remapped mask (T = 27: what ships)")
+for lvl in (1, 2, 3, 4):
+    sm = d[f"slotmask_{lvl}"]
+    win_groups = 64 if lvl <= 3 else 16
+    tot = popc(sm.reshape(-1)).sum()
+    res = {}
+    for T in (27, 18, 14, 12, 10, 8, 6, 0):
+        ors = []
+        for w0 in range(0, len(sm), win_groups):
+            m = sm[w0:w0 + win_groups].reshape(-1); m = m[m != 0]
+            if len(m) == 0: continue
+            key = remap(m) >> np.uint32(27 - T) if T else np.zeros_like(m)
+            ors.append(group_consecutive(m[np.argsort(key, kind="stable")]))
+        res[T] = pad_of(np.concatenate(ors), tot)
+    print(f"L{lvl}: " + "  ".join(f"T={k}: {v:.3f}" for k, v in res.items()), flush=True)
