@@ -56,6 +56,7 @@ struct RGArgs {
 
 static constexpr int RG_THREADS = 1024;                 // 16 waves per window: the per-group passes are latency chains
 static constexpr int RG_WAVES = RG_THREADS / 64;
+template <bool TRACE>    // TRACE: measurement build (tools/rowgroup_trace.py), s_memtime stamps per phase; the release build has none
 __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
   // The window's slice of the kernel map (WIN x K ints, contiguous in memory: 110 KB for K = 27) is read ONCE, fully
   // coalesced, into LDS; masks, sort and the transposed emit all work from there.  (The first version read the rows twice
@@ -69,8 +70,12 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
   __shared__ uint16_t s_i[RG_MAX_WIN];
   __shared__ int32_t s_info[4];
   const int tid = threadIdx.x, lane = tid & 63;
-  unsigned long long* const tr = a.trace ? a.trace + (size_t)blockIdx.x * 8 : nullptr;
-  auto stamp = [&](int i) { if (tr && tid == 0) tr[i] = __builtin_amdgcn_s_memtime(); };
+  unsigned long long* const tr = (TRACE && a.trace) ? a.trace + (size_t)blockIdx.x * 8 : nullptr;
+  auto stamp = [&](int i) {
+    if constexpr (TRACE) {
+      if (tr && tid == 0) tr[i] = __builtin_amdgcn_s_memtime();
+    }
+  };
   stamp(0);
   int j = 0;
   while (j + 1 < a.njobs && (int)blockIdx.x >= a.job[j + 1].wbase) ++j;
@@ -246,7 +251,9 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
     reinterpret_cast<int4*>(J.snbr + (gbase + gl) * K * 16)[pc] = make_int4(v[0], v[1], v[2], v[3]);
   }
   stamp(6);
-  if (tr && tid == 0) tr[7] = (unsigned long long)K | ((unsigned long long)rows << 8);
+  if constexpr (TRACE) {
+    if (tr && tid == 0) tr[7] = (unsigned long long)K | ((unsigned long long)rows << 8);
+  }
 }
 
 // Builds the row-group tables of `jobs` (all in one launch).  Every job's arrays must hold cap_groups groups.
@@ -271,12 +278,14 @@ int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream) {
   if (nb == 0) return EGONN_OK;
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgroup_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));   // + 35 KB static
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgroup_build_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));   // + 35 KB static
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgroup_build_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
     attr_done = true;
   }
   size_t lds = 0;                                        // the largest window table of the launch
   for (int j = 0; j < njobs; ++j) lds = std::max(lds, (size_t)jobs[j].rg->win * jobs[j].rg->K * sizeof(int32_t));
-  hipLaunchKernelGGL(rowgroup_build_kernel, dim3((unsigned)nb), dim3(RG_THREADS), lds, stream, a);
+  if (a.trace) hipLaunchKernelGGL(rowgroup_build_kernel<true>, dim3((unsigned)nb), dim3(RG_THREADS), lds, stream, a);
+  else hipLaunchKernelGGL(rowgroup_build_kernel<false>, dim3((unsigned)nb), dim3(RG_THREADS), lds, stream, a);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
