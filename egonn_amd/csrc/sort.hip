@@ -39,18 +39,37 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_hist_kernel(const uint64_t* _
   hist[tid] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
-#pragma unroll 4
+  // wave-aggregated counting: the lanes of a wave that hold the same digit are found with a ballot match-any and ONE of them
+  // adds their number — the high digits of a Z-order key are nearly constant inside a tile (the batch digit exactly), and
+  // 2048 LDS atomics on one bin serialise (the histogram of such a pass took as long as the scatter)
+  const int lane = tid & 63;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint64_t kreg[SORT_ROUNDS];
+#pragma unroll
   for (int r = 0; r < SORT_ROUNDS; ++r) {
-    int64_t i = base + (int64_t)r * SORT_BLOCK + tid;
-    if (i < n) atomicAdd(&hist[(keys[i] >> shift) & 0xFF], 1);
+    const int64_t i = base + (int64_t)r * SORT_BLOCK + tid;
+    kreg[r] = (i < n) ? keys[i] : 0ull;
+  }
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int64_t i = base + (int64_t)r * SORT_BLOCK + tid;
+    const bool valid = i < n;
+    const uint32_t d = (uint32_t)(kreg[r] >> shift) & 0xFF;
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1;
+      const uint64_t bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    if (valid && (m & lt) == 0) atomicAdd(&hist[d], (int32_t)__popcll(m));
   }
   __syncthreads();
   const int32_t c = hist[tid];
   tilehist[(int64_t)blockIdx.x * 256 + tid] = c;
-  if (c) {
-    atomicAdd(&superhist[(blockIdx.x / SORT_SUPER) * 256 + tid], c);
-    atomicAdd(&total[tid], c);
-  }
+  // (no grand-total atomics: every tile of a pass adding to the same 256 words serialised — 1 563 tiles at batch 64 cost
+  // more than reading the keys; the scatter sums the <= 64 supertile rows instead)
+  if (c) atomicAdd(&superhist[(blockIdx.x / SORT_SUPER) * 256 + tid], c);
 }
 
 __global__ __launch_bounds__(SORT_BLOCK) void sort_scatter_kernel(
@@ -68,12 +87,16 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_scatter_kernel(
 
   // ---- global base for digit d = tid: (#keys with smaller digit) + (#keys with digit d in earlier tiles)
   {
-    int32_t before = 0;
+    int32_t before = 0, tot = 0;
     const int super = tile / SORT_SUPER;
-    for (int s = 0; s < super; ++s) before += superhist[s * 256 + tid];
+    const int nsuper = (gridDim.x + SORT_SUPER - 1) / SORT_SUPER;
+    for (int s = 0; s < nsuper; ++s) {
+      const int32_t c = superhist[s * 256 + tid];
+      tot += c;
+      if (s < super) before += c;
+    }
     for (int t = super * SORT_SUPER; t < tile; ++t) before += tilehist[(int64_t)t * 256 + tid];
-    // exclusive scan of total[] over the 256 digits (wave scan + 4 wave sums)
-    const int32_t tot = total[tid];
+    // exclusive scan of the digit totals over the 256 digits (wave scan + 4 wave sums)
     int32_t incl = tot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
