@@ -404,38 +404,50 @@ __device__ static inline int sample_of_row(const int32_t* __restrict__ boff, int
   return lo;
 }
 
+// thread = 16 bytes of a row (4 fp32 or 8 bf16 channels): full-width accesses for both precisions (8-byte accesses run at
+// 0.5-0.7 of the 16-byte rate); cq = channels / (16 bytes' worth) is a power of two
 template <bool BF16>
 __global__ void eca_apply_kernel(const void* __restrict__ x, const void* __restrict__ res,
                                  const float* __restrict__ gate, const int32_t* __restrict__ boff, int B, int64_t n,
-                                 int c4, void* __restrict__ out) {
+                                 int cq_shift, void* __restrict__ out) {
+  constexpr int CPT = BF16 ? 8 : 4;                      // channels per thread
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   n = min((int64_t)boff[B], n);                          // rows in use (reserved plans size the grid for the capacity)
-  if (t >= n * c4) return;
-  const int32_t r = (int32_t)(t / c4);
-  const int q = (int)(t - (int64_t)r * c4);
+  if (t >= (n << cq_shift)) return;
+  const int32_t r = (int32_t)(t >> cq_shift);
+  const int q = (int)(t - ((int64_t)r << cq_shift));
   const int b = sample_of_row(boff, B, r);
-  float4 xv, rv;
+  const float* gp = gate + (((int64_t)b << cq_shift) + q) * CPT;
+  float xv[CPT], rv[CPT], g[CPT];
   if constexpr (BF16) {
-    const uint2 xh = reinterpret_cast<const uint2*>(x)[t], rh = reinterpret_cast<const uint2*>(res)[t];
-    xv = make_float4(bf2f(xh.x & 0xFFFFu), bf2f(xh.x >> 16), bf2f(xh.y & 0xFFFFu), bf2f(xh.y >> 16));
-    rv = make_float4(bf2f(rh.x & 0xFFFFu), bf2f(rh.x >> 16), bf2f(rh.y & 0xFFFFu), bf2f(rh.y >> 16));
+    const uint4 xh = reinterpret_cast<const uint4*>(x)[t], rh = reinterpret_cast<const uint4*>(res)[t];
+    const uint32_t xw[4] = {xh.x, xh.y, xh.z, xh.w}, rw[4] = {rh.x, rh.y, rh.z, rh.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xv[2 * i] = bf2f(xw[i] & 0xFFFFu); xv[2 * i + 1] = bf2f(xw[i] >> 16);
+      rv[2 * i] = bf2f(rw[i] & 0xFFFFu); rv[2 * i + 1] = bf2f(rw[i] >> 16);
+    }
+    const float4 g0 = reinterpret_cast<const float4*>(gp)[0], g1 = reinterpret_cast<const float4*>(gp)[1];
+    g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
   } else {
-    xv = reinterpret_cast<const float4*>(x)[t];
-    rv = reinterpret_cast<const float4*>(res)[t];
+    const float4 xf = reinterpret_cast<const float4*>(x)[t], rf = reinterpret_cast<const float4*>(res)[t];
+    const float4 g0 = reinterpret_cast<const float4*>(gp)[0];
+    xv[0] = xf.x; xv[1] = xf.y; xv[2] = xf.z; xv[3] = xf.w;
+    rv[0] = rf.x; rv[1] = rf.y; rv[2] = rf.z; rv[3] = rf.w;
+    g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w;
   }
-  const float4 g = reinterpret_cast<const float4*>(gate)[(int64_t)b * c4 + q];
-  float4 o;
-  o.x = fmaxf(xv.x * g.x + rv.x, 0.f);
-  o.y = fmaxf(xv.y * g.y + rv.y, 0.f);
-  o.z = fmaxf(xv.z * g.z + rv.z, 0.f);
-  o.w = fmaxf(xv.w * g.w + rv.w, 0.f);
+  float o[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) o[i] = fmaxf(xv[i] * g[i] + rv[i], 0.f);
   if constexpr (BF16) {
-    uint2 oh;
-    oh.x = f2bf_rn(o.x) | (f2bf_rn(o.y) << 16);
-    oh.y = f2bf_rn(o.z) | (f2bf_rn(o.w) << 16);
-    reinterpret_cast<uint2*>(out)[t] = oh;
+    uint4 oh;
+    oh.x = f2bf_rn(o[0]) | (f2bf_rn(o[1]) << 16);
+    oh.y = f2bf_rn(o[2]) | (f2bf_rn(o[3]) << 16);
+    oh.z = f2bf_rn(o[4]) | (f2bf_rn(o[5]) << 16);
+    oh.w = f2bf_rn(o[6]) | (f2bf_rn(o[7]) << 16);
+    reinterpret_cast<uint4*>(out)[t] = oh;
   } else {
-    reinterpret_cast<float4*>(out)[t] = o;
+    reinterpret_cast<float4*>(out)[t] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 __global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ in, int64_t n, float* __restrict__ out) {
@@ -459,8 +471,9 @@ int eca_apply(const float* x, const float* res, const float* partial, const int3
   hipLaunchKernelGGL(eca_gate_kernel, dim3(B), dim3(256), c * sizeof(float), stream, partial, boff, c, wconv, ksize,
                      gate);
   const int c4 = c / 4;
+  EGONN_REQUIRE((c4 & (c4 - 1)) == 0, EGONN_ERR_INVALID, "eca_apply: %d channels (a power of two expected)", c);
   hipLaunchKernelGGL(eca_apply_kernel<false>, dim3((unsigned)cdiv(n * c4, 256)), dim3(256), 0, stream, x, res, gate, boff, B,
-                     n, c4, out);
+                     n, __builtin_ctz(c4), out);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
@@ -522,13 +535,14 @@ int eca_gate_groups(const float* psum, const RowGroups& rg, const int32_t* boff,
 int eca_apply_gate(const void* x, const void* res, const float* gate, const int32_t* boff, int B, int64_t n, int c,
                    void* out, int bf16, hipStream_t stream) {
   if (n == 0) return EGONN_OK;
-  const int c4 = c / 4;
+  const int cq = bf16 ? c / 8 : c / 4;                   // 16-byte pieces per row
+  EGONN_REQUIRE(cq >= 1 && (cq & (cq - 1)) == 0, EGONN_ERR_INVALID, "eca_apply: %d channels (a power of two expected)", c);
   if (bf16)
-    hipLaunchKernelGGL(eca_apply_kernel<true>, dim3((unsigned)cdiv(n * c4, 256)), dim3(256), 0, stream, x, res, gate, boff, B, n,
-                       c4, out);
+    hipLaunchKernelGGL(eca_apply_kernel<true>, dim3((unsigned)cdiv(n * cq, 256)), dim3(256), 0, stream, x, res, gate, boff, B, n,
+                       __builtin_ctz(cq), out);
   else
-    hipLaunchKernelGGL(eca_apply_kernel<false>, dim3((unsigned)cdiv(n * c4, 256)), dim3(256), 0, stream, x, res, gate, boff, B, n,
-                       c4, out);
+    hipLaunchKernelGGL(eca_apply_kernel<false>, dim3((unsigned)cdiv(n * cq, 256)), dim3(256), 0, stream, x, res, gate, boff, B, n,
+                       __builtin_ctz(cq), out);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
