@@ -84,18 +84,42 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_scatter_kernel(
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int tile = blockIdx.x;
+  // the tile's keys are requested first: they do not depend on the histogram sums below, whose L2 round trips they overlap
+  const int64_t wbase = (int64_t)tile * SORT_TILE + (int64_t)wave * (64 * SORT_ROUNDS);
+  uint64_t k[SORT_ROUNDS];
+  uint32_t v[SORT_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int64_t i = wbase + r * 64 + lane;
+    const bool valid = i < n;
+    k[r] = valid ? keys_in[i] : ~0ull;
+    v[r] = valid ? vals_in[i] : 0u;
+  }
 
   // ---- global base for digit d = tid: (#keys with smaller digit) + (#keys with digit d in earlier tiles)
   {
+    // (the loads of these two sums are issued 8 at a time: as a plain loop every load waited for the previous one, and ~30
+    // L2 round trips were most of a tile's 15 us)
     int32_t before = 0, tot = 0;
     const int super = tile / SORT_SUPER;
     const int nsuper = (gridDim.x + SORT_SUPER - 1) / SORT_SUPER;
-    for (int s = 0; s < nsuper; ++s) {
-      const int32_t c = superhist[s * 256 + tid];
-      tot += c;
-      if (s < super) before += c;
+    for (int s0 = 0; s0 < nsuper; s0 += 8) {
+      int32_t c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = (s0 + u < nsuper) ? superhist[(s0 + u) * 256 + tid] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        tot += c[u];
+        if (s0 + u < super) before += c[u];
+      }
     }
-    for (int t = super * SORT_SUPER; t < tile; ++t) before += tilehist[(int64_t)t * 256 + tid];
+    for (int t0 = super * SORT_SUPER; t0 < tile; t0 += 8) {
+      int32_t c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = (t0 + u < tile) ? tilehist[(int64_t)(t0 + u) * 256 + tid] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) before += c[u];
+    }
     // exclusive scan of the digit totals over the 256 digits (wave scan + 4 wave sums)
     int32_t incl = tot;
 #pragma unroll
@@ -114,19 +138,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_scatter_kernel(
   __syncthreads();
 
   // ---- stable ranking: wave `wave` owns keys [base + wave*64*ROUNDS, +64*ROUNDS)
-  const int64_t wbase = (int64_t)tile * SORT_TILE + (int64_t)wave * (64 * SORT_ROUNDS);
-  uint64_t k[SORT_ROUNDS];
-  uint32_t v[SORT_ROUNDS];
   int32_t rank[SORT_ROUNDS];
   volatile int32_t* my = whist[wave];
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-  for (int r = 0; r < SORT_ROUNDS; ++r) {
-    const int64_t i = wbase + r * 64 + lane;
-    const bool valid = i < n;
-    k[r] = valid ? keys_in[i] : ~0ull;
-    v[r] = valid ? vals_in[i] : 0u;
-  }
 #pragma unroll
   for (int r = 0; r < SORT_ROUNDS; ++r) {
     const int64_t i = wbase + r * 64 + lane;
@@ -146,9 +160,29 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_scatter_kernel(
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  // ---- per-digit offset of this wave = dbase + counts of earlier waves  (thread = digit)
+  // ---- thread = digit: the tile's count of the digit, the start of the digit's run INSIDE the tile (exclusive scan over
+  // the digits), and per wave the local position of its first key of that digit
+  __shared__ uint64_t lkey[SORT_TILE];          // the tile, locally sorted by digit (stable)
+  __shared__ uint32_t lval[SORT_TILE];
+  __shared__ int32_t delta[256];                // global position - local position, per digit
   {
-    int32_t acc = dbase[tid];
+    int32_t cnt = 0;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) cnt += whist[w][tid];
+    int32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int32_t u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    __syncthreads();                             // wsum was last read in the digit-base scan above
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int32_t lstart = woff + incl - cnt;
+    delta[tid] = dbase[tid] - lstart;
+    int32_t acc = lstart;
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; ++w) {
       const int32_t c = whist[w][tid];
@@ -157,14 +191,31 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_scatter_kernel(
     }
   }
   __syncthreads();
+  // ---- local reorder: every key goes to its place in the tile's digit-sorted image ...
 #pragma unroll
   for (int r = 0; r < SORT_ROUNDS; ++r) {
     const int64_t i = wbase + r * 64 + lane;
     if (i < n) {
       const uint32_t d = (uint32_t)(k[r] >> shift) & 0xFF;
-      const int64_t dst = (int64_t)whist[wave][d] + rank[r];
-      keys_out[dst] = k[r];
-      vals_out[dst] = v[r];
+      const int32_t pos = whist[wave][d] + rank[r];
+      lkey[pos] = k[r];
+      lval[pos] = v[r];
+    }
+  }
+  __syncthreads();
+  // ---- ... and leaves in runs: consecutive threads hold consecutive keys of one digit => consecutive global addresses.
+  // (Scattering straight from the registers made every store instruction touch up to 64 different lines: most of a
+  // tile's time.)
+  const int64_t tile_base = (int64_t)tile * SORT_TILE;
+  const int32_t nk = (int32_t)min((int64_t)SORT_TILE, n - tile_base);
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int32_t p = r * SORT_BLOCK + tid;
+    if (p < nk) {
+      const uint64_t kk = lkey[p];
+      const int64_t dst = (int64_t)delta[(uint32_t)(kk >> shift) & 0xFF] + p;
+      keys_out[dst] = kk;
+      vals_out[dst] = lval[p];
     }
   }
 }
