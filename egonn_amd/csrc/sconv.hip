@@ -1,4 +1,9 @@
-// Sparse convolution for gfx950: row-group kernel with register accumulators.
+// Sparse convolution for gfx950: row-group kernels with register accumulators.
+//
+// Three kernels share the decomposition below and produce bitwise-identical results:
+//   sconv_rg_kernel   operands through a register ring            (small launches, bf16 maps)
+//   sconv_dma_kernel  gathered rows by LDS-DMA in full 128-B lines (fp32 maps, launches that fill the chip)
+//   sconv_wg_kernel   W slabs shared by a workgroup through LDS   (bf16 maps, big layers with >= 64 channels)
 //
 // Replaces MinkowskiConvolution / MinkowskiConvolutionTranspose forward as called from the reference
 // (models/minkgl.py:39,100,105 and :46-60; ME BasicBlock conv1/conv2 via layers/eca_block.py:58-63;
@@ -16,14 +21,16 @@
 // Missing neighbours are row "-1": the buffer resource's bounds check returns zeros without touching memory, so the
 // loop has no predicates.  Operands are fed swapped (D^T = W^T A^T): lane (row = l&15, g = l>>4) ends up with four
 // CONSECUTIVE output columns of its row, i.e. one 16-byte (fp32) / 8-byte (bf16) store per tile, BN scale/shift and
-// ReLU fused.  There is no LDS accumulator, no atomics, no split over offsets and no workgroup barrier: every output row
-// is produced by one wave, summed in ascending k, ascending channel order => results do not depend on the grouping
-// (batch-invariant, bitwise reproducible).
+// ReLU fused.  There is no LDS accumulator, no atomics and no split over offsets: every output row is produced by one wave
+// (or, for >= 64 input channels, by the KSP waves of one workgroup that split the channel blocks and add their partials
+// in fixed order), summed in ascending k, ascending channel order => results do not depend on the grouping, the batch or
+// the kernel variant (batch-invariant, bitwise reproducible).
 // Items are software pipelined through a register ring (D slots of A+W), issued in consumption order because
 // s_waitcnt vmcnt is in-order; the neighbour rows of a group (K x 16 ints) are staged once into wave-private LDS so the
 // index lookups ride the lgkm counter and never drain the vector-memory queue.
-// The launch is persistent: the number of groups is read from device memory (meta[0]), workgroups stride over the
-// group range XCD by XCD (block b runs on XCD b % 8: consecutive groups — Z-order neighbours — share an L2).
+// The number of groups is read from device memory (meta[0]); the grid is sized from the host's upper bound, one task per
+// workgroup (workgroup = the KSP waves of a tile), and every XCD takes a contiguous eighth of the tasks (block b runs on
+// XCD b % 8: consecutive groups — Z-order neighbours — share an L2).
 // Optional epilogue: per-group column sums of the stored values (fixed order) for the ECA / GeM pooling.
 #include <algorithm>
 #include <type_traits>
