@@ -4,7 +4,7 @@ set -u
 REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/swkt -o kt -- python $REPO/tools/bench_sconv.py > $OUT/swkt.log 2>&1
 python $REPO/tools/rocpd_summary.py $(find $OUT/swkt -name '*.db' | head -1) $OUT/sweep_kernel_stats.csv 1 > /dev/null 2>&1
-grep -E "sconv_rg|pack_rg|rowgroup" $OUT/sweep_kernel_stats.csv | cut -c1-200
+grep -E "sconv_|pack_rg|rowgroup" $OUT/sweep_kernel_stats.csv | cut -c1-200
 rm -rf $OUT/swkt
 i=0
 while IFS= read -r line; do
@@ -30,7 +30,7 @@ for d in sorted(glob.glob("gpurun_out/sw*/")):
     if not dbs: continue
     c = sqlite3.connect(dbs[0])
     for name, cn, v in c.execute("select kernel_name, counter_name, avg(value) from counters_collection group by kernel_name, counter_name"):
-        m = re.search(r"sconv_rg_kernel<[^>]*>|conv0_k5_kernel<[^>]*>", name)
+        m = re.search(r"sconv_(rg|dma|wg)_kernel<[^>]*>|conv0_k5_kernel<[^>]*>", name)
         if m: res[m.group(0).replace(" ", "")][cn] = v
 for k, d in res.items():
     print(k)
