@@ -421,7 +421,7 @@ __device__ static inline float row16_sum(float v) {      // sum over the 16 lane
   return v;
 }
 
-template <int CIN, int COUT, int D, int KSP, int NW, bool TRACE = false>
+template <int CIN, int COUT, int D, int KSP, int NW, bool TRACE = false, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64) void sconv_dma_kernel(const SconvArgs p) {
   constexpr int NS = COUT / 32, NCB = CIN / 32;
   constexpr int NCBL = NCB / KSP;
@@ -610,6 +610,28 @@ __global__ __launch_bounds__(NW * 64) void sconv_dma_kernel(const SconvArgs p) {
               acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wring[rs][nt * 2 + tt][u], (tt ? a1 : a0)[u], acc[nt], 0, 0, 0);
       };
 
+      // split-phase fetch (PIPE): the LDS reads of item i+1 are issued BEFORE the MFMAs of item i and awaited after them, so
+      // the LDS round trip leaves the wave's per-item critical path (costs one ring slot of look-ahead: D = 4)
+      auto fetch_issue = [&](auto RS, auto VM, f32x4& b0, f32x4& b1, int32_t& i0, int32_t& i1) {
+        constexpr int rs = decltype(RS)::value;
+        constexpr int vm = decltype(VM)::value;
+        const uint32_t r0 = rd0, r1 = rd1, tb = nxt_tb;
+        asm volatile(
+            "s_waitcnt vmcnt(%6)\n\t"
+            "ds_read_b128 %0, %4 offset:%7\n\t"
+            "ds_read_b128 %1, %5 offset:%7\n\t"
+            "ds_read_b32 %2, %8\n\t"
+            "ds_read_b32 %3, %8 offset:32"
+            : "=&v"(b0), "=&v"(b1), "=&v"(i0), "=&v"(i1)
+            : "v"(r0), "v"(r1), "n"(vm), "n"(rs * SLOT), "v"(tb)
+            : "memory");
+      };
+      auto fetch_wait = [&](f32x4& b0, f32x4& b1, int32_t& i0, int32_t& i1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(i0), "+v"(i1)::"memory");
+        pend_i0 = i0; pend_i1 = i1;
+        pend_acb = nxt_acb; pend_woff = nxt_woff;
+      };
+
       // ---- prologue: D-1 items in flight
       generate();
       rows_only();
@@ -617,32 +639,72 @@ __global__ __launch_bounds__(NW * 64) void sconv_dma_kernel(const SconvArgs p) {
         ((issue(std::integral_constant<int, Is>{}), generate(), rows_only(), __builtin_amdgcn_sched_barrier(0)), ...);
       }(std::make_integer_sequence<int, D - 1>{});
       if constexpr (TRACE) tr[2] = __builtin_amdgcn_s_memtime();
-      // ---- main loop
       const int n_main = n_items / D;
-      for (int it = 0; it < n_main; ++it) {
+      const int rem = n_items - n_main * D;
+      if constexpr (!PIPE) {
+        // ---- main loop
+        for (int it = 0; it < n_main; ++it) {
+          [&]<int... Is>(std::integer_sequence<int, Is...>) {
+            (([&] {
+               f32x4 a0, a1;
+               issue(std::integral_constant<int, (Is + D - 1) % D>{});
+               generate();
+               __builtin_amdgcn_sched_barrier(0);
+               fetch(std::integral_constant<int, Is>{}, std::integral_constant<int, VM_PER_ITEM*(D - 1)>{}, a0, a1);
+               mfmas(std::integral_constant<int, Is>{}, a0, a1);
+               __builtin_amdgcn_sched_barrier(0);
+             }()), ...);
+          }(std::make_integer_sequence<int, D>{});
+        }
+        // ---- remainder (< D items, in flight in slots 0..rem-1; nothing more is issued: wait for everything once)
         [&]<int... Is>(std::integer_sequence<int, Is...>) {
           (([&] {
-             f32x4 a0, a1;
-             issue(std::integral_constant<int, (Is + D - 1) % D>{});
-             generate();
-             __builtin_amdgcn_sched_barrier(0);
-             fetch(std::integral_constant<int, Is>{}, std::integral_constant<int, VM_PER_ITEM*(D - 1)>{}, a0, a1);
-             mfmas(std::integral_constant<int, Is>{}, a0, a1);
-             __builtin_amdgcn_sched_barrier(0);
+             if (Is < rem) {
+               f32x4 a0, a1;
+               fetch(std::integral_constant<int, Is>{}, std::integral_constant<int, 0>{}, a0, a1);
+               mfmas(std::integral_constant<int, Is>{}, a0, a1);
+             }
            }()), ...);
-        }(std::make_integer_sequence<int, D>{});
+        }(std::make_integer_sequence<int, D - 1>{});
+      } else {
+        f32x4 a0, a1;
+        {                                                  // operands of item 0 (its rows were read by rows_only above)
+          const uint32_t r0 = rd0, r1 = rd1;
+          asm volatile(
+              "s_waitcnt vmcnt(%4)\n\t"
+              "ds_read_b128 %0, %2\n\t"
+              "ds_read_b128 %1, %3\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(a0), "=&v"(a1)
+              : "v"(r0), "v"(r1), "n"(VM_PER_ITEM * (D - 2))
+              : "memory");
+        }
+        for (int it = 0; it < n_main; ++it) {
+          [&]<int... Is>(std::integer_sequence<int, Is...>) {
+            (([&] {
+               f32x4 b0, b1;
+               int32_t i0, i1;
+               issue(std::integral_constant<int, (Is + D - 1) % D>{});
+               generate();
+               __builtin_amdgcn_sched_barrier(0);
+               fetch_issue(std::integral_constant<int, (Is + 1) % D>{}, std::integral_constant<int, VM_PER_ITEM*(D - 2)>{}, b0, b1, i0, i1);
+               mfmas(std::integral_constant<int, Is>{}, a0, a1);
+               fetch_wait(b0, b1, i0, i1);
+               a0 = b0; a1 = b1;
+               __builtin_amdgcn_sched_barrier(0);
+             }()), ...);
+          }(std::make_integer_sequence<int, D>{});
+        }
+        // ---- remainder: item n_main*D (slot 0) is already in (a0, a1); the others are fetched with everything landed
+        [&]<int... Is>(std::integer_sequence<int, Is...>) {
+          (([&] {
+             if (Is < rem) {
+               if constexpr (Is > 0) fetch(std::integral_constant<int, Is>{}, std::integral_constant<int, 0>{}, a0, a1);
+               mfmas(std::integral_constant<int, Is>{}, a0, a1);
+             }
+           }()), ...);
+        }(std::make_integer_sequence<int, D - 1>{});
       }
-      // ---- remainder (< D items, in flight in slots 0..rem-1; nothing more is issued: wait for everything once)
-      const int rem = n_items - n_main * D;
-      [&]<int... Is>(std::integer_sequence<int, Is...>) {
-        (([&] {
-           if (Is < rem) {
-             f32x4 a0, a1;
-             fetch(std::integral_constant<int, Is>{}, std::integral_constant<int, 0>{}, a0, a1);
-             mfmas(std::integral_constant<int, Is>{}, a0, a1);
-           }
-         }()), ...);
-      }(std::make_integer_sequence<int, D - 1>{});
       if constexpr (TRACE) tr[3] = __builtin_amdgcn_s_memtime();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // items past the end are still landing in the ring
       __builtin_amdgcn_wave_barrier();
@@ -685,7 +747,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_dma_kernel(const SconvArgs p) {
 // 9 live waves of 16 (tools/sconv_trace.py).  The waves of a workgroup only have to be together when they split the input
 // channels of one tile (KSP > 1), so a workgroup is exactly those KSP waves; the dispatcher starts > 3000 workgroups/us
 // (tools/exp/dispatch_rate.hip), far more than these launches need.
-template <int CIN, int COUT, int KSP, int D, bool TRACE = false>
+template <int CIN, int COUT, int KSP, int D, bool TRACE = false, bool PIPE = false>
 static int launch_dma_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stream, int nw_sel = 0) {
   constexpr int NS = COUT / 32;
   auto go = [&](auto NWC) -> int {
@@ -693,7 +755,7 @@ static int launch_dma_d(const SconvArgs& a, int64_t groups_hint, hipStream_t str
     const size_t lds = NW * ((2 * 256 + 32) * 4 + D * 2048);
     static bool attr_done = false;                       // per instantiation (the lambda is instantiated per NW)
     if (!attr_done) {
-      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_dma_kernel<CIN, COUT, D, KSP, NW, TRACE>),
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_dma_kernel<CIN, COUT, D, KSP, NW, TRACE, PIPE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_done = true;
     }
@@ -702,10 +764,10 @@ static int launch_dma_d(const SconvArgs& a, int64_t groups_hint, hipStream_t str
     grid = (grid + 7) / 8 * 8;
     hipEvent_t* pev = prof_kernel_events();
     if (pev[0]) {
-      hipExtLaunchKernelGGL((sconv_dma_kernel<CIN, COUT, D, KSP, NW, TRACE>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, pev[0], pev[1], 0, a);
+      hipExtLaunchKernelGGL((sconv_dma_kernel<CIN, COUT, D, KSP, NW, TRACE, PIPE>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, pev[0], pev[1], 0, a);
       pev[0] = pev[1] = nullptr;
     } else {
-      hipLaunchKernelGGL((sconv_dma_kernel<CIN, COUT, D, KSP, NW, TRACE>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
+      hipLaunchKernelGGL((sconv_dma_kernel<CIN, COUT, D, KSP, NW, TRACE, PIPE>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
     }
     HIP_CHECK(hipGetLastError());
     return EGONN_OK;
@@ -992,7 +1054,7 @@ static int launch_rg_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stre
   return EGONN_OK;
 }
 // sel (tests / A-B measurements; every choice gives bitwise-identical results): 0 = product choice, 1 = register-ring
-// kernel, 2 = register-ring kernel with two groups per wave, 3 = LDS-DMA kernel (fp32 maps), 4 = LDS-DMA kernel with 4-wave workgroups, 9 = traced build
+// kernel, 2 = register-ring kernel with two groups per wave, 3 = LDS-DMA kernel (fp32 maps; split-phase LDS fetch, 4 ring slots), 4 = LDS-DMA kernel with the fetch inside the item (3 slots), 9 = traced build
 template <int CIN, int COUT, bool BF16>
 static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream, int sel) {
   constexpr int NS = COUT / 32, NCB = CIN / 32;
@@ -1005,10 +1067,10 @@ static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
   const bool small = groups_hint * NS * KSP < 6144;     // fewer waves than 6 per SIMD
   if constexpr (!BF16) {
     {
-      if (sel == 3 || (sel == 0 && !small)) return launch_dma_d<CIN, COUT, KSP, 3>(a, groups_hint, stream);
-      if (sel == 4) return launch_dma_d<CIN, COUT, KSP, 3>(a, groups_hint, stream, 4);
+      if (sel == 3 || (sel == 0 && !small)) return launch_dma_d<CIN, COUT, KSP, 4, false, true>(a, groups_hint, stream);
+      if (sel == 4) return launch_dma_d<CIN, COUT, KSP, 3>(a, groups_hint, stream);
       if constexpr ((CIN == 32 && COUT == 32) || (CIN == 64 && COUT == 64)) {
-        if (sel == 9) return launch_dma_d<CIN, COUT, KSP, 3, true>(a, groups_hint, stream);
+        if (sel == 9) return launch_dma_d<CIN, COUT, KSP, 4, true, true>(a, groups_hint, stream);
       }
     }
   }
