@@ -586,19 +586,6 @@ __global__ __launch_bounds__(NW * 64) void sconv_dma_kernel(const SconvArgs p) {
         pend_i0 = i0; pend_i1 = i1;
         pend_acb = nxt_acb; pend_woff = nxt_woff;
       };
-      auto rows_only = [&]() {
-        const uint32_t tb = nxt_tb;
-        int32_t i0, i1;
-        asm volatile(
-            "ds_read_b32 %0, %2\n\t"
-            "ds_read_b32 %1, %2 offset:32\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(i0), "=&v"(i1)
-            : "v"(tb)
-            : "memory");
-        pend_i0 = i0; pend_i1 = i1;
-        pend_acb = nxt_acb; pend_woff = nxt_woff;
-      };
       auto mfmas = [&](auto RS, const f32x4& a0, const f32x4& a1) {
         constexpr int rs = decltype(RS)::value;
 #pragma unroll
@@ -632,12 +619,44 @@ __global__ __launch_bounds__(NW * 64) void sconv_dma_kernel(const SconvArgs p) {
         pend_acb = nxt_acb; pend_woff = nxt_woff;
       };
 
-      // ---- prologue: D-1 items in flight
-      generate();
-      rows_only();
-      [&]<int... Is>(std::integer_sequence<int, Is...>) {
-        ((issue(std::integral_constant<int, Is>{}), generate(), rows_only(), __builtin_amdgcn_sched_barrier(0)), ...);
-      }(std::make_integer_sequence<int, D - 1>{});
+      // ---- prologue: D-1 items in flight.  The neighbour rows of the first D items are read with ONE LDS round trip
+      // (they were D dependent round trips: generate -> read -> issue -> generate -> read ...)
+      {
+        uint32_t ptb[D];
+        int pacb[D], pwoff[D];
+        int32_t pi0[D], pi1[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          generate();
+          ptb[j] = nxt_tb; pacb[j] = nxt_acb; pwoff[j] = nxt_woff;
+        }
+        static_assert(D == 3 || D == 4, "prologue asm is written for 3 or 4 ring slots");
+        if constexpr (D == 4) {
+          asm volatile(
+              "ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:32\n\t"
+              "ds_read_b32 %2, %9\n\tds_read_b32 %3, %9 offset:32\n\t"
+              "ds_read_b32 %4, %10\n\tds_read_b32 %5, %10 offset:32\n\t"
+              "ds_read_b32 %6, %11\n\tds_read_b32 %7, %11 offset:32\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(pi0[0]), "=&v"(pi1[0]), "=&v"(pi0[1]), "=&v"(pi1[1]), "=&v"(pi0[2]), "=&v"(pi1[2]), "=&v"(pi0[3]), "=&v"(pi1[3])
+              : "v"(ptb[0]), "v"(ptb[1]), "v"(ptb[2]), "v"(ptb[3])
+              : "memory");
+        } else {
+          asm volatile(
+              "ds_read_b32 %0, %6\n\tds_read_b32 %1, %6 offset:32\n\t"
+              "ds_read_b32 %2, %7\n\tds_read_b32 %3, %7 offset:32\n\t"
+              "ds_read_b32 %4, %8\n\tds_read_b32 %5, %8 offset:32\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(pi0[0]), "=&v"(pi1[0]), "=&v"(pi0[1]), "=&v"(pi1[1]), "=&v"(pi0[2]), "=&v"(pi1[2])
+              : "v"(ptb[0]), "v"(ptb[1]), "v"(ptb[2])
+              : "memory");
+        }
+        [&]<int... Is>(std::integer_sequence<int, Is...>) {
+          ((pend_i0 = pi0[Is], pend_i1 = pi1[Is], pend_acb = pacb[Is], pend_woff = pwoff[Is],
+            issue(std::integral_constant<int, Is>{}), __builtin_amdgcn_sched_barrier(0)), ...);
+        }(std::make_integer_sequence<int, D - 1>{});
+        pend_i0 = pi0[D - 1]; pend_i1 = pi1[D - 1]; pend_acb = pacb[D - 1]; pend_woff = pwoff[D - 1];
+      }
       if constexpr (TRACE) tr[2] = __builtin_amdgcn_s_memtime();
       const int n_main = n_items / D;
       const int rem = n_items - n_main * D;
