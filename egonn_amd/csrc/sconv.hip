@@ -449,6 +449,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_dma_kernel(const SconvArgs p) {
   const uint32_t tb0 = wl_addr + (uint32_t)((lane >> 3) * 4);
   const int dma_chunk = ((lane & 7) ^ (lane >> 3)) * 16;
   const int w_lane = lane * 16;
+  const int w_oob = (int)(0x80000000u | (uint32_t)(lane * 16));   // items past the end: out-of-range W loads (no traffic)
 
   const __amdgpu_buffer_rsrc_t a_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), (short)(CIN * 4), (int)(p.in_bytes / (CIN * 4)), 0x00020000);
@@ -541,29 +542,31 @@ __global__ __launch_bounds__(NW * 64) void sconv_dma_kernel(const SconvArgs p) {
       int gen_k = 0, gen_cb = 0;
       // the item whose loads are issued next: its two neighbour rows (written by the asm below), channel block, W offset
       int32_t pend_i0 = -1, pend_i1 = -1;
-      int pend_acb = 0, pend_woff = 0;
+      int pend_acb = 0, pend_woff = 0;                  // pend_woff < 0: item past the end
       // the item after that (generated: table address known, rows not read yet)
       uint32_t nxt_tb = tb0 + 512 * 4;
       int nxt_acb = 0, nxt_woff = 0;
       auto generate = [&]() {                            // scalar selects only; fills nxt_*
         const bool need = (gen_cb == 0);
         const bool take = need && (mk != 0);
-        const bool valid = !need || take;                // items past the end gather the all-absent row and W item 0: never used
+        const bool valid = !need || take;                // items past the end gather the all-absent row and out-of-range W: never used, no traffic
         gen_k = take ? __builtin_ctz(mk | 0x80000000u) : gen_k;
         mk = take ? (mk & (mk - 1)) : mk;
         const int cb = sub * NCBL + gen_cb;
         nxt_tb = tb0 + (uint32_t)((valid ? gen_k * 16 : 512) * 4);
         nxt_acb = cb * 128;
-        nxt_woff = valid ? (int)((uint32_t)(((gen_k * NCB + cb) * NS + ns)) * ITEM_BYTES) : 0;
+        nxt_woff = valid ? (int)((uint32_t)(((gen_k * NCB + cb) * NS + ns)) * ITEM_BYTES) : -1;
         gen_cb = (valid && gen_cb + 1 < NCBL) ? gen_cb + 1 : 0;
       };
 
       f32x4 wring[D][4];
       auto issue = [&](auto RS) {                        // loads of the pending item; then nxt -> pend (rows arrive by asm)
         constexpr int rs = decltype(RS)::value;
+        const int wv = pend_woff >= 0 ? w_lane : w_oob;  // (scalar condition: one v_cndmask)
+        const int ws = pend_woff >= 0 ? pend_woff : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          wring[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane + i * 1024, pend_woff, 0));
+          wring[rs][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wv + i * 1024, ws, 0));
         __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(ring + rs * SLOT), 16, pend_i0, dma_chunk, pend_acb, 0, 0);
         __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(ring + rs * SLOT + 1024), 16, pend_i1, dma_chunk, pend_acb, 0, 0);
       };
