@@ -233,15 +233,16 @@ def main():
     bound = "hbm" if t_hbm >= t_mfma else "mfma"
     traffic, traffic_src = None, None
     try:                                                   # HBM bytes per launch: PMC passes of this command (tools/measure.sh)
-        # "sconv<ci,co>" = every kernel of that channel plan (sconv_dma_kernel for big fp32 launches, sconv_rg_kernel /
-        # sconv_wg_kernel otherwise): launch-weighted mean over the kernels of the committed PMC summary
+        # dominant = "<kernel>_kernel<ci,co>" as tagged by the library (the kernel it dispatched for those launches):
+        # launch-weighted mean over the instantiations of that kernel and channel plan in the committed PMC summary
+        kname = dominant[:dominant.index("<")]
         ci_co = dominant[dominant.index("<") + 1:dominant.index(">")]
         want_bf16 = "true" if args.dtype == "bf16" else "false"
         tot, nl = 0.0, 0
         with open(os.path.join(REPO, "profiles", "traffic_latest.json")) as f:
             for k, v in json.load(f).items():
                 kk = k.replace(" ", "")
-                if not (kk.startswith("sconv_") and kk.split("<", 1)[1].startswith(ci_co + ",")):
+                if not (kk.startswith(kname + "<") and kk.split("<", 1)[1].startswith(ci_co + ",")):
                     continue
                 targs = kk.split("<", 1)[1].rstrip(">").split(",")
                 is_bf16 = targs[2] if not kk.startswith("sconv_dma") else "false"
@@ -252,8 +253,8 @@ def main():
         if nl:
             traffic = int(tot / nl)
             traffic_src = "profiles/traffic_latest.json (separate FETCH_SIZE / WRITE_SIZE rocprofv3 passes of this command, gfx950 " \
-                          "FETCH_SIZE x2 correction, launch-weighted over the kernels of this channel plan; read back from the " \
-                          "committed file, not measured in this run)"
+                          "FETCH_SIZE x2 correction, launch-weighted over the instantiations of this kernel and channel plan; read back " \
+                          "from the committed file, not measured in this run)"
     except Exception:
         pass
     roofline = {

@@ -14,6 +14,7 @@ bool sconv_rg_supported(int cin, int cout);
 int pack_rg_weights(const float* W, int K, int cin, int cout, int bf16, int flip, int transpose, void* out,
                     hipStream_t stream);
 extern unsigned long long* g_sconv_trace;
+const char* sconv_kernel_name(int cin, int cout, int bf16, int64_t groups_hint, int variant);
 int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wp, int cin,
                      int cout, int bf16, const float* scale, const float* shift, int relu, void* out, float* psum,
                      hipStream_t stream, int variant = 0);

@@ -747,7 +747,8 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     FALLOC(y, n * b.cin);
     char tag[64];
     {
-      snprintf(tag, sizeof(tag), "sconv<%d,%d>/L%d/k2s2", b.cin, b.cin, i);
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k2s2", sconv_kernel_name(b.cin, b.cin, bf16, L.rg8.cap_groups, c->conv_variant), b.cin,
+               b.cin, i);
       ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, (int)es);
       EGONN_TRY(sconv_map(c, 1, i, x[i - 1], nullptr, bf16 ? m->q_convs[i] : m->p_convs[i], b.cin, b.cin, bf16, m->bn[i].scale,
                           m->bn[i].shift, 1, y, nullptr, nullptr, 0, st));
@@ -755,7 +756,8 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     // ECABasicBlock (layers/eca_block.py:56-73)
     FALLOC(t1, n * b.cout);
     {
-      snprintf(tag, sizeof(tag), "sconv<%d,%d>/L%d/k3.conv1", b.cin, b.cout, i);
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv1", sconv_kernel_name(b.cin, b.cout, bf16, L.rg27.cap_groups, c->conv_variant),
+               b.cin, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cin, b.cout, (int)es);
       EGONN_TRY(sconv_map(c, 0, i, y, nullptr, bf16 ? m->q_c1[i] : m->p_c1[i], b.cin, b.cout, bf16, b.n1.scale, b.n1.shift, 1, t1,
                           nullptr, nullptr, 0, st));
@@ -763,7 +765,8 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     FALLOC(t2, n * b.cout);
     WALLOC(psum, (size_t)L.rg27.cap_groups * b.cout);
     {
-      snprintf(tag, sizeof(tag), "sconv<%d,%d>/L%d/k3.conv2", b.cout, b.cout, i);
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv2", sconv_kernel_name(b.cout, b.cout, bf16, L.rg27.cap_groups, c->conv_variant),
+               b.cout, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cout, b.cout, (int)es);
       EGONN_TRY(sconv_map(c, 0, i, t1, nullptr, bf16 ? m->q_c2[i] : m->p_c2[i], b.cout, b.cout, bf16, b.n2.scale, b.n2.shift, 0, t2,
                           psum, nullptr, 0, st));

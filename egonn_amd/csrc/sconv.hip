@@ -1158,6 +1158,18 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
   return EGONN_ERR_INVALID;
 }
 
+// Name of the kernel sconv_rg_forward dispatches for this launch (the profiler tags carry it, so that bench.py's dominant
+// kernel is the kernel rocprofv3 names).  Mirrors the choice in sconv_rg_forward / launch_rg.
+const char* sconv_kernel_name(int cin, int cout, int bf16, int64_t groups_hint, int variant) {
+  const int ns = cout / 32, ncb = cin / 32;
+  const int ksp = ncb >= 4 ? 4 : ncb;
+  const bool small = groups_hint * ns * ksp < 6144;
+  const bool coop = variant == 2 || (variant == 0 && bf16 && groups_hint >= 2048 && cin * cout >= 32 * 64);
+  if (coop) return "sconv_wg_kernel";
+  if (!bf16 && (variant == 5 || variant == 6 || variant == 9 || (variant == 0 && !small))) return "sconv_dma_kernel";
+  return "sconv_rg_kernel";
+}
+
 int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, int cin, int cout, int bf16,
               const float* scale, const float* shift, int relu, void* out, float* psum, float* scratch,
               size_t scratch_floats, hipStream_t stream) {
