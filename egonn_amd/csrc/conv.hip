@@ -226,6 +226,164 @@ __global__ __launch_bounds__(256) void conv0_k5_kernel(const float* __restrict__
   }
 }
 
+// Unit input features (what the reference always feeds): the A operand is an occupancy bit, i.e. exactly 0 or 1 — exactly
+// representable in bf16 — and an fp32 weight is exactly the sum of three bf16 numbers (24 = 3 x 8 significand bits).  So the
+// first layer runs on v_mfma_f32_16x16x32_bf16 with the kernel split hi + mid + lo: 2 x 4 x 3 = 24 MFMAs of 16 cycles per
+// 16-row tile instead of 64 MFMAs of 32 cycles, every product exact, fp32 accumulation — same accuracy as the fp32-MFMA
+// kernel (a different summation order), 5.3 x less matrix-pipe time.  Lane (row, g) supplies 8 CONSECUTIVE offsets per
+// MFMA (k = 32 j + 8 g + e): its 8 table entries are one 16-byte LDS read.  Everything else (per-block neighbourhood table,
+// software pipeline over the tiles, zero-mask slot for the padding offsets) is the fp32 kernel's.
+typedef short bf16x8_c0 __attribute__((ext_vector_type(8)));
+__device__ static inline uint32_t bf16_rne(float a) {
+  uint32_t u = __float_as_uint(a);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void conv0_k5_unit_kernel(const uint64_t* __restrict__ vkeys,     // level 0
+                                                             const int32_t* __restrict__ g0,         // level-2 block of row
+                                                             const uint64_t* __restrict__ t2m,       // [n2][27] masks
+                                                             const int32_t* __restrict__ counts, int32_t cap2, int32_t cap0,
+                                                             const float* __restrict__ W,            // [125][32]
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             int relu, void* __restrict__ out_v,
+                                                             const uint16_t* __restrict__ lut) {
+  constexpr int MS = 29;                                   // 27 neighbour blocks + the all-zero mask (slot 27)
+  constexpr int LUT_STRIDE = 136;                          // entries per row: 16-byte aligned rows, spread over the banks
+  __shared__ uint64_t s_m[4][16][MS];
+  __shared__ __attribute__((aligned(16))) uint16_t s_lut[64 * LUT_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int32_t nvox = min(__builtin_amdgcn_readfirstlane(counts[0]), cap0);
+  const int32_t n2 = min(__builtin_amdgcn_readfirstlane(counts[2]), cap2);
+  const int32_t ntiles = (nvox + 15) >> 4;
+  for (int e = tid; e < 64 * 128 / 2; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    reinterpret_cast<uint32_t*>(s_lut)[r * (LUT_STRIDE / 2) + c] = reinterpret_cast<const uint32_t*>(lut)[e];
+  }
+  if (tid < 64) s_m[tid >> 4][tid & 15][27] = 0ull;
+  // W fragments: wf[nt][j][split] = bf16x8 of W[k = 32 j + 8 g + e][nt * 16 + l15], split = hi / mid / lo
+  bf16x8_c0 wf[2][4][3];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t h[3][8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 32 * j + 8 * g4 + e;
+        float w = (k < 125) ? W[k * COUT0 + nt * 16 + l15] : 0.f;
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) {
+          const uint32_t b = bf16_rne(w);
+          h[sp][e] = b;
+          w -= __uint_as_float(b << 16);                   // exact: the residual has at most 16 (then 8) significant bits
+        }
+      }
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) {
+        const uint4 pk = make_uint4(h[sp][0] | (h[sp][1] << 16), h[sp][2] | (h[sp][3] << 16), h[sp][4] | (h[sp][5] << 16),
+                                    h[sp][6] | (h[sp][7] << 16));
+        wf[nt][j][sp] = __builtin_bit_cast(bf16x8_c0, pk);
+      }
+    }
+  f32x4 sc[2], sh[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    sc[nt] = scale ? *reinterpret_cast<const f32x4*>(scale + nt * 16 + 4 * g4) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    sh[nt] = scale ? *reinterpret_cast<const f32x4*>(shift + nt * 16 + 4 * g4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t m_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(t2m), 0, (int)((uint32_t)n2 * 27u * 8u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t g_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(g0), 0, (int)((uint32_t)nvox * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t k_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(vkeys), 0, (int)((uint32_t)nvox * 8u), 0x00020000);
+  const int tstep = gridDim.x * 4;
+  constexpr int NE = (16 * 27 + 63) / 64;
+  uint64_t pm[NE];
+  auto row_info = [&](int32_t tile, int32_t& g, uint32_t& lkbits) {
+    const uint32_t r = (uint32_t)tile * 16u + (uint32_t)l15;
+    g = __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (int)(r * 4u), 0, 0);
+    lkbits = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(k_rsrc, (int)(r * 8u), 0, 0) & 63u;
+  };
+  auto table_issue = [&](int32_t g_of_lane) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int idx = lane + 64 * e;
+      const int row = idx / 27, slot = idx - row * 27;
+      const int32_t g = __shfl(g_of_lane, row & 15, 64);
+      const uint32_t ent = (idx < 16 * 27) ? (uint32_t)g * 27u + (uint32_t)slot : 0x3FFFFFFFu;
+      const auto m2 = __builtin_amdgcn_raw_buffer_load_b64(m_rsrc, (int)(ent * 8u), 0, 0);
+      pm[e] = ((uint64_t)m2[1] << 32) | (uint64_t)m2[0];
+    }
+  };
+  int32_t tile = blockIdx.x * 4 + wave;
+  int32_t g_cur, g_nxt, g_nn;
+  uint32_t lk_cur, lk_nxt, lk_nn;
+  row_info(tile, g_cur, lk_cur);
+  row_info(tile + tstep, g_nxt, lk_nxt);
+  table_issue(g_cur);
+  for (; tile < ntiles; tile += tstep) {
+    const int32_t r0 = tile * 16;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int idx = lane + 64 * e;
+      if (idx < 16 * 27) {
+        const int row = idx / 27, slot = idx - row * 27;
+        s_m[wave][row][slot] = pm[e];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    table_issue(g_nxt);
+    row_info(tile + 2 * tstep, g_nn, lk_nn);
+    const uint16_t* lrow = s_lut + lk_cur * LUT_STRIDE + 8 * g4;
+    const char* mrow = reinterpret_cast<const char*>(&s_m[wave][l15][0]);
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint4 ent = *reinterpret_cast<const uint4*>(lrow + 32 * j);     // 8 entries: offsets 32 j + 8 g .. + 7
+      const uint32_t ew[4] = {ent.x, ent.y, ent.z, ent.w};
+      uint32_t pk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t e0 = ew[q] & 0xFFFFu, e1 = ew[q] >> 16;
+        const uint64_t m0 = *reinterpret_cast<const uint64_t*>(mrow + (e0 >> 6));
+        const uint64_t m1 = *reinterpret_cast<const uint64_t*>(mrow + (e1 >> 6));
+        const uint32_t h0 = (uint32_t)(m0 >> (e0 & 63)) & 1u, h1 = (uint32_t)(m1 >> (e1 & 63)) & 1u;
+        pk[q] = h0 * 0x3F80u + h1 * 0x3F800000u;             // bf16 1.0 in the low / high half
+      }
+      const bf16x8_c0 av = __builtin_bit_cast(bf16x8_c0, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][j][sp], av, acc[nt], 0, 0, 0);
+    }
+    const int32_t orow = r0 + l15;
+    if (orow < nvox) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 o = acc[nt] * sc[nt] + sh[nt];
+        if (relu) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) o[u] = fmaxf(o[u], 0.f);
+        }
+        if constexpr (OUT_BF16) {
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_v) + (int64_t)orow * COUT0 + nt * 16 + 4 * g4) =
+              make_uint2(bf16_rne(o[0]) | (bf16_rne(o[1]) << 16), bf16_rne(o[2]) | (bf16_rne(o[3]) << 16));
+        } else {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out_v) + (int64_t)orow * COUT0 + nt * 16 + 4 * g4) = o;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    g_cur = g_nxt; lk_cur = lk_nxt;
+    g_nxt = g_nn; lk_nxt = lk_nn;
+  }
+}
+
 // (local voxel position, kernel offset) -> (8 * adjacent-block slot) << 6 | bit in that block's mask
 static void conv0_lut_host(uint16_t* lut) {
   for (int lk = 0; lk < 64; ++lk)
@@ -267,8 +425,18 @@ int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, cons
 #define EGONN_CONV0_LAUNCH(U, OB)                                                                                      \
   hipLaunchKernelGGL((conv0_k5_kernel<U, OB>), dim3(grid), dim3(256), 0, stream, feat, V.keys, P.g0, P.t2m, P.t2s,       \
                      ctx->dev_counts, (int32_t)P.cap[2], (int32_t)P.cap[0], W, scale, shift, relu, out, ctx->conv0_lut)
-  if (feat) { if (out_bf16) EGONN_CONV0_LAUNCH(false, true); else EGONN_CONV0_LAUNCH(false, false); }
-  else      { if (out_bf16) EGONN_CONV0_LAUNCH(true, true); else EGONN_CONV0_LAUNCH(true, false); }      // unit features
+  if (feat) {
+    if (out_bf16) EGONN_CONV0_LAUNCH(false, true); else EGONN_CONV0_LAUNCH(false, false);
+  } else if (ctx->conv_variant == 3) {                     // cross-check path (egonn_debug_set_naive_conv): fp32-MFMA kernel
+    if (out_bf16) EGONN_CONV0_LAUNCH(true, true); else EGONN_CONV0_LAUNCH(true, false);
+  } else {                                                 // unit features: exact bf16 x 3 split of the kernel
+    if (out_bf16)
+      hipLaunchKernelGGL((conv0_k5_unit_kernel<true>), dim3(grid), dim3(256), 0, stream, V.keys, P.g0, P.t2m, ctx->dev_counts,
+                         (int32_t)P.cap[2], (int32_t)P.cap[0], W, scale, shift, relu, out, ctx->conv0_lut);
+    else
+      hipLaunchKernelGGL((conv0_k5_unit_kernel<false>), dim3(grid), dim3(256), 0, stream, V.keys, P.g0, P.t2m, ctx->dev_counts,
+                         (int32_t)P.cap[2], (int32_t)P.cap[0], W, scale, shift, relu, out, ctx->conv0_lut);
+  }
 #undef EGONN_CONV0_LAUNCH
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
