@@ -163,15 +163,23 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const void* __restrict__
     dl_frags[i] = v;
   }
   __syncthreads();
+  // bias / folded-BN vectors of the epilogue -> LDS (behind the fragments): they were three dependent L1 round trips per
+  // 16 output columns of every tile
+  float* const s_vec = reinterpret_cast<float*>(dl_frags + (int64_t)NT * KS * 64);      // [3][cout]: bias, scale, shift
+  for (int i = tid; i < cout; i += 256) {
+    s_vec[i] = bias ? bias[i] : 0.f;
+    s_vec[cout + i] = scale ? scale[i] : 1.f;
+    s_vec[2 * cout + i] = scale ? shift[i] : 0.f;
+  }
+  __syncthreads();
   const int64_t ntiles = (n + 15) >> 4;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  const int64_t tstep = (int64_t)gridDim.x * 4;
+  auto load_rows = [&](int64_t tile, f32x4 (&a)[KS]) {      // the 16 input rows of a tile (zeros past the end)
     const int64_t row = tile * 16 + l15;
-    const bool ok = row < n;
-    f32x4 a[KS];
 #pragma unroll
     for (int t = 0; t < KS; ++t) {
       a[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (ok) {
+      if (tile < ntiles && row < n) {
         if constexpr (IN_BF16) {
           const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(in_v) + row * CIN + 16 * t + 4 * g4);
           a[t] = (f32x4){bf2f(h.x & 0xFFFFu), bf2f(h.x >> 16), bf2f(h.y & 0xFFFFu), bf2f(h.y >> 16)};
@@ -180,6 +188,14 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const void* __restrict__
         }
       }
     }
+  };
+  f32x4 a[KS], an[KS];
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  load_rows(tile, a);
+  for (; tile < ntiles; tile += tstep) {
+    const int64_t row = tile * 16 + l15;
+    const bool ok = row < n;
+    load_rows(tile + tstep, an);                             // next tile's rows in flight while this one is computed
     for (int nt = 0; nt < NT; ++nt) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const f32x4* fr = dl_frags + (int64_t)nt * KS * 64 + lane;
@@ -191,9 +207,8 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const void* __restrict__
       }
       if (ok) {
         const int c0 = 16 * nt + 4 * g4;
-        f32x4 v = acc;
-        if (bias) v += *reinterpret_cast<const f32x4*>(bias + c0);
-        if (scale) v = v * *reinterpret_cast<const f32x4*>(scale + c0) + *reinterpret_cast<const f32x4*>(shift + c0);
+        f32x4 v = acc + *reinterpret_cast<const f32x4*>(s_vec + c0);
+        v = v * *reinterpret_cast<const f32x4*>(s_vec + cout + c0) + *reinterpret_cast<const f32x4*>(s_vec + 2 * cout + c0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = apply_act(v[u], act);
         if (residual_v) {
@@ -212,6 +227,8 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const void* __restrict__
         }
       }
     }
+#pragma unroll
+    for (int t = 0; t < KS; ++t) a[t] = an[t];
   }
 }
 
@@ -245,7 +262,7 @@ int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const floa
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
       attr_done = true;                                                                                               \
     }                                                                                                                 \
-    hipLaunchKernelGGL((dense_lds_kernel<WOI, CI, INB>), dim3(g1), dim3(256), frag_bytes, stream, in, n, W, cout, bias, scale, \
+    hipLaunchKernelGGL((dense_lds_kernel<WOI, CI, INB>), dim3(g1), dim3(256), frag_bytes + 3 * (size_t)cout * sizeof(float), stream, in, n, W, cout, bias, scale, \
                        shift, act, residual, out, io, n_dev);                                                         \
   }
 #define EGONN_DENSE_LDS_CASE(CI)                                                                                      \
