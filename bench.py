@@ -40,8 +40,8 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense MFMA peaks (MI355X_M
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--batch", type=int, default=16, help="scans per GPU per step (BASELINE configs[1]: 16, configs[2]: 64)")
     p.add_argument("--points", type=int, default=50_000)
     p.add_argument("--voxel", type=float, default=0.1)
