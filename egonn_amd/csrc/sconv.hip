@@ -1098,6 +1098,9 @@ static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
   }
   // bf16 maps, big launches: two groups per wave share the W fragments (the items are load-bound: W is two thirds of the
   // bytes an item moves) — 9-12 % on the 32-channel layers at batch 64; fp32 items are MFMA-bound and gain nothing
+  if constexpr (BF16) {      // very large launches (batch 64, levels 1-2): four groups per wave, another 4 %
+    if (sel == 0 && groups_hint * NS * KSP >= 32768) return launch_rg_d<CIN, COUT, BF16, KSP, 3, 4>(a, groups_hint, stream);
+  }
   if ((sel == 2 || (BF16 && sel == 0)) && !small) return launch_rg_d<CIN, COUT, BF16, KSP, BF16 ? 4 : 3, 2>(a, groups_hint, stream);
   if (small) return launch_rg_d<CIN, COUT, BF16, KSP, 6, 1>(a, groups_hint, stream);
   return launch_rg_d<CIN, COUT, BF16, KSP, BF16 ? 4 : 3, 1>(a, groups_hint, stream);
