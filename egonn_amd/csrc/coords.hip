@@ -69,7 +69,7 @@ ProfScope::ProfScope(Ctx* c, hipStream_t s, const char* name, int kind, int leve
   r.kind = kind; r.level = level; r.K = K; r.cin = cin; r.cout = cout; r.es = es;
   r.e0 = c->prof.get();
   r.e1 = c->prof.get();
-  exact = c->prof.mode == 2 && (kind == PK_K3 || kind == PK_K2S2);
+  exact = c->prof.mode == 2 && (kind == PK_K3 || kind == PK_K2S2 || kind == PK_TCONV);
   if (exact) {
     prof_kernel_events()[0] = r.e0;
     prof_kernel_events()[1] = r.e1;

@@ -728,8 +728,14 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     EGONN_TRY(dense_forward_ex(x[4], bf16, n4, 128, m->l1x1[4], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0, l4,
                                bf16, st, cnt + 4));
     FALLOC(u3, n3 * LOCAL_CH);
-    EGONN_TRY(sconv_map(c, 2, 3, l4, nullptr, bf16 ? m->q_lt[4] : m->p_lt[4], LOCAL_CH, LOCAL_CH, bf16, nullptr, nullptr, 0, u3,
-                        nullptr, nullptr, 0, st));
+    {
+      char tag[64];
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L3/tconv", sconv_kernel_name(LOCAL_CH, LOCAL_CH, bf16, P.lv[3].rgT.cap_groups, c->conv_variant),
+               LOCAL_CH, LOCAL_CH);
+      ProfScope ps(c, st, tag, PK_TCONV, 3, 8, LOCAL_CH, LOCAL_CH, (int)es);
+      EGONN_TRY(sconv_map(c, 2, 3, l4, nullptr, bf16 ? m->q_lt[4] : m->p_lt[4], LOCAL_CH, LOCAL_CH, bf16, nullptr, nullptr, 0, u3,
+                          nullptr, nullptr, 0, st));
+    }
     WALLOC(l3, n3 * LOCAL_CH);
     EGONN_TRY(dense_forward_ex(x[3], bf16, n3, 64, m->l1x1[3], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u3, bf16, l3, 0, st, cnt + 3));
     EGONN_REQUIRE(m->ldec.cin == 64 && m->ldec.mid == 96 && m->ldec.cout == 128 && m->kp.mid == 32 && m->sg.mid == 32,
@@ -797,14 +803,26 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     EGONN_TRY(dense_forward_ex(x[7], bf16, P.cap[7], 128, m->g1x1[7], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0,
                                g7, bf16, st, cnt + 7));
     FALLOC(u6, P.cap[6] * GLOBAL_CH);
-    EGONN_TRY(sconv_map(c, 2, 6, g7, nullptr, bf16 ? m->q_gt[7] : m->p_gt[7], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u6,
-                        nullptr, nullptr, 0, st));
+    {
+      char tag[64];
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L6/tconv", sconv_kernel_name(GLOBAL_CH, GLOBAL_CH, bf16, P.lv[6].rgT.cap_groups, c->conv_variant),
+               GLOBAL_CH, GLOBAL_CH);
+      ProfScope ps(c, st, tag, PK_TCONV, 6, 8, GLOBAL_CH, GLOBAL_CH, (int)es);
+      EGONN_TRY(sconv_map(c, 2, 6, g7, nullptr, bf16 ? m->q_gt[7] : m->p_gt[7], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u6,
+                          nullptr, nullptr, 0, st));
+    }
     FALLOC(g6, P.cap[6] * GLOBAL_CH);
     EGONN_TRY(dense_forward_ex(x[6], bf16, P.cap[6], 128, m->g1x1[6], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u6, bf16,
                                g6, bf16, st, cnt + 6));
     FALLOC(u5, P.cap[5] * GLOBAL_CH);
-    EGONN_TRY(sconv_map(c, 2, 5, g6, nullptr, bf16 ? m->q_gt[6] : m->p_gt[6], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u5,
-                        nullptr, nullptr, 0, st));
+    {
+      char tag[64];
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L5/tconv", sconv_kernel_name(GLOBAL_CH, GLOBAL_CH, bf16, P.lv[5].rgT.cap_groups, c->conv_variant),
+               GLOBAL_CH, GLOBAL_CH);
+      ProfScope ps(c, st, tag, PK_TCONV, 5, 8, GLOBAL_CH, GLOBAL_CH, (int)es);
+      EGONN_TRY(sconv_map(c, 2, 5, g6, nullptr, bf16 ? m->q_gt[6] : m->p_gt[6], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u5,
+                          nullptr, nullptr, 0, st));
+    }
     WALLOC(g5, P.cap[5] * GLOBAL_CH);
     EGONN_TRY(dense_forward_ex(x[5], bf16, P.cap[5], 128, m->g1x1[5], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u5, bf16,
                                g5, 0, st, cnt + 5));
