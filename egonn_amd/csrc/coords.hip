@@ -422,9 +422,18 @@ __device__ static inline int32_t lookup_local(const uint64_t* nbm, const int32_t
 // Row adjacency by direct search: adj[i][s] = row of the same-level voxel at offset s (27 slots, x fastest), -1 =
 // absent.  Used for the two top (virtual) levels only, where N is tiny; every level below derives its table
 // from the table two levels up (nbr27_kernel), so no level with many rows ever binary-searches.
-__global__ void adj27_search_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ counts, int level,
-                                    int32_t cap, int cbL, int32_t* __restrict__ adj) {
-  const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+// (the two searched levels are independent: one launch covers both; threads past the first level's cap0 * 27 slots
+//  belong to the second)
+__global__ void adj27_search_kernel(const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
+                                    const int32_t* __restrict__ counts, int level0, int level1, int32_t cap0, int32_t cap1,
+                                    int cbL0, int cbL1, int32_t* __restrict__ adj0, int32_t* __restrict__ adj1) {
+  int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool second = t >= cap0 * 27;
+  if (second) t -= cap0 * 27;
+  const uint64_t* __restrict__ keys = second ? keys1 : keys0;
+  int32_t* __restrict__ adj = second ? adj1 : adj0;
+  const int level = second ? level1 : level0, cbL = second ? cbL1 : cbL0;
+  const int32_t cap = second ? cap1 : cap0;
   const int32_t n = level_rows(counts, level, cap);
   if (t >= n * 27) return;
   const int32_t i = t / 27, sl = t - i * 27;
@@ -444,16 +453,37 @@ __global__ void adj27_search_kernel(const uint64_t* __restrict__ keys, const int
 // k=3 neighbour table of level l from the adjacency of its 4x4x4 blocks (= the k=3 table of level l+2).
 // One wave per block: 27 lanes fetch (mask, first row) of the adjacent blocks into LDS, then every
 // (voxel, offset) pair is an LDS mask test + popcount.
-__global__ __launch_bounds__(256) void nbr27_kernel(const uint64_t* __restrict__ vkeys,      // level l
-                                                     const int32_t* __restrict__ badj,        // [nblocks][27] level l+2
-                                                     const uint64_t* __restrict__ bmask,
-                                                     const int32_t* __restrict__ bstart,
-                                                     const int32_t* __restrict__ counts, int level, int32_t cap_blocks,
-                                                     int32_t cap_vox, int32_t* __restrict__ nbr) {
+// Two levels per launch: level l needs the table of level l+2 only, so (l, l-1) are independent and share a launch
+// (seven ~5 us launches per step became four).
+struct Nbr27Job {
+  const uint64_t* vkeys;       // level l
+  const int32_t* badj;         // [nblocks][27] level l+2
+  const uint64_t* bmask;
+  const int32_t* bstart;
+  int32_t* nbr;
+  int32_t level, cap_blocks, cap_vox;
+};
+struct Nbr27Pair {
+  Nbr27Job job[2];
+  const int32_t* counts;
+  uint32_t split;              // workgroups of job[0]
+};
+__global__ __launch_bounds__(256) void nbr27_kernel(const Nbr27Pair a) {
+  const bool second = blockIdx.x >= a.split;
+  const Nbr27Job& J = a.job[second ? 1 : 0];
+  const uint64_t* __restrict__ vkeys = J.vkeys;
+  const int32_t* __restrict__ badj = J.badj;
+  const uint64_t* __restrict__ bmask = J.bmask;
+  const int32_t* __restrict__ bstart = J.bstart;
+  const int32_t* __restrict__ counts = a.counts;
+  int32_t* __restrict__ nbr = J.nbr;
+  const int level = J.level;
+  const int32_t cap_blocks = J.cap_blocks, cap_vox = J.cap_vox;
+  const uint32_t bid = second ? blockIdx.x - a.split : blockIdx.x;
   __shared__ uint64_t s_m[4][27];
   __shared__ int32_t s_s[4][27];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int32_t j = blockIdx.x * 4 + wave;
+  const int32_t j = (int32_t)bid * 4 + wave;
   const int32_t nblocks = level_rows(counts, level + 2, cap_blocks), nvox = level_rows(counts, level, cap_vox);
   if (j >= nblocks) return;
   // Two memory round trips per block instead of four: (adjacency row, first/last voxel row of the block) are requested
@@ -769,6 +799,17 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
 
   // ---- kernel maps, top-down: the two virtual levels by search (tiny), every other level from the k=3
   //      table of the level two above (which is the adjacency of its 4x4x4 blocks)
+  Nbr27Pair pair;
+  int npair = 0;
+  pair.counts = counts;
+  pair.split = 0;
+  auto flush = [&]() {
+    if (npair == 0) return;
+    if (npair == 1) pair.job[1] = pair.job[0];
+    const unsigned g0 = pair.split, g1 = npair == 2 ? (unsigned)cdiv(pair.job[1].cap_blocks, 4) : 0u;
+    hipLaunchKernelGGL(nbr27_kernel, dim3(g0 + g1), dim3(256), 0, stream, pair);
+    npair = 0;
+  };
   for (int l = NL - 1; l >= 1; --l) {
     Level& V = P.lv[l];
     const int32_t nv = (int32_t)P.cap[l];
@@ -776,14 +817,24 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
     EGONN_REQUIRE(V.nbr27, EGONN_ERR_STATE, "plan arena too small");
     if (nv == 0) continue;
     if (l + 2 >= NL) {
-      hipLaunchKernelGGL(adj27_search_kernel, dim3((unsigned)cdiv((int64_t)nv * 27, 256)), dim3(256), 0, stream, V.keys,
-                         counts, l, nv, cb - l, V.nbr27);
+      if (l == NL - 1) continue;                         // searched together with level NL - 2 (next iteration)
+      Level& V1 = P.lv[NL - 1];
+      const int32_t nv1 = V1.nbr27 ? (int32_t)P.cap[NL - 1] : 0;
+      hipLaunchKernelGGL(adj27_search_kernel, dim3((unsigned)cdiv(((int64_t)nv + nv1) * 27, 256)), dim3(256), 0, stream, V.keys,
+                         V1.keys, counts, l, NL - 1, nv, nv1, cb - l, cb - (NL - 1), V.nbr27, V1.nbr27);
     } else {
       const Level& Bk = P.lv[l + 2];
-      hipLaunchKernelGGL(nbr27_kernel, dim3((unsigned)cdiv(P.cap[l + 2], 4)), dim3(256), 0, stream, V.keys, Bk.nbr27, Bk.mask,
-                         Bk.bstart, counts, l, (int32_t)P.cap[l + 2], nv, V.nbr27);
+      // levels (NL-3, NL-4), (NL-5, NL-6), ... pair up: both members of a pair read tables finished by earlier launches
+      if (npair == 1 && pair.job[0].level != l + 1) flush();
+      Nbr27Job& J = pair.job[npair];
+      J.vkeys = V.keys; J.badj = Bk.nbr27; J.bmask = Bk.mask; J.bstart = Bk.bstart; J.nbr = V.nbr27;
+      J.level = l; J.cap_blocks = (int32_t)P.cap[l + 2]; J.cap_vox = nv;
+      if (npair == 0) pair.split = (unsigned)cdiv(P.cap[l + 2], 4);
+      ++npair;
+      if (npair == 2) flush();
     }
   }
+  flush();
   {   // first-layer (k=5) helpers
     const int32_t n0 = (int32_t)P.cap[0], n2 = (int32_t)P.cap[2];
     P.g0 = A.alloc<int32_t>(n0);

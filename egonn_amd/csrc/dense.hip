@@ -129,6 +129,114 @@ __global__ __launch_bounds__(256) void dense_kernel(const void* __restrict__ in_
   }
 }
 
+// dense_small_kernel: the same tile arithmetic for launches too small to hide latency (n < 32768 rows) — see its first comment.
+template <int W_OUT_IN, int CIN, bool IN_BF16>
+__global__ __launch_bounds__(256) void dense_small_kernel(const void* __restrict__ in_v, int64_t n,
+                                                    const float* __restrict__ W, int cout,
+                                                    const float* __restrict__ bias, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, int act,
+                                                    const void* __restrict__ residual_v, void* __restrict__ out_v, int io,
+                                                    const int32_t* __restrict__ n_dev) {
+  // ONE memory round trip per wave: the live row count, the 16 input rows, the weights of all four 16-column tiles,
+  // the epilogue vectors and the residual values are all requested before anything is waited for (the first version
+  // walked a chain of five dependent round trips — count, rows, weights of pass 0, its epilogue vectors, weights of
+  // pass 1 ... — and took 12-14 us on launches of a dozen workgroups, eight times per step: profiles/r02x_timeline.txt).
+  // `n` is the capacity of the buffers, so rows between the live count and `n` may be read (never stored).
+  const int64_t ncap = n;
+  int32_t nlive32 = 0x7FFFFFFF;
+  if (n_dev) nlive32 = *n_dev;
+  const float* in = reinterpret_cast<const float*>(in_v);
+  const float* residual = reinterpret_cast<const float*>(residual_v);
+  float* out = reinterpret_cast<float*>(out_v);
+  constexpr int KS = CIN / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int64_t row_base = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  if (row_base >= ncap) return;
+  const int64_t row = row_base + l15;
+  float4 a[KS];
+#pragma unroll
+  for (int t = 0; t < KS; ++t) {
+    a[t] = make_float4(0, 0, 0, 0);
+    if (row < ncap) {
+      if constexpr (IN_BF16) {
+        const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(in_v) + row * CIN + 16 * t + 4 * g4);
+        a[t] = make_float4(bf2f(h.x & 0xFFFFu), bf2f(h.x >> 16), bf2f(h.y & 0xFFFFu), bf2f(h.y >> 16));
+      } else {
+        a[t] = *reinterpret_cast<const float4*>(in + row * CIN + 16 * t + 4 * g4);
+      }
+    }
+  }
+  const int ncol0 = blockIdx.y * 64;
+  float4 b[4][KS];
+  float bi[4], sc[4], sh[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int col = ncol0 + nt * 16 + l15;
+    const bool okc = col < cout;
+    bi[nt] = (bias && okc) ? bias[col] : 0.f;
+    sc[nt] = (scale && okc) ? scale[col] : 1.f;
+    sh[nt] = (scale && okc) ? shift[col] : 0.f;
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      float4 v = make_float4(0, 0, 0, 0);
+      if (okc) {
+        if (W_OUT_IN) {
+          v = *reinterpret_cast<const float4*>(W + (int64_t)col * CIN + 16 * t + 4 * g4);
+        } else {
+          const float* wp = W + (int64_t)(16 * t + 4 * g4) * cout + col;
+          v.x = wp[0];
+          v.y = wp[cout];
+          v.z = wp[2 * (int64_t)cout];
+          v.w = wp[3 * (int64_t)cout];
+        }
+      }
+      b[nt][t] = v;
+    }
+  }
+  float res[4][4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int col = ncol0 + nt * 16 + l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t orow = row_base + 4 * g4 + r;
+      res[nt][r] = 0.f;
+      if (residual_v && col < cout && orow < ncap)
+        res[nt][r] = (io & 1) ? bf2f(reinterpret_cast<const uint16_t*>(residual_v)[orow * cout + col]) : residual[orow * cout + col];
+    }
+  }
+  n = min((int64_t)nlive32, ncap);
+  if (row_base >= n) return;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int col = ncol0 + nt * 16 + l15;
+    if (ncol0 + nt * 16 >= cout) break;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b[nt][t].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, b[nt][t].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, b[nt][t].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b[nt][t].w, acc, 0, 0, 0);
+    }
+    if (col < cout) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t orow = row_base + 4 * g4 + r;
+        if (orow < n) {
+          float v = acc[r] + bi[nt];
+          if (scale) v = v * sc[nt] + sh[nt];
+          v = apply_act(v, act);
+          if (residual_v) v += res[nt][r];
+          if (io & 2) reinterpret_cast<uint16_t*>(out_v)[orow * cout + col] = (uint16_t)f2bf_rn(v);
+          else out[orow * cout + col] = v;
+        }
+      }
+    }
+  }
+}
+
 // The same product with the weights staged ONCE per workgroup into LDS as MFMA fragments
 //   frag[(nt * CIN/16 + t) * 64 + lane] = W(col = 16 nt + (lane & 15), ci = 16 t + 4 (lane >> 4) .. +3)
 // (whatever the caller's layout), workgroups persistent over the row tiles, operands swapped (D^T = W^T A^T) so that lane
@@ -282,8 +390,12 @@ int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const floa
 #undef EGONN_DENSE_LDS_LAUNCH
   }
 #define EGONN_DENSE_LAUNCH(WOI, CI, INB)                                                                              \
-  hipLaunchKernelGGL((dense_kernel<WOI, CI, INB>), grid, dim3(256), 0, stream, in, n, W, cout, bias, scale, shift, act, \
-                     residual, out, io, n_dev)
+  if (n < 32768)                                                                                                      \
+    hipLaunchKernelGGL((dense_small_kernel<WOI, CI, INB>), grid, dim3(256), 0, stream, in, n, W, cout, bias, scale, shift, act, \
+                       residual, out, io, n_dev);                                                                     \
+  else                                                                                                                \
+    hipLaunchKernelGGL((dense_kernel<WOI, CI, INB>), grid, dim3(256), 0, stream, in, n, W, cout, bias, scale, shift, act, \
+                       residual, out, io, n_dev)
 #define EGONN_DENSE_CASE(CI)                                                                                       \
   if (cin == CI) {                                                                                                 \
     if (w_out_in) { if (in_bf16) EGONN_DENSE_LAUNCH(1, CI, true); else EGONN_DENSE_LAUNCH(1, CI, false); }         \
@@ -509,19 +621,29 @@ __global__ __launch_bounds__(1024) void eca_gate_groups_kernel(const float* __re
   const int g0 = meta[1 + b], g1 = meta[2 + b];
   const int32_t cntr = boff[b + 1] - boff[b];
   const int nsl = 1024 / c, sl = tid / c, ch = tid - sl * c;    // c <= 256, power of two: 4..32 slices of groups
-  // fixed order per slice; the loads of 4 groups are in flight together
+  // fixed order per slice; the loads of 8 groups are in flight together, and the sums are read whether or not the group
+  // is flagged (the buffer covers every group; an unflagged group's value is dropped by the select): with the load behind
+  // the flag every group cost two dependent round trips, 16 us for the 800 groups per scan of level 1.
   float acc = 0.f;
   {
+    constexpr int U = 8;
     int g = g0 + sl;
-    for (; g + 3 * nsl < g1; g += 4 * nsl) {
-      float v[4];
+    for (; g + (U - 1) * nsl < g1; g += U * nsl) {
+      float v[U];
+      uint32_t m[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = (gmask[g + u * nsl] >> 31) ? psum[(int64_t)(g + u * nsl) * c + ch] : 0.f;
+      for (int u = 0; u < U; ++u) {
+        m[u] = gmask[g + u * nsl];
+        v[u] = psum[(int64_t)(g + u * nsl) * c + ch];
+      }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc += v[u];
+      for (int u = 0; u < U; ++u) acc += (m[u] >> 31) ? v[u] : 0.f;
     }
-    for (; g < g1; g += nsl)
-      if (gmask[g] >> 31) acc += psum[(int64_t)g * c + ch];
+    for (; g < g1; g += nsl) {
+      const uint32_t m = gmask[g];
+      const float v = psum[(int64_t)g * c + ch];
+      acc += (m >> 31) ? v : 0.f;
+    }
   }
   red[tid] = acc;
   __syncthreads();
@@ -870,31 +992,118 @@ int local_heads_forward(const float* x, int64_t n, const int32_t* n_dev, const f
 // MinkLocGLEvaluator.get_keypoints_idxes (eval/evaluate.py:352-361: torch.topk(sigma, n_k, largest=False) per scan) +
 // the gather of the selected keypoints / descriptors, ONE launch: workgroup = scan.  Keys = (monotone sigma bits << 32 |
 // row inside the scan) are unique, so the order is total (ties by Z-order row, as the stable radix sort it replaces).
-// The scan's rows stream through an LDS bitonic sorter S keys at a time together with the best k so far.
+// Radix SELECT, then a sort of the k winners only: 11-bit digits of the 64-bit key from the top, one LDS histogram per
+// digit over the rows that still match the prefix, until the tie group is taken whole (two or three passes on real
+// saliencies, six at most: the keys are unique) -> a threshold key; the k keys at or below it are compacted into LDS and
+// ordered by counting (k <= 512) or by a bitonic network.  (The r01/r02 kernel sorted the whole scan through a 2048-key
+// bitonic network, 66 barrier stages per 1920 rows: 49 us at 23 k rows per scan.)
 __device__ static inline uint32_t sigma_bits(float v) {
   const uint32_t u = __float_as_uint(v);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotone float -> uint
 }
-__global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restrict__ sigma, const int32_t* __restrict__ boff,
-                                                           int k, int S, const float* __restrict__ kp,
-                                                           const float* __restrict__ desc, int dc,
-                                                           int32_t* __restrict__ sel_rows, int32_t* __restrict__ sel_count,
-                                                           float* __restrict__ out_kp, float* __restrict__ out_desc) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];   // [S]
-  const int b = blockIdx.x, tid = threadIdx.x;
+constexpr int TK_THREADS = 1024, TK_BINS = 2048, TK_CACHE = 8;
+__global__ __launch_bounds__(TK_THREADS) void select_topk_kernel(const float* __restrict__ sigma, const int32_t* __restrict__ boff,
+                                                                 int k, int S, const float* __restrict__ kp,
+                                                                 const float* __restrict__ desc, int dc,
+                                                                 int32_t* __restrict__ sel_rows, int32_t* __restrict__ sel_count,
+                                                                 float* __restrict__ out_kp, float* __restrict__ out_desc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];   // [S] winners, S = pow2 >= k; + [k] when ranked
+  __shared__ uint32_t s_hist[TK_BINS];
+  __shared__ uint32_t s_wave[TK_THREADS / 64];
+  __shared__ uint32_t s_pick[3];                         // digit, rows below it, rows in it
+  __shared__ uint32_t s_n;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t r0 = boff[b], nb = boff[b + 1] - r0;
   const int kk = min(k, nb);
-  const int fresh = S - k;                               // new rows per round (k <= S / 2)
-  int have = 0;                                          // best-so-far keys parked in skeys[0 .. have)
-  for (int base = 0; base < nb || base == 0; base += fresh) {
-    for (int i = tid; i < S - have; i += 1024) {
-      const int r = base + i;
-      skeys[have + i] = (i < fresh && r < nb) ? (((unsigned long long)sigma_bits(sigma[r0 + r]) << 32) | (unsigned)r) : ~0ull;
+  // the scan's keys: the first TK_CACHE * 1024 rows stay in registers, longer scans re-read the tail
+  uint32_t sb[TK_CACHE];
+#pragma unroll
+  for (int i = 0; i < TK_CACHE; ++i) {
+    const int r = i * TK_THREADS + tid;
+    sb[i] = r < nb ? sigma_bits(sigma[r0 + r]) : 0xFFFFFFFFu;
+  }
+  auto key_of = [&](uint32_t bits, int r) { return ((unsigned long long)bits << 32) | (unsigned)r; };
+  unsigned long long T = 0;                              // threshold: the kk smallest keys are the keys <= T
+  if (kk > 0) {
+    unsigned long long prefix = 0;
+    uint32_t need = (uint32_t)kk;
+    const int shifts[6] = {53, 42, 31, 20, 9, 0};
+#pragma unroll 1
+    for (int p = 0; p < 6; ++p) {
+      const int sh = shifts[p], bits = p == 5 ? 9 : 11;
+      const uint32_t dmask = (1u << bits) - 1;
+      for (int i = tid; i < TK_BINS; i += TK_THREADS) s_hist[i] = 0;
+      __syncthreads();
+      auto count = [&](uint32_t sbits, int r) {
+        const unsigned long long key = key_of(sbits, r);
+        if (p == 0 || (key >> (sh + bits)) == prefix) atomicAdd(&s_hist[(uint32_t)(key >> sh) & dmask], 1u);
+      };
+#pragma unroll
+      for (int i = 0; i < TK_CACHE; ++i) {
+        const int r = i * TK_THREADS + tid;
+        if (r < nb) count(sb[i], r);
+      }
+      for (int r = TK_CACHE * TK_THREADS + tid; r < nb; r += TK_THREADS) count(sigma_bits(sigma[r0 + r]), r);
+      __syncthreads();
+      // digit that holds the need-th smallest key: exclusive scan of the histogram, two bins per thread
+      const uint32_t h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
+      uint32_t inc = h0 + h1;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+      }
+      if (lane == 63) s_wave[wave] = inc;
+      __syncthreads();
+      uint32_t ex = inc - (h0 + h1);
+      for (int w = 0; w < wave; ++w) ex += s_wave[w];
+      if (ex < need && need <= ex + h0) {
+        s_pick[0] = 2 * tid; s_pick[1] = ex; s_pick[2] = h0;
+      } else if (ex + h0 < need && need <= ex + h0 + h1) {
+        s_pick[0] = 2 * tid + 1; s_pick[1] = ex + h0; s_pick[2] = h1;
+      }
+      __syncthreads();
+      const uint32_t digit = s_pick[0], below = s_pick[1], inbin = s_pick[2];
+      prefix = (prefix << bits) | digit;
+      need -= below;
+      if (inbin == need || sh == 0) {                    // the tie group is taken whole
+        T = sh ? ((prefix << sh) | ((1ull << sh) - 1)) : prefix;
+        break;
+      }
+    }
+  }
+  // ---- the kk winners -> LDS (any order), then ordered
+  if (tid == 0) s_n = 0;
+  for (int i = tid; i < S; i += TK_THREADS) skeys[i] = ~0ull;
+  __syncthreads();
+  if (kk > 0) {
+    auto take = [&](uint32_t sbits, int r) {
+      const unsigned long long key = key_of(sbits, r);
+      if (key <= T) skeys[atomicAdd(&s_n, 1u)] = key;
+    };
+#pragma unroll
+    for (int i = 0; i < TK_CACHE; ++i) {
+      const int r = i * TK_THREADS + tid;
+      if (r < nb) take(sb[i], r);
+    }
+    for (int r = TK_CACHE * TK_THREADS + tid; r < nb; r += TK_THREADS) take(sigma_bits(sigma[r0 + r]), r);
+  }
+  __syncthreads();
+  if (k <= 512) {                                        // order by counting: every key reads all the others (broadcasts)
+    unsigned long long* sorted = skeys + S;
+    if (tid < kk) {
+      const unsigned long long mine = skeys[tid];
+      int rank = 0;
+      for (int j = 0; j < kk; ++j) rank += skeys[j] < mine ? 1 : 0;
+      sorted[rank] = mine;
     }
     __syncthreads();
+    if (tid < kk) skeys[tid] = sorted[tid];
+    __syncthreads();
+  } else {
     for (int k2 = 2; k2 <= S; k2 <<= 1)
       for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-        for (int e = tid; e < S / 2; e += 1024) {
+        for (int e = tid; e < S / 2; e += TK_THREADS) {
           const int i = ((e & ~(j2 - 1)) << 1) | (e & (j2 - 1));
           const int q = i | j2;
           const bool up = (i & k2) == 0;
@@ -903,18 +1112,26 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restri
         }
         __syncthreads();
       }
-    have = k;                                            // the first k sorted keys stay for the next round
-    if (nb == 0) break;
   }
   // ---- selected rows + gathered keypoints / descriptors (padded with -1 / zeros)
-  for (int i = tid; i < k; i += 1024) sel_rows[(int64_t)b * k + i] = (i < kk) ? r0 + (int32_t)(skeys[i] & 0xFFFFFFFFu) : -1;
+  for (int i = tid; i < k; i += TK_THREADS) sel_rows[(int64_t)b * k + i] = (i < kk) ? r0 + (int32_t)(skeys[i] & 0xFFFFFFFFu) : -1;
   if (tid == 0) sel_count[b] = kk;
   if (out_desc) {
-    for (int64_t t = tid; t < (int64_t)k * dc; t += 1024) {
-      const int i = (int)(t / dc), c = (int)(t - (int64_t)i * dc);
-      out_desc[((int64_t)b * k + i) * dc + c] = (i < kk) ? desc[(int64_t)(r0 + (int32_t)(skeys[i] & 0xFFFFFFFFu)) * dc + c] : 0.f;
+    if ((dc & 3) == 0) {                                 // 16-byte pieces of the descriptor rows
+      const int q4 = dc >> 2;
+      for (int t = tid; t < k * q4; t += TK_THREADS) {
+        const int i = t / q4, c = t - i * q4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < kk) v = *reinterpret_cast<const float4*>(desc + (int64_t)(r0 + (int32_t)(skeys[i] & 0xFFFFFFFFu)) * dc + 4 * c);
+        *reinterpret_cast<float4*>(out_desc + ((int64_t)b * k + i) * dc + 4 * c) = v;
+      }
+    } else {
+      for (int64_t t = tid; t < (int64_t)k * dc; t += TK_THREADS) {
+        const int i = (int)(t / dc), c = (int)(t - (int64_t)i * dc);
+        out_desc[((int64_t)b * k + i) * dc + c] = (i < kk) ? desc[(int64_t)(r0 + (int32_t)(skeys[i] & 0xFFFFFFFFu)) * dc + c] : 0.f;
+      }
     }
-    for (int t = tid; t < k * 3; t += 1024) {
+    for (int t = tid; t < k * 3; t += TK_THREADS) {
       const int i = t / 3, c = t - i * 3;
       out_kp[((int64_t)b * k + i) * 3 + c] = (i < kk) ? kp[(int64_t)(r0 + (int32_t)(skeys[i] & 0xFFFFFFFFu)) * 3 + c] : 0.f;
     }
@@ -923,16 +1140,16 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restri
 int select_topk(const float* sigma, const int32_t* boff_dev, int B, int k, const float* kp, const float* desc, int dc,
                 int32_t* sel_rows, int32_t* sel_count, float* out_kp, float* out_desc, hipStream_t stream) {
   EGONN_REQUIRE(k >= 1 && k <= 8192, EGONN_ERR_INVALID, "select_keypoints: n_k=%d outside [1, 8192]", k);
-  int S = 2048;
-  while (S < 2 * k) S <<= 1;
-  const size_t lds = (size_t)S * sizeof(unsigned long long);
+  int S = 64;
+  while (S < k) S <<= 1;
+  const size_t lds = (size_t)(S + (k <= 512 ? k : 0)) * sizeof(unsigned long long);
   static bool attr_done = false;
   if (!attr_done) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024));
+                                  128 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(1024), lds, stream, sigma, boff_dev, k, S, kp, desc, dc, sel_rows,
+  hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(TK_THREADS), lds, stream, sigma, boff_dev, k, S, kp, desc, dc, sel_rows,
                      sel_count, out_kp, out_desc);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
