@@ -143,69 +143,81 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const void* __restrict
   // pass 1 ... — and took 12-14 us on launches of a dozen workgroups, eight times per step: profiles/r02x_timeline.txt).
   // `n` is the capacity of the buffers, so rows between the live count and `n` may be read (never stored).
   const int64_t ncap = n;
-  int32_t nlive32 = 0x7FFFFFFF;
-  if (n_dev) nlive32 = *n_dev;
-  const float* in = reinterpret_cast<const float*>(in_v);
-  const float* residual = reinterpret_cast<const float*>(residual_v);
-  float* out = reinterpret_cast<float*>(out_v);
-  constexpr int KS = CIN / 16;
+  const int32_t* nd = n_dev ? n_dev : reinterpret_cast<const int32_t*>(W);      // every load below is unconditional:
+  const int32_t nlive_raw = *nd;                                                // indices are clamped into the buffers and
+  const int32_t nlive32 = n_dev ? nlive_raw : 0x7FFFFFFF;                       // null pointers replaced by W, so the code is
+  const float* in = reinterpret_cast<const float*>(in_v);                       // one straight line of requests followed by
+  float* out = reinterpret_cast<float*>(out_v);                                 // one wait (guarded loads compiled into a
+  constexpr int KS = CIN / 16;                                                  // branch and a partial wait per load)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g4 = lane >> 4;
   const int64_t row_base = ((int64_t)blockIdx.x * 4 + wave) * 16;
   if (row_base >= ncap) return;
-  const int64_t row = row_base + l15;
+  const int64_t row = min(row_base + l15, ncap - 1);
   float4 a[KS];
 #pragma unroll
   for (int t = 0; t < KS; ++t) {
-    a[t] = make_float4(0, 0, 0, 0);
-    if (row < ncap) {
-      if constexpr (IN_BF16) {
-        const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(in_v) + row * CIN + 16 * t + 4 * g4);
-        a[t] = make_float4(bf2f(h.x & 0xFFFFu), bf2f(h.x >> 16), bf2f(h.y & 0xFFFFu), bf2f(h.y >> 16));
-      } else {
-        a[t] = *reinterpret_cast<const float4*>(in + row * CIN + 16 * t + 4 * g4);
-      }
+    if constexpr (IN_BF16) {
+      const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(in_v) + row * CIN + 16 * t + 4 * g4);
+      a[t] = make_float4(bf2f(h.x & 0xFFFFu), bf2f(h.x >> 16), bf2f(h.y & 0xFFFFu), bf2f(h.y >> 16));
+    } else {
+      a[t] = *reinterpret_cast<const float4*>(in + row * CIN + 16 * t + 4 * g4);
     }
   }
   const int ncol0 = blockIdx.y * 64;
   float4 b[4][KS];
   float bi[4], sc[4], sh[4];
+  const float* bias_p = bias ? bias : W;
+  const float* scale_p = scale ? scale : W;
+  const float* shift_p = scale ? shift : W;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
-    const int col = ncol0 + nt * 16 + l15;
-    const bool okc = col < cout;
-    bi[nt] = (bias && okc) ? bias[col] : 0.f;
-    sc[nt] = (scale && okc) ? scale[col] : 1.f;
-    sh[nt] = (scale && okc) ? shift[col] : 0.f;
+    const int col = min(ncol0 + nt * 16 + l15, cout - 1);
+    bi[nt] = bias_p[col];
+    sc[nt] = scale_p[col];
+    sh[nt] = shift_p[col];
 #pragma unroll
     for (int t = 0; t < KS; ++t) {
-      float4 v = make_float4(0, 0, 0, 0);
-      if (okc) {
-        if (W_OUT_IN) {
-          v = *reinterpret_cast<const float4*>(W + (int64_t)col * CIN + 16 * t + 4 * g4);
-        } else {
-          const float* wp = W + (int64_t)(16 * t + 4 * g4) * cout + col;
-          v.x = wp[0];
-          v.y = wp[cout];
-          v.z = wp[2 * (int64_t)cout];
-          v.w = wp[3 * (int64_t)cout];
-        }
+      float4 v;
+      if (W_OUT_IN) {
+        v = *reinterpret_cast<const float4*>(W + (int64_t)col * CIN + 16 * t + 4 * g4);
+      } else {
+        const float* wp = W + (int64_t)(16 * t + 4 * g4) * cout + col;
+        v.x = wp[0];
+        v.y = wp[cout];
+        v.z = wp[2 * (int64_t)cout];
+        v.w = wp[3 * (int64_t)cout];
       }
       b[nt][t] = v;
     }
   }
   float res[4][4];
+  {
+    const bool has_res = residual_v != nullptr;
+    const void* rp = has_res ? residual_v : static_cast<const void*>(W);
+    int64_t ridx[4][4];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int col = ncol0 + nt * 16 + l15;
+    for (int nt = 0; nt < 4; ++nt) {
+      const int col = min(ncol0 + nt * 16 + l15, cout - 1);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t orow = row_base + 4 * g4 + r;
-      res[nt][r] = 0.f;
-      if (residual_v && col < cout && orow < ncap)
-        res[nt][r] = (io & 1) ? bf2f(reinterpret_cast<const uint16_t*>(residual_v)[orow * cout + col]) : residual[orow * cout + col];
+      for (int r = 0; r < 4; ++r) {
+        const int64_t orow = min(row_base + 4 * g4 + r, ncap - 1);
+        ridx[nt][r] = has_res ? orow * cout + col : 0;
+      }
+    }
+    if (io & 1) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[nt][r] = bf2f(reinterpret_cast<const uint16_t*>(rp)[ridx[nt][r]]);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[nt][r] = reinterpret_cast<const float*>(rp)[ridx[nt][r]];
     }
   }
+  if (!bias) bi[0] = bi[1] = bi[2] = bi[3] = 0.f;
   n = min((int64_t)nlive32, ncap);
   if (row_base >= n) return;
 #pragma unroll

@@ -221,3 +221,56 @@ def test_mac_and_spoc_pooling(gpu):
     assert (mx >= av - 1e-6).all()                     # max >= mean, per scan and channel
     # GeM with p = 3 on clamped rows lies between the mean of the clamped rows and their max
     assert (g <= np.maximum(mx, 1e-6) + 1e-5).all() and (g >= np.maximum(av, 0) - 1e-5).all()
+
+
+def _topk_rows(gpu, sigma, offsets, k):
+    """egonn_topk_rows through the C-ABI: (rows [B,k] int32 with -1 padding, counts [B])"""
+    from egonn_amd import _lib
+    lib = _lib.load()
+    B = len(offsets) - 1
+    sg = torch.from_numpy(sigma).cuda()
+    boff = torch.tensor(offsets, dtype=torch.int32, device="cuda")
+    rows = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    cnt = torch.empty((B,), dtype=torch.int32, device="cuda")
+    _lib.check(lib.egonn_topk_rows(sg.data_ptr(), boff.data_ptr(), B, k, rows.data_ptr(), cnt.data_ptr(), _lib._stream()))
+    torch.cuda.synchronize()
+    return rows.cpu().numpy(), cnt.cpu().numpy()
+
+
+@pytest.mark.parametrize("k", [1, 128, 500, 513, 2048])
+def test_topk_radix_select_edge_cases(gpu, k):
+    """The radix-select top-k against a stable argsort (eval/evaluate.py:359 torch.topk(largest=False); ties by row):
+    ragged scans incl. an empty one and one shorter than k, a scan longer than the 8192 keys a workgroup caches, heavy
+    ties (a handful of distinct values, all-equal, +-0, negatives, infinities) and both ordering paths (k <= 512 counted,
+    k > 512 bitonic)."""
+    rng = np.random.default_rng(100 + k)
+    sizes = [0, 5, 127, 1000, 8192, 8193, 23001, 300]
+    parts = []
+    for i, n in enumerate(sizes):
+        kind = i % 4
+        if kind == 0:
+            v = rng.uniform(0.01, 2.0, n)
+        elif kind == 1:
+            v = rng.choice(np.array([0.25, 0.5, 0.5000001, 1.0, -0.0, 0.0, -3.0, np.inf, -np.inf]), n)   # heavy ties
+        elif kind == 2:
+            v = np.full(n, 0.75)                                                                       # one value: order = rows
+        else:
+            v = np.round(rng.standard_normal(n), 2)                                                     # ~600 distinct values
+        parts.append(v.astype(np.float32))
+    sigma = np.concatenate(parts) if parts else np.zeros(0, np.float32)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    rows, cnt = _topk_rows(gpu, sigma, off.tolist(), k)
+    for b, n in enumerate(sizes):
+        seg = sigma[off[b]:off[b + 1]]
+        # the library's order: monotone bits of the float (so -0.0 sorts before +0.0), then the row
+        u = seg.view(np.uint32).astype(np.uint64)
+        bits = np.where(u & 0x80000000, ~u & 0xFFFFFFFF, u | 0x80000000)
+        want = np.argsort((bits << np.uint64(32)) | np.arange(n, dtype=np.uint64), kind="stable")[:k]
+        kk = min(k, n)
+        assert cnt[b] == kk
+        assert np.array_equal(rows[b, :kk], want + off[b]), (b, n)
+        assert np.all(rows[b, kk:] == -1)
+        # and the values agree with torch.topk (which leaves the order of equal values open)
+        if kk:
+            tv = torch.topk(torch.from_numpy(seg), kk, largest=False).values.numpy()
+            assert np.array_equal(seg[rows[b, :kk] - off[b]], tv)
