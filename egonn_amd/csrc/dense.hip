@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void dense_kernel(const void* __restrict__ in_
   }
 }
 
-// dense_small_kernel: the same tile arithmetic for launches too small to hide latency (n < 32768 rows) — see its first comment.
+// dense_small_kernel: the same tile arithmetic for launches too small to hide latency (n < 8192 rows) — see its first comment.
 template <int W_OUT_IN, int CIN, bool IN_BF16>
 __global__ __launch_bounds__(256) void dense_small_kernel(const void* __restrict__ in_v, int64_t n,
                                                     const float* __restrict__ W, int cout,
@@ -262,34 +262,43 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const void* __restrict__
                                                         const float* __restrict__ bias, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int act,
                                                         const void* __restrict__ residual_v, void* __restrict__ out_v, int io,
-                                                        const int32_t* __restrict__ n_dev) {
+                                                        const int32_t* __restrict__ n_dev, int colblk) {
   extern __shared__ __attribute__((aligned(16))) f32x4 dl_frags[];
   if (n_dev) n = min((int64_t)*n_dev, n);
   constexpr int KS = CIN / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g4 = lane >> 4;
-  const int NT = cout >> 4;
-  for (int i = tid; i < NT * KS * 64; i += 256) {
+  // grid.y splits the output columns into blocks of `colblk` (a multiple of 16) when all the fragments do not fit in LDS
+  const int cb0 = blockIdx.y * colblk;
+  const int NT = min(colblk, cout - cb0) >> 4, ncl = NT * 16;
+  // eight fragments per thread in flight (one at a time made the staging a chain of up to 96 dependent round trips:
+  // 24 us for the 96 KB block of the 192 -> 256 layer)
+  auto frag_of = [&](int i) -> f32x4 {
     const int ln = i & 63, ft = i >> 6;
     const int nt = ft / KS, t = ft - nt * KS;
-    const int col = 16 * nt + (ln & 15), k0 = 16 * t + 4 * (ln >> 4);
-    f32x4 v;
-    if (W_OUT_IN) {
-      v = *reinterpret_cast<const f32x4*>(W + (int64_t)col * CIN + k0);
-    } else {
-      const float* wp = W + (int64_t)k0 * cout + col;
-      v = (f32x4){wp[0], wp[cout], wp[2 * (int64_t)cout], wp[3 * (int64_t)cout]};
-    }
-    dl_frags[i] = v;
+    const int col = cb0 + 16 * nt + (ln & 15), k0 = 16 * t + 4 * (ln >> 4);
+    if (W_OUT_IN) return *reinterpret_cast<const f32x4*>(W + (int64_t)col * CIN + k0);
+    const float* wp = W + (int64_t)k0 * cout + col;
+    return (f32x4){wp[0], wp[cout], wp[2 * (int64_t)cout], wp[3 * (int64_t)cout]};
+  };
+  const int nfrag = NT * KS * 64;
+  int i0 = tid;
+  for (; i0 + 7 * 256 < nfrag; i0 += 8 * 256) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = frag_of(i0 + u * 256);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dl_frags[i0 + u * 256] = v[u];
   }
+  for (; i0 < nfrag; i0 += 256) dl_frags[i0] = frag_of(i0);
   __syncthreads();
   // bias / folded-BN vectors of the epilogue -> LDS (behind the fragments): they were three dependent L1 round trips per
   // 16 output columns of every tile
   float* const s_vec = reinterpret_cast<float*>(dl_frags + (int64_t)NT * KS * 64);      // [3][cout]: bias, scale, shift
-  for (int i = tid; i < cout; i += 256) {
-    s_vec[i] = bias ? bias[i] : 0.f;
-    s_vec[cout + i] = scale ? scale[i] : 1.f;
-    s_vec[2 * cout + i] = scale ? shift[i] : 0.f;
+  for (int i = tid; i < ncl; i += 256) {
+    s_vec[i] = bias ? bias[cb0 + i] : 0.f;
+    s_vec[ncl + i] = scale ? scale[cb0 + i] : 1.f;
+    s_vec[2 * ncl + i] = scale ? shift[cb0 + i] : 0.f;
   }
   __syncthreads();
   const int64_t ntiles = (n + 15) >> 4;
@@ -326,9 +335,9 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const void* __restrict__
         for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], a[t][u], acc, 0, 0, 0);
       }
       if (ok) {
-        const int c0 = 16 * nt + 4 * g4;
-        f32x4 v = acc + *reinterpret_cast<const f32x4*>(s_vec + c0);
-        v = v * *reinterpret_cast<const f32x4*>(s_vec + cout + c0) + *reinterpret_cast<const f32x4*>(s_vec + 2 * cout + c0);
+        const int cl = 16 * nt + 4 * g4, c0 = cb0 + cl;
+        f32x4 v = acc + *reinterpret_cast<const f32x4*>(s_vec + cl);
+        v = v * *reinterpret_cast<const f32x4*>(s_vec + ncl + cl) + *reinterpret_cast<const f32x4*>(s_vec + 2 * ncl + cl);
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = apply_act(v[u], act);
         if (residual_v) {
@@ -372,8 +381,16 @@ int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const floa
   const dim3 grid((unsigned)cdiv(n, 64), (unsigned)cdiv(cout, 64));
   const int io = (res_bf16 ? 1 : 0) | (out_bf16 ? 2 : 0);
   const size_t frag_bytes = (size_t)cin * cout * sizeof(float);
-  if (cout % 16 == 0 && frag_bytes <= 96 * 1024 && n >= 32768) {     // weights resident in LDS, persistent over the row tiles
-    const unsigned g1 = (unsigned)std::min<int64_t>(cdiv(cdiv(n, 16), 4), frag_bytes > 72 * 1024 ? 256 : 512);
+  // weights resident in LDS, workgroups persistent over the row tiles; weight sets above 96 KB (the 192 -> 256 layer of the
+  // global decoder) are split over grid.y into column blocks that fit
+  const int ysplit = (int)cdiv((int64_t)frag_bytes, 96 * 1024);
+  const int colblk = (int)(cdiv(cdiv(cout, ysplit), 16) * 16);
+  // measured (batch 16 / 64): from 8192 rows on the staged weights win over dense_small_kernel; the split blocks replace
+  // the 64-column kernel that re-reads its 48 KB weight slice per wave (17 / 56 us -> 18 / 41 us for 192 -> 256)
+  if (cout % 16 == 0 && n >= (ysplit == 1 ? 8192 : 2048)) {
+    const size_t blk_bytes = (size_t)cin * colblk * sizeof(float);
+    const int ny = (int)cdiv(cout, colblk);
+    const unsigned g1 = (unsigned)std::min<int64_t>(cdiv(cdiv(n, 16), 4), (blk_bytes > 72 * 1024 ? 256 : 512) / ny);
 #define EGONN_DENSE_LDS_LAUNCH(WOI, CI, INB)                                                                           \
   {                                                                                                                   \
     static bool attr_done = false;                                                                                    \
@@ -382,8 +399,8 @@ int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const floa
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
       attr_done = true;                                                                                               \
     }                                                                                                                 \
-    hipLaunchKernelGGL((dense_lds_kernel<WOI, CI, INB>), dim3(g1), dim3(256), frag_bytes + 3 * (size_t)cout * sizeof(float), stream, in, n, W, cout, bias, scale, \
-                       shift, act, residual, out, io, n_dev);                                                         \
+    hipLaunchKernelGGL((dense_lds_kernel<WOI, CI, INB>), dim3(g1, ny), dim3(256), blk_bytes + 3 * (size_t)colblk * sizeof(float), stream, in, n, W, cout, bias, scale, \
+                       shift, act, residual, out, io, n_dev, colblk);                                                 \
   }
 #define EGONN_DENSE_LDS_CASE(CI)                                                                                      \
   if (cin == CI) {                                                                                                    \
@@ -402,7 +419,7 @@ int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const floa
 #undef EGONN_DENSE_LDS_LAUNCH
   }
 #define EGONN_DENSE_LAUNCH(WOI, CI, INB)                                                                              \
-  if (n < 32768)                                                                                                      \
+  if (n < 8192 && CI <= 128)                                                                                          \
     hipLaunchKernelGGL((dense_small_kernel<WOI, CI, INB>), grid, dim3(256), 0, stream, in, n, W, cout, bias, scale, shift, act, \
                        residual, out, io, n_dev);                                                                     \
   else                                                                                                                \
