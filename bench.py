@@ -30,6 +30,12 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+# One hardware queue per batch in flight: the HIP runtime multiplexes its streams over GPU_MAX_HW_QUEUES (default 4)
+# hardware queues, and two in-flight batches that share a queue serialise.  Measured (profiles/r02y_streams.txt): 3 streams
+# on the default 4 queues 20.1-20.3 k scans/s, 4 streams 17.8 k; with 8 queues 4 streams 21.3-21.4 k, 5 streams 16.5 k.
+# Must be in the environment before the runtime initialises (= before `import torch`); a caller's own setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -53,7 +59,7 @@ def parse():
                    help="f32 = BASELINE configs[1] (default, the headline metric); bf16 = configs[2]: feature maps and "
                         "sparse-conv weights bf16 in HBM, fp32 accumulate")
     p.add_argument("--mode", choices=["graph", "eager"], default="graph")
-    p.add_argument("--streams", type=int, default=3, help="batches in flight (HIP streams, one egonn_ctx / graph each)")
+    p.add_argument("--streams", type=int, default=4, help="batches in flight (HIP streams, one egonn_ctx / graph each)")
     p.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median one is reported")
     return p.parse_args()
 
@@ -340,7 +346,7 @@ def main():
                                    + "; step = voxelise + forward + top-128 keypoints; random-init weights",
                        "batch_per_gpu": args.batch, "points_per_scan": args.points, "voxel_m": args.voxel,
                        "voxels_per_level": n_levels, "parallelism": f"scan-sharded x{world} (no collective)",
-                       "batches_in_flight": S,
+                       "batches_in_flight": S, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "launch": "one hipGraphLaunch per step (captured voxelise + forward + select; level sizes stay on the device)"
                                  if args.mode == "graph" else "eager: ~150 launches + one size query per step"},
             "repeats": {"timed_regions": len(elapsed_all), "reported": "median",

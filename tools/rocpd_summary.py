@@ -10,6 +10,11 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else None
 c = sqlite3.connect(db)
 rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels "
                       "order by total_duration desc"))
+# a step launches points_to_keys_kernel exactly once: when it is in the trace, its call count IS the number of steps
+for name, calls, *_ in rows:
+    if "points_to_keys_kernel" in name:
+        steps = calls
+        break
 with open(out, "w", newline="") as f:
     w = csv.writer(f)
     hdr = ["kernel", "calls", "total_us", "avg_us", "percent"]
