@@ -43,6 +43,26 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense MFMA peaks (MI355X_MICROARCH.md): exact-fp32 / bf16
 
 
+def _masked_stream(dev, slot, n_slots, layout):
+    """A HIP stream restricted to one CU partition, wrapped for torch (None = let the extractor make a plain stream)."""
+    if layout == "none":
+        return None
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    bits = [False] * ncu
+    for i in range(ncu):
+        bits[i] = (i * n_slots // ncu == slot) if layout == "block" else (i % n_slots == slot)
+    words = [sum((1 << b) for b in range(32) if w * 32 + b < ncu and bits[w * 32 + b]) for w in range((ncu + 31) // 32)]
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    st = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(words), arr)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(st.value, device=dev)
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -60,6 +80,9 @@ def parse():
                         "sparse-conv weights bf16 in HBM, fp32 accumulate")
     p.add_argument("--mode", choices=["graph", "eager"], default="graph")
     p.add_argument("--streams", type=int, default=4, help="batches in flight (HIP streams, one egonn_ctx / graph each)")
+    p.add_argument("--cu-partition", choices=["none", "block", "xcd"], default="none",
+                   help="graph mode: give every batch in flight its own CU partition (hipExtStreamCreateWithCUMask): "
+                        "block = 256/streams consecutive mask bits, xcd = mask bits i with i %% streams == slot")
     p.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median one is reported")
     return p.parse_args()
 
@@ -163,7 +186,7 @@ def main():
     if args.mode == "graph":
         caps = ex.calibrate(points, offsets, margin=1.25)
         for i in range(S):
-            gx = ex.graph(args.batch, points.shape[0], caps, slot=100 + i)
+            gx = ex.graph(args.batch, points.shape[0], caps, slot=100 + i, stream=_masked_stream(dev, i, S, args.cu_partition))
             gx.ctx.profile_enable(3, dominant + "/")       # event brackets around the dominant kernel, captured with it
             gx.run(points, offsets)                        # eager once + capture + first replay; the batch now lives
             gx.status()                                    # in the graph's own input buffer (resident in HBM)

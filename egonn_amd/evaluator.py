@@ -92,8 +92,8 @@ class DescriptorExtractor:
         ctx.voxelize(points, offsets, q.mode, q.step)
         return [int(ctx.level_count(l) * margin) + 1024 for l in range(8)]
 
-    def graph(self, batch_size: int, max_points: int, level_capacity=None, slot: int = 0):
-        return GraphExtractor(self, batch_size, max_points, level_capacity, slot)
+    def graph(self, batch_size: int, max_points: int, level_capacity=None, slot: int = 0, stream=None):
+        return GraphExtractor(self, batch_size, max_points, level_capacity, slot, stream)
 
     @torch.no_grad()
     def extract_stream(self, batches, n_streams: int = 2, model: MinkGL = None):
@@ -132,7 +132,8 @@ class GraphExtractor:
     instead of ~150 launches) and returns the static output tensors; `status()` synchronises and raises if a batch left
     the coordinate range or the reservation."""
 
-    def __init__(self, extractor: DescriptorExtractor, batch_size: int, max_points: int, level_capacity=None, slot: int = 0):
+    def __init__(self, extractor: DescriptorExtractor, batch_size: int, max_points: int, level_capacity=None, slot: int = 0,
+                 stream=None):
         self.ex = extractor
         model = extractor.model
         self.model = model
@@ -146,7 +147,9 @@ class GraphExtractor:
         self.offsets = torch.zeros((self.B + 1,), dtype=torch.int64, device=dev)
         self._host_off = torch.zeros((self.B + 1,), dtype=torch.int64).pin_memory()
         self._off_copied = None                      # event: the previous batch's offsets left the pinned buffer
-        self.stream = torch.cuda.Stream(device=dev)
+        # `stream`: a caller-made stream (e.g. torch.cuda.ExternalStream around hipExtStreamCreateWithCUMask: one CU
+        # partition per batch in flight); default: a fresh stream of this device
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         self.graph = None
         self.out = None
 
