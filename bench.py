@@ -83,6 +83,9 @@ def parse():
     p.add_argument("--cu-partition", choices=["none", "block", "xcd"], default="none",
                    help="graph mode: give every batch in flight its own CU partition (hipExtStreamCreateWithCUMask): "
                         "block = 256/streams consecutive mask bits, xcd = mask bits i with i %% streams == slot")
+    p.add_argument("--conv-variant", type=int, default=0,
+                   help="A/B measurements only: egonn_debug_set_naive_conv code (2 register-ring kernel, 16 LDS-DMA kernel with "
+                        "split-phase fetch, 32 LDS-DMA kernel with 3 ring slots; all bitwise identical); 0 = product choice")
     p.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median one is reported")
     return p.parse_args()
 
@@ -187,6 +190,8 @@ def main():
         caps = ex.calibrate(points, offsets, margin=1.25)
         for i in range(S):
             gx = ex.graph(args.batch, points.shape[0], caps, slot=100 + i, stream=_masked_stream(dev, i, S, args.cu_partition))
+            if args.conv_variant:
+                gx.ctx.set_naive_conv(args.conv_variant)
             gx.ctx.profile_enable(3, dominant + "/")       # event brackets around the dominant kernel, captured with it
             gx.run(points, offsets)                        # eager once + capture + first replay; the batch now lives
             gx.status()                                    # in the graph's own input buffer (resident in HBM)
