@@ -101,7 +101,7 @@ __host__ __device__ static inline uint64_t morton3(uint32_t x, uint32_t y, uint3
 // The form of a kernel map the sparse-convolution kernel consumes: rows regrouped (per sample, per window, sorted by
 // neighbour-presence mask) into groups of 16 that share their set of present kernel offsets.
 static constexpr int RG_MAX_JOBS = 24;
-static constexpr int RG_MAX_WIN = 1024;
+static constexpr int RG_MAX_WIN = 512;
 struct RowGroups {
   int K = 0;                  // kernel volume of the map (27 or 8)
   int win = 0;                // rows per sort window (256 / 512 / 1024); groups per window = win / 16

@@ -54,7 +54,9 @@ struct RGArgs {
   unsigned long long* trace;   // measurement hook (egonn_debug_set_trace): 8 s_memtime stamps per window; null = off
 };
 
-static constexpr int RG_THREADS = 1024;                 // 16 waves per window: the per-group passes are latency chains
+static constexpr int RG_THREADS = 512;                  // 8 waves per window; 55 KB table + 19 KB static LDS => two windows per CU
+                                                        // (1024-row windows with 1024 threads took a whole CU each: 328 large windows on
+                                                        // 256 CUs ran as two rounds, 46 us per step at batch 16, 187 at batch 64)
 static constexpr int RG_WAVES = RG_THREADS / 64;
 template <bool TRACE>    // TRACE: measurement build (tools/rowgroup_trace.py), s_memtime stamps per phase; the release build has none
 __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
@@ -266,7 +268,7 @@ int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream) {
   for (int j = 0; j < njobs; ++j) {
     const RGBuild& b = jobs[j];
     EGONN_REQUIRE(b.rg && b.nbr && b.n_dev && b.boff, EGONN_ERR_INVALID, "rowgroup_build: null job field");
-    EGONN_REQUIRE(b.rg->win == 256 || b.rg->win == 512 || b.rg->win == 1024, EGONN_ERR_INVALID, "rowgroup window %d", b.rg->win);
+    EGONN_REQUIRE(b.rg->win == 256 || b.rg->win == 512, EGONN_ERR_INVALID, "rowgroup window %d", b.rg->win);
     RGJob& J = a.job[j];
     J.nbr = b.nbr; J.n_dev = b.n_dev; J.boff = b.boff;
     J.perm = b.rg->perm; J.snbr = b.rg->snbr; J.gmask = b.rg->gmask; J.meta = b.rg->meta;
@@ -278,8 +280,8 @@ int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream) {
   if (nb == 0) return EGONN_OK;
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgroup_build_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));   // + 35 KB static
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgroup_build_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgroup_build_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));   // + 19 KB static
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgroup_build_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     attr_done = true;
   }
   size_t lds = 0;                                        // the largest window table of the launch
