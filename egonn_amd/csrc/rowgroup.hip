@@ -60,7 +60,7 @@ static constexpr int RG_THREADS = 512;                  // 8 waves per window; 5
 static constexpr int RG_WAVES = RG_THREADS / 64;
 template <bool TRACE>    // TRACE: measurement build (tools/rowgroup_trace.py), s_memtime stamps per phase; the release build has none
 __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
-  // The window's slice of the kernel map (WIN x K ints, contiguous in memory: 110 KB for K = 27) is read ONCE, fully
+  // The window's slice of the kernel map (WIN x K ints, contiguous in memory: 55 KB for K = 27, WIN = 512) is read ONCE, fully
   // coalesced, into LDS; masks, sort and the transposed emit all work from there.  (The first version read the rows twice
   // from global memory in 108-byte pieces — the builder was bound by those partial-line requests, 66 us per step.)
   extern __shared__ __attribute__((aligned(16))) int32_t stbl[];          // [WIN][K]
