@@ -391,3 +391,34 @@ def test_minkloc_train_step_matches_reference_fixture(name, shapes):
     sd = model.state_dict()
     for k in [k[4:] for k in case if k.startswith("buf/")]:
         assert np.allclose(sd[k].cpu().numpy(), case["buf/" + k], rtol=1e-3, atol=1e-5), k
+
+
+@pytest.mark.parametrize("cin", [32, 64, 128, 192, 256])
+def test_dense_every_kernel_path_matches_fp64(plan, cin):
+    """egonn_dense (MinkowskiLinear / 1x1 convolution, models/minkgl.py:175-225) on every row-count regime of its three
+    kernels — dense_small (< 8192 rows, Cin <= 128), dense_lds (weights staged in LDS; column blocks over grid.y when the
+    weight set exceeds 96 KB: Cin*Cout*4 > 96 KB) and the 64-column kernel — both weight layouts, bias, ReLU, ragged row
+    counts and column counts that are not multiples of 16, against an fp64 matmul.  fp32 MFMA accumulation over <= 256
+    terms: |err| <= 2e-5 * sum|x||w| is generous."""
+    ctx, dev = plan, plan.device
+    seed = 1000 + cin
+    for n in (1, 37, 2047, 2048, 8191, 8192, 8200, 33000):
+        for cout, out_in, use_bias, act in ((16, 1, False, 0), (64, 0, True, 1), (100, 1, True, 0), (192, 0, False, 0),
+                                             (256, 1, True, 1), (256, 0, False, 0), (3, 1, True, 0)):
+            if n > 9000 and cout in (100, 3):
+                continue
+            seed += 1
+            x = rnd((n, cin), seed, dev)
+            w = rnd((cout, cin) if out_in else (cin, cout), seed + 7, dev, 0.2)
+            b = rnd((cout,), seed + 9, dev) if use_bias else None
+            got = ctx.dense(x, w, bool(out_in), b, act).cpu().double()
+            wd = w.cpu().double()
+            wd = wd.t() if out_in else wd
+            want = x.cpu().double() @ wd
+            bound = 2e-5 * (x.cpu().double().abs() @ wd.abs()) + 1e-6
+            if use_bias:
+                want = want + b.cpu().double()
+            if act == 1:
+                want = torch.relu(want)
+            err = (got - want).abs()
+            assert bool((err <= bound).all()), (n, cin, cout, out_in, float(err.max()), float(bound.min()))
