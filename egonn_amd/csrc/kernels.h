@@ -21,9 +21,18 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
 // Convolution over a map of the plan.  kind 0: k=3 on `level`; 1: k=2,s=2 from level-1 into `level`; 2: transposed from
 // level+1 onto `level`.  Wp: kernel already packed for this precision (or null: W is packed into `scratch` first).
 // bf16: feature maps in/out and weights are bf16.  psum (nullable): [groups][cout] per-group column sums of the output.
-int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, int cin, int cout, int bf16,
-              const float* scale, const float* shift, int relu, void* out, float* psum, float* scratch,
+// Wsp: the kernel packed for the split-bf16 path (pack_split_weights; fp32 maps only, nullable like Wp).
+int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, const void* Wsp, int cin, int cout,
+              int bf16, const float* scale, const float* shift, int relu, void* out, float* psum, float* scratch,
               size_t scratch_floats, hipStream_t stream);
+bool sconv_uses_split(int cin, int cout, int bf16, int64_t groups_hint, int variant);
+// sconv_split.hip: fp32 maps on the bf16 matrix pipe (three-way split operands, fp32 accumulate)
+bool sconv_split_supported(int cin, int cout);
+int pack_split_weights(const float* W, int K, int cin, int cout, int flip, int transpose, void* out, hipStream_t stream);
+int sconv_split_default_cfg(int cin, int cout, int64_t groups_hint);
+int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
+                        int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
+                        int cfg = 0);
 static constexpr size_t SCONV_SCRATCH_FLOATS = (size_t)2 << 20;   // 8 MB: one packed kernel (27 x 256 x 256 fp32 = 7 MB)
 // conv.hip -------------------------------------------------------------------------------------
 int sconv_naive(const float* in, const int32_t* nbr, const float* W, const float* scale, const float* shift, int relu,

@@ -73,6 +73,8 @@ struct egonn_model {
   const float *p_convs[8] = {}, *p_c1[8] = {}, *p_c2[8] = {}, *p_gt[8] = {}, *p_lt[8] = {};
   // the same kernels packed as bf16 (EGONN_FLAG_BF16): [0] = fp32 set, [1] = bf16 set
   const float *q_convs[8] = {}, *q_c1[8] = {}, *q_c2[8] = {}, *q_gt[8] = {}, *q_lt[8] = {};
+  // the same kernels as hi|mid|lo bf16 fragments for the split-bf16 fp32 path (sconv_split.hip)
+  const float *s_convs[8] = {}, *s_c1[8] = {}, *s_c2[8] = {}, *s_gt[8] = {}, *s_lt[8] = {};
 };
 
 // ------------------------------------------------------------------------------------------ lifecycle
@@ -80,6 +82,7 @@ API const char* egonn_last_error(void) { return last_error(); }
 
 API int egonn_debug_set_naive_conv(egonn_ctx* c, int on) {
   EGONN_REQUIRE(c, EGONN_ERR_INVALID, "debug_set_naive_conv: null context");
+  if (on >= 1000) { c->conv_variant = on; return EGONN_OK; }     // split-bf16 kernel with an explicit configuration
   c->conv_variant = (on == 1) ? 3 : (on == 2 ? 1 : (on == 4 ? 2 : (on == 8 ? 4 : (on == 16 ? 5 : (on == 32 ? 6 : (on == 128 ? 9 : 0))))));
   return EGONN_OK;
 }
@@ -306,12 +309,12 @@ API int egonn_conv(egonn_ctx* c, int level_in, int level_out, int ks, const floa
   if (ks == 3) {
     EGONN_REQUIRE(level_in == level_out && level_in >= 1, EGONN_ERR_INVALID,
                   "k=3 convolution is implemented for levels 1..7 (same in/out level)");
-    return sconv_map(c, 0, level_out, in, kernel, nullptr, cin, cout, 0, scale, shift, relu, out, nullptr, op_scratch(c),
+    return sconv_map(c, 0, level_out, in, kernel, nullptr, nullptr, cin, cout, 0, scale, shift, relu, out, nullptr, op_scratch(c),
                      SCONV_SCRATCH_FLOATS, st);
   }
   if (ks == 2) {
     EGONN_REQUIRE(level_out == level_in + 1, EGONN_ERR_INVALID, "k=2,s=2 convolution maps level l to l+1");
-    return sconv_map(c, 1, level_out, in, kernel, nullptr, cin, cout, 0, scale, shift, relu, out, nullptr, op_scratch(c),
+    return sconv_map(c, 1, level_out, in, kernel, nullptr, nullptr, cin, cout, 0, scale, shift, relu, out, nullptr, op_scratch(c),
                      SCONV_SCRATCH_FLOATS, st);
   }
   set_error("conv: kernel_size %d not supported (1, 2, 3, 5)", ks);
@@ -325,7 +328,7 @@ API int egonn_conv_transpose(egonn_ctx* c, int level_in, const float* in, int ci
   EGONN_REQUIRE(level_in >= 1 && level_in < EGONN_NUM_LEVELS, EGONN_ERR_INVALID,
                 "transposed conv: input level %d out of range [1,7]", level_in);
   if (level_in == 1) EGONN_TRY(ensure_level0_parent_table(c, (hipStream_t)stream));
-  return sconv_map(c, 2, level_in - 1, in, kernel, nullptr, cin, cout, 0, nullptr, nullptr, 0, out, nullptr, op_scratch(c),
+  return sconv_map(c, 2, level_in - 1, in, kernel, nullptr, nullptr, cin, cout, 0, nullptr, nullptr, 0, out, nullptr, op_scratch(c),
                    SCONV_SCRATCH_FLOATS, (hipStream_t)stream);
 }
 
@@ -336,7 +339,7 @@ API int egonn_sparse_conv(egonn_ctx* c, int map_kind, int level_out, const void*
   REQUIRE_PLAN(c);
   HIP_CHECK(hipSetDevice(c->device));
   EGONN_REQUIRE(in && kernel && out, EGONN_ERR_INVALID, "sparse_conv: null argument");
-  return sconv_map(c, map_kind, level_out, in, kernel, nullptr, cin, cout, bf16, scale, shift, relu, out, group_sums,
+  return sconv_map(c, map_kind, level_out, in, kernel, nullptr, nullptr, cin, cout, bf16, scale, shift, relu, out, group_sums,
                    op_scratch(c), SCONV_SCRATCH_FLOATS, (hipStream_t)stream);
 }
 // Measurement hook (tools/sconv_trace.py): device buffer the traced conv build (debug variant 128) writes its per-task
@@ -614,29 +617,36 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
     need_p += (size_t)2 * 8 * GLOBAL_CH * GLOBAL_CH + (size_t)8 * LOCAL_CH * LOCAL_CH;
     if (m->packed_cap < need_p) {
       if (m->packed) HIP_CHECK(hipFree(m->packed));
-      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->packed), (need_p + need_p / 2 + 64) * sizeof(float)));
+      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->packed), (3 * need_p + 64) * sizeof(float)));
       m->packed_cap = need_p;
     }
     float* pc = m->packed;
     uint16_t* qc = reinterpret_cast<uint16_t*>(m->packed + need_p);      // bf16 copies behind the fp32 ones
-    auto pack2 = [&](const float* w, int K, int ci, int co, const float** dst32, const float** dst16) -> int {
+    uint16_t* sc = reinterpret_cast<uint16_t*>(m->packed + need_p + need_p / 2 + 16);   // split fragments behind the bf16 ones
+    auto pack2 = [&](const float* w, int K, int ci, int co, const float** dst32, const float** dst16, const float** dsts) -> int {
       EGONN_TRY(pack_rg_weights(w, K, ci, co, 0, 0, 0, pc, st));
       EGONN_TRY(pack_rg_weights(w, K, ci, co, 1, 0, 0, qc, st));
       *dst32 = pc;
       *dst16 = reinterpret_cast<const float*>(qc);
+      *dsts = nullptr;
+      if (sconv_split_supported(ci, co)) {
+        EGONN_TRY(pack_split_weights(w, K, ci, co, 0, 0, sc, st));
+        *dsts = reinterpret_cast<const float*>(sc);
+        sc += (size_t)K * ci * co * 3;
+      }
       pc += (size_t)K * ci * co;
       qc += (size_t)K * ci * co;
       return EGONN_OK;
     };
     for (int i = 1; i <= 7; ++i) {
       const BlockRef& b = m->blk[i];
-      EGONN_TRY(pack2(m->convs[i], 8, b.cin, b.cin, &m->p_convs[i], &m->q_convs[i]));
-      EGONN_TRY(pack2(b.conv1, 27, b.cin, b.cout, &m->p_c1[i], &m->q_c1[i]));
-      EGONN_TRY(pack2(b.conv2, 27, b.cout, b.cout, &m->p_c2[i], &m->q_c2[i]));
+      EGONN_TRY(pack2(m->convs[i], 8, b.cin, b.cin, &m->p_convs[i], &m->q_convs[i], &m->s_convs[i]));
+      EGONN_TRY(pack2(b.conv1, 27, b.cin, b.cout, &m->p_c1[i], &m->q_c1[i], &m->s_c1[i]));
+      EGONN_TRY(pack2(b.conv2, 27, b.cout, b.cout, &m->p_c2[i], &m->q_c2[i], &m->s_c2[i]));
     }
-    EGONN_TRY(pack2(m->gt[6], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[6], &m->q_gt[6]));
-    EGONN_TRY(pack2(m->gt[7], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[7], &m->q_gt[7]));
-    EGONN_TRY(pack2(m->lt[4], 8, LOCAL_CH, LOCAL_CH, &m->p_lt[4], &m->q_lt[4]));
+    EGONN_TRY(pack2(m->gt[6], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[6], &m->q_gt[6], &m->s_gt[6]));
+    EGONN_TRY(pack2(m->gt[7], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[7], &m->q_gt[7], &m->s_gt[7]));
+    EGONN_TRY(pack2(m->lt[4], 8, LOCAL_CH, LOCAL_CH, &m->p_lt[4], &m->q_lt[4], &m->s_lt[4]));
   }
   EGONN_TRY(fold(m->bn[0], st));
   for (int i = 1; i <= 7; ++i) {
@@ -733,7 +743,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
       snprintf(tag, sizeof(tag), "%s<%d,%d>/L3/tconv", sconv_kernel_name(LOCAL_CH, LOCAL_CH, bf16, P.lv[3].rgT.cap_groups, c->conv_variant),
                LOCAL_CH, LOCAL_CH);
       ProfScope ps(c, st, tag, PK_TCONV, 3, 8, LOCAL_CH, LOCAL_CH, (int)es);
-      EGONN_TRY(sconv_map(c, 2, 3, l4, nullptr, bf16 ? m->q_lt[4] : m->p_lt[4], LOCAL_CH, LOCAL_CH, bf16, nullptr, nullptr, 0, u3,
+      EGONN_TRY(sconv_map(c, 2, 3, l4, nullptr, bf16 ? m->q_lt[4] : m->p_lt[4], m->s_lt[4], LOCAL_CH, LOCAL_CH, bf16, nullptr, nullptr, 0, u3,
                           nullptr, nullptr, 0, st));
     }
     WALLOC(l3, n3 * LOCAL_CH);
@@ -756,7 +766,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
       snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k2s2", sconv_kernel_name(b.cin, b.cin, bf16, L.rg8.cap_groups, c->conv_variant), b.cin,
                b.cin, i);
       ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, (int)es);
-      EGONN_TRY(sconv_map(c, 1, i, x[i - 1], nullptr, bf16 ? m->q_convs[i] : m->p_convs[i], b.cin, b.cin, bf16, m->bn[i].scale,
+      EGONN_TRY(sconv_map(c, 1, i, x[i - 1], nullptr, bf16 ? m->q_convs[i] : m->p_convs[i], m->s_convs[i], b.cin, b.cin, bf16, m->bn[i].scale,
                           m->bn[i].shift, 1, y, nullptr, nullptr, 0, st));
     }
     // ECABasicBlock (layers/eca_block.py:56-73)
@@ -765,7 +775,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
       snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv1", sconv_kernel_name(b.cin, b.cout, bf16, L.rg27.cap_groups, c->conv_variant),
                b.cin, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cin, b.cout, (int)es);
-      EGONN_TRY(sconv_map(c, 0, i, y, nullptr, bf16 ? m->q_c1[i] : m->p_c1[i], b.cin, b.cout, bf16, b.n1.scale, b.n1.shift, 1, t1,
+      EGONN_TRY(sconv_map(c, 0, i, y, nullptr, bf16 ? m->q_c1[i] : m->p_c1[i], m->s_c1[i], b.cin, b.cout, bf16, b.n1.scale, b.n1.shift, 1, t1,
                           nullptr, nullptr, 0, st));
     }
     FALLOC(t2, n * b.cout);
@@ -774,7 +784,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
       snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv2", sconv_kernel_name(b.cout, b.cout, bf16, L.rg27.cap_groups, c->conv_variant),
                b.cout, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cout, b.cout, (int)es);
-      EGONN_TRY(sconv_map(c, 0, i, t1, nullptr, bf16 ? m->q_c2[i] : m->p_c2[i], b.cout, b.cout, bf16, b.n2.scale, b.n2.shift, 0, t2,
+      EGONN_TRY(sconv_map(c, 0, i, t1, nullptr, bf16 ? m->q_c2[i] : m->p_c2[i], m->s_c2[i], b.cout, b.cout, bf16, b.n2.scale, b.n2.shift, 0, t2,
                           psum, nullptr, 0, st));
     }
     WALLOC(gate, (size_t)B * b.cout);
@@ -808,7 +818,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
       snprintf(tag, sizeof(tag), "%s<%d,%d>/L6/tconv", sconv_kernel_name(GLOBAL_CH, GLOBAL_CH, bf16, P.lv[6].rgT.cap_groups, c->conv_variant),
                GLOBAL_CH, GLOBAL_CH);
       ProfScope ps(c, st, tag, PK_TCONV, 6, 8, GLOBAL_CH, GLOBAL_CH, (int)es);
-      EGONN_TRY(sconv_map(c, 2, 6, g7, nullptr, bf16 ? m->q_gt[7] : m->p_gt[7], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u6,
+      EGONN_TRY(sconv_map(c, 2, 6, g7, nullptr, bf16 ? m->q_gt[7] : m->p_gt[7], m->s_gt[7], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u6,
                           nullptr, nullptr, 0, st));
     }
     FALLOC(g6, P.cap[6] * GLOBAL_CH);
@@ -820,7 +830,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
       snprintf(tag, sizeof(tag), "%s<%d,%d>/L5/tconv", sconv_kernel_name(GLOBAL_CH, GLOBAL_CH, bf16, P.lv[5].rgT.cap_groups, c->conv_variant),
                GLOBAL_CH, GLOBAL_CH);
       ProfScope ps(c, st, tag, PK_TCONV, 5, 8, GLOBAL_CH, GLOBAL_CH, (int)es);
-      EGONN_TRY(sconv_map(c, 2, 5, g6, nullptr, bf16 ? m->q_gt[6] : m->p_gt[6], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u5,
+      EGONN_TRY(sconv_map(c, 2, 5, g6, nullptr, bf16 ? m->q_gt[6] : m->p_gt[6], m->s_gt[6], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u5,
                           nullptr, nullptr, 0, st));
     }
     WALLOC(g5, P.cap[5] * GLOBAL_CH);

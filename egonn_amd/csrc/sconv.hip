@@ -1166,6 +1166,7 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
 // Name of the kernel sconv_rg_forward dispatches for this launch (the profiler tags carry it, so that bench.py's dominant
 // kernel is the kernel rocprofv3 names).  Mirrors the choice in sconv_rg_forward / launch_rg.
 const char* sconv_kernel_name(int cin, int cout, int bf16, int64_t groups_hint, int variant) {
+  if (sconv_uses_split(cin, cout, bf16, groups_hint, variant)) return "sconv_split_kernel";
   const int ns = cout / 32, ncb = cin / 32;
   const int ksp = ncb >= 4 ? 4 : ncb;
   const bool small = groups_hint * ns * ksp < 6144;
@@ -1175,8 +1176,19 @@ const char* sconv_kernel_name(int cin, int cout, int bf16, int64_t groups_hint, 
   return "sconv_rg_kernel";
 }
 
-int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, int cin, int cout, int bf16,
-              const float* scale, const float* shift, int relu, void* out, float* psum, float* scratch,
+// Arithmetic of an fp32 sparse convolution (ctx->conv_variant; egonn_debug_set_naive_conv):
+//   0           product choice: split-bf16 kernel (sconv_split.hip) where it is instantiated, exact fp32 MFMA kernels elsewhere
+//   1..9        the exact fp32 kernels of this file (3 = plain one-thread-per-output kernel)
+//   1000 + cfg  split-bf16 kernel with an explicit configuration (cfg 0 = its default)
+bool sconv_uses_split(int cin, int cout, int bf16, int64_t groups_hint, int variant) {
+  if (bf16 || !sconv_split_supported(cin, cout)) return false;
+  if (variant >= 1000) return true;
+  (void)groups_hint;
+  return false;
+}
+
+int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, const void* Wsp, int cin, int cout,
+              int bf16, const float* scale, const float* shift, int relu, void* out, float* psum, float* scratch,
               size_t scratch_floats, hipStream_t stream) {
   Plan& P = ctx->plan;
   EGONN_REQUIRE(kind >= 0 && kind <= 2, EGONN_ERR_INVALID, "sconv: map kind %d", kind);
@@ -1197,6 +1209,17 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
   }
   EGONN_TRY(ensure_rowgroups(ctx, &kind, &level, 1, stream));
   const RowGroups& rg = kind == 0 ? V.rg27 : (kind == 1 ? V.rg8 : V.rgT);
+  if (sconv_uses_split(cin, cout, bf16, rg.cap_groups, ctx->conv_variant)) {
+    if (!Wsp) {   // stand-alone operator call: pack into the caller's scratch
+      const size_t wn = ((size_t)K * cin * cout * 3 + 1) / 2;
+      EGONN_REQUIRE(W && scratch && scratch_floats >= wn, EGONN_ERR_STATE, "sconv: no scratch to pack the kernel into");
+      EGONN_TRY(pack_split_weights(W, K, cin, cout, 0, 0, scratch, stream));
+      Wsp = scratch;
+    }
+    return sconv_split_forward(reinterpret_cast<const float*>(in), P.cap[lin], rg, rg.cap_groups, Wsp, cin, cout, scale, shift,
+                               relu, reinterpret_cast<float*>(out), psum, stream,
+                               ctx->conv_variant >= 1000 ? ctx->conv_variant - 1000 : 0);
+  }
   if (!Wp) {      // stand-alone operator call: pack into the caller's scratch
     const size_t wn = (size_t)K * cin * cout;
     EGONN_REQUIRE(W && scratch && scratch_floats >= wn, EGONN_ERR_STATE, "sconv: no scratch to pack the kernel into");

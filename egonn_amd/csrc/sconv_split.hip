@@ -1,0 +1,540 @@
+// fp32 sparse convolution on the bf16 matrix pipe: three-way split operands, fp32 accumulate (gfx950).
+//
+// Replaces the same reference operators as sconv.hip (MinkowskiConvolution k=3 / k=2,s=2 and
+// MinkowskiConvolutionTranspose forward: models/minkgl.py:39,100,105 and :46-60; ME BasicBlock conv1/conv2 via
+// layers/eca_block.py:58-63) for fp32 feature maps:
+//
+//   out[o] = act( (sum_k in[nbr[o][k]] @ W[k]) * scale + shift )
+//
+// Why.  v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (157 TFLOP/s, 1/16 of the bf16 matrix rate) and was the binding
+// roof of every fp32 layer with >= 64 channels (0.29-0.34 of it on 1.4x-padded tiles).  An fp32 number is
+// EXACTLY the sum of three bf16 numbers (24 = 8 + 8 + 8 significand bits: hi = rn(x), mid = rn(x - hi), lo = x - hi - mid),
+// and a bf16 x bf16 product is exact in fp32.  So  a*w = sum over the nine (part of a, part of w) products; the six with
+// weight >= 2^-16 relative (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) are issued on v_mfma_f32_16x16x32_bf16 with fp32
+// accumulation; the three dropped ones are <= 2^-25 |a w| each (round-to-nearest parts: |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|),
+// i.e. below the rounding of an fp32 FMA chain.  6 bf16 MFMAs of 16 cycles replace 16 fp32 MFMAs of 32: 0.1875 x the matrix
+// time per product.  TERMS = 3 / 9 are measurement variants (tools/bench_sconv.py).
+//
+// Once the matrix pipe is out of the way the per-wave kernel of sconv.hip is bound by its W fragments (every wave re-reads
+// W[k][cb] for every 16 rows: 3 x more bytes than the rows it gathers), so the decomposition changes as well:
+//   * a WORKGROUP of NW waves owns NW*G consecutive row groups (rowgroup.hip: 16 output rows each, sorted by neighbour mask
+//     inside a window, so consecutive groups have nearly the same offsets present) and ALL output columns;
+//   * the workgroup walks the UNION of its groups' offsets k and the 32-channel blocks cb in lock-step.  Per step the slab
+//     W[k][cb][all columns] (hi|mid|lo fragments, 192*COUT bytes) is copied ONCE per workgroup global -> LDS by LDS-DMA
+//     (buffer_load_dwordx4 ... lds, lane-linear = fragment order) and every wave reads its B fragments from there;
+//   * every wave gathers the rows of its own G groups by LDS-DMA in full 128-byte lines (structured buffer: vindex = the
+//     neighbour row from the table, -1 = absent = out of range = zeros without traffic; XOR-swizzled source chunk so that
+//     the lane-linear LDS image is conflict-free for the ds_read_b128 fragment reads), splits them ONCE in registers
+//     (44 VALU per group and step) and feeds the MFMAs of all COUT/32 column slices;
+//   * DMA of step i+LA is issued at the start of step i (LA = DA-1 ring slots of look-ahead); a wave waits for its own
+//     pieces of step i+1 at the end of step i and one s_barrier per step publishes the slab (and retires the slab that is
+//     overwritten next);
+//   * a group that lacks the offset skips the step's split and MFMAs (wave-uniform branch).
+// Every output row is produced by one wave, summed in ascending k, ascending channel block, fixed term order: results do not
+// depend on the batch, the grouping of other rows or eager vs graph execution (bitwise reproducible, batch-invariant).
+// The compiler does not know that an LDS-DMA write feeds a later ds_read (it would drain vmcnt(0) in front of any LDS read
+// it can see), so every LDS read of the step loop is issued from asm with its own counted waits.
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include <hip/hip_ext.h>
+#include "kernels.h"
+
+namespace egonn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// channel of the 32-channel block that lane group g (= lane >> 4) holds in element e of its 8-element MFMA operand: the two
+// 16-byte chunks g and 4+g of the gathered 128-byte row (the conflict-free ds_read_b128 pattern of the swizzled image)
+__host__ __device__ static inline int sp_chan(int g, int e) { return e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4); }
+
+__device__ static inline uint32_t bf16_rn_bits(float a) {
+  uint32_t u = __float_as_uint(a);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// ------------------------------------------------------------------ weight packing
+// W[k][ci][co] -> Wsp[k][cb][ns][f][lane][e] (bf16), f = 2*part + nt, part: 0 hi, 1 mid, 2 lo
+//   = part( W[k][32cb + sp_chan(lane>>4, e)][32ns + 16nt + (lane&15)] )
+// so that the slab of a step (k, cb) is one contiguous block of COUT/32 * 6 KB and every 1 KB piece is one lane-linear
+// MFMA A-operand fragment.  flip / transpose: as pack_rg_weights (input-gradient kernels, k=2 <-> transposed pairs).
+__global__ void pack_split_weights_kernel(const float* __restrict__ W, int K, int cin, int cout, int flip, int transpose,
+                                          uint16_t* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per_k = (int64_t)cin * cout;
+  if (t >= K * per_k * 3) return;
+  const int ncb = cin / 32, ns_n = cout / 32;
+  int64_t r = t;
+  const int e = (int)(r & 7); r >>= 3;
+  const int lane = (int)(r & 63); r >>= 6;
+  const int f = (int)(r % 6); r /= 6;
+  const int ns = (int)(r % ns_n); r /= ns_n;
+  const int cb = (int)(r % ncb); r /= ncb;
+  const int k = (int)r;
+  const int part = f >> 1, nt = f & 1;
+  const int ci = 32 * cb + sp_chan(lane >> 4, e);
+  const int co = 32 * ns + 16 * nt + (lane & 15);
+  const int ks = flip ? K - 1 - k : k;
+  const float v = transpose ? W[(int64_t)ks * per_k + (int64_t)co * cin + ci] : W[(int64_t)ks * per_k + (int64_t)ci * cout + co];
+  const uint32_t hi = bf16_rn_bits(v);
+  const float r1 = v - __uint_as_float(hi << 16);
+  const uint32_t mid = bf16_rn_bits(r1);
+  const float r2 = r1 - __uint_as_float(mid << 16);
+  const uint32_t lo = bf16_rn_bits(r2);                  // exact: r2 has <= 8 significant bits
+  out[t] = (uint16_t)(part == 0 ? hi : (part == 1 ? mid : lo));
+}
+
+int pack_split_weights(const float* W, int K, int cin, int cout, int flip, int transpose, void* out, hipStream_t stream) {
+  EGONN_REQUIRE(cin % 32 == 0 && cout % 32 == 0, EGONN_ERR_INVALID, "sconv: channel counts must be multiples of 32 (%d->%d)", cin, cout);
+  const int64_t n = (int64_t)K * cin * cout * 3;
+  hipLaunchKernelGGL(pack_split_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, W, K, cin, cout, flip,
+                     transpose, reinterpret_cast<uint16_t*>(out));
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ the kernel
+struct SplitArgs {
+  const float* in;           // [n_in][CIN] fp32
+  const int32_t* snbr;       // row-group tables
+  const uint32_t* gmask;
+  const int32_t* perm;
+  const int32_t* meta;       // [0] = groups in use
+  const void* Wsp;           // pack_split_weights
+  const float* scale;        // folded BatchNorm (nullable)
+  const float* shift;
+  float* out;                // [n_out][COUT]
+  float* psum;               // [groups][COUT] column sums of the stored values (nullable)
+  uint32_t in_rows, w_bytes;
+  int K, relu, cap_groups;
+};
+
+__device__ static inline float sp_row16_sum(float v) {   // sum over the 16 lanes of a DPP row (= the 16 rows of a tile)
+  int x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));   // row_half_mirror
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
+// fp32 x 8 -> (hi, mid, lo) bf16 x 8, round to nearest even at every level (v_cvt_pk_bf16_f32): 44 VALU
+__device__ static inline void split8(const f32x4& a0, const f32x4& a1, bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
+  uint32_t h[4], m[4], l[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float x0 = p < 2 ? a0[2 * p] : a1[2 * p - 4], x1 = p < 2 ? a0[2 * p + 1] : a1[2 * p - 3];
+    const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){x0, x1}, bf16x2_t));
+    const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xFFFF0000u);
+    const uint32_t mp = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){r0, r1}, bf16x2_t));
+    const float s0 = r0 - __uint_as_float(mp << 16), s1 = r1 - __uint_as_float(mp & 0xFFFF0000u);
+    h[p] = hp;
+    m[p] = mp;
+    l[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){s0, s1}, bf16x2_t));
+  }
+  hi = __builtin_bit_cast(bf16x8_t, (uint4){h[0], h[1], h[2], h[3]});
+  mid = __builtin_bit_cast(bf16x8_t, (uint4){m[0], m[1], m[2], m[3]});
+  lo = __builtin_bit_cast(bf16x8_t, (uint4){l[0], l[1], l[2], l[3]});
+}
+
+template <int COUT, int G, int NW, int DA>
+struct SplitGeom {
+  static constexpr int NS = COUT / 32;
+  static constexpr int SLAB = NS * 6144;                 // bytes of W[k][cb][all columns], three parts
+  static constexpr int NPIECE = NS * 6;                  // 1 KB DMA pieces per slab
+  static constexpr int WPP = (NPIECE + NW - 1) / NW;     // pieces a wave issues per step
+  static constexpr int NV = WPP + 2 * G;                 // vector-memory instructions per wave and step
+  static constexpr int TROW = 28 * 16;                   // ints per group table (27 offsets x 16 slots, padded)
+  static constexpr int TBL_BYTES = G * TROW * 4 + 128;   // + the all-absent row
+  static constexpr int RING_BYTES = DA * G * 2048;       // gathered rows: 16 x 128 B per group and slot
+  static constexpr int WAVE_LDS = TBL_BYTES + RING_BYTES;
+  static constexpr int SCRATCH = DA * SLAB;              // target of surplus (out-of-range) DMA pieces
+  static constexpr int WAVES_AT = SCRATCH + 1024;
+  static constexpr int LDS_BYTES = WAVES_AT + NW * WAVE_LDS;
+};
+
+template <int CIN, int COUT, int G, int NW, int DA, int TERMS>
+__global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p) {
+  using GEO = SplitGeom<COUT, G, NW, DA>;
+  constexpr int NS = GEO::NS, NCB = CIN / 32;
+  constexpr int SLAB = GEO::SLAB, NPIECE = GEO::NPIECE, WPP = GEO::WPP, NV = GEO::NV, TROW = GEO::TROW;
+  constexpr int LA = DA - 1;                             // steps of look-ahead
+  static_assert(DA == 2 || DA == 3, "ring depth");
+  static_assert(GEO::LDS_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(TERMS == 3 || TERMS == 6 || TERMS == 9, "terms");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  typedef __attribute__((address_space(3))) char lds_char;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int K = p.K;
+  char* const wl = smem + GEO::WAVES_AT + wave * GEO::WAVE_LDS;
+  int32_t* const tbl = reinterpret_cast<int32_t*>(wl);
+  char* const ring = wl + GEO::TBL_BYTES;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)(lds_char*)smem;
+  const uint32_t wl_addr = (uint32_t)(uintptr_t)(lds_char*)wl;
+  // operand read addresses inside a gathered group image: chunks g4 and 4+g4 of row l15 (XOR swizzle on the chunk index)
+  const uint32_t rd0 = wl_addr + GEO::TBL_BYTES + (uint32_t)(l15 * 128 + ((g4 ^ (l15 & 7)) * 16));
+  const uint32_t rd1 = wl_addr + GEO::TBL_BYTES + (uint32_t)(l15 * 128 + (((4 + g4) ^ (l15 & 7)) * 16));
+  const uint32_t tb0 = wl_addr + (uint32_t)((lane >> 3) * 4);          // table row entry of this lane's DMA rows (L>>3, 8+(L>>3))
+  const uint32_t wrd = smem_addr + (uint32_t)(lane * 16);              // fragment read address inside a slab piece
+  const int dma_chunk = ((lane & 7) ^ (lane >> 3)) * 16;
+  const int w_lane = lane * 16;
+  const int w_oob = (int)(0x80000000u | (uint32_t)(lane * 16));
+
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), (short)(CIN * 4), (int)p.in_rows, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wsp), 0, (int)p.w_bytes, 0x00020000);
+
+  const int ngroups = __builtin_amdgcn_readfirstlane(min(p.meta[0], p.cap_groups));
+  constexpr int GPT = NW * G;                            // groups per task
+  const int ntask = (ngroups + GPT - 1) / GPT;
+  // contiguous eighth of the tasks per XCD (block b runs on XCD b % 8): a Z-order slice of the map per L2
+  const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3;
+  const int cpx = (ntask + 7) >> 3;
+
+  for (int lt = blockIdx.x >> 3; lt < cpx; lt += nper) {
+    const int task = xcd * cpx + lt;
+    if (task >= ntask) continue;                         // workgroup-uniform
+    const int g0 = task * GPT;
+    const int gw = g0 + wave * G;                        // first group of this wave
+    // ---- masks: union over the workgroup (identical in every wave), own groups
+    uint32_t mload = 0;
+    if (lane < GPT && g0 + lane < ngroups) mload = p.gmask[g0 + lane];
+    uint32_t U = mload;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) U |= (uint32_t)__shfl_xor((int)U, o, 64);
+    U = __builtin_amdgcn_readfirstlane(U);
+    if (!(U >> 31)) continue;                            // nothing but padding groups
+    uint32_t gm[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) gm[j] = (uint32_t)__builtin_amdgcn_readlane((int)mload, wave * G + j);
+
+    // ---- the groups' neighbour tables -> wave-private LDS; output rows of the epilogue
+    int32_t orow[G];
+    {
+      const int n16 = K * 4;
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const bool live = (gm[j] >> 31) != 0;
+        const int4* src = reinterpret_cast<const int4*>(p.snbr + (int64_t)(gw + j) * K * 16);
+        int4 v0 = make_int4(-1, -1, -1, -1), v1 = make_int4(-1, -1, -1, -1);
+        if (live && lane < n16) v0 = src[lane];
+        if (live && lane + 64 < n16) v1 = src[lane + 64];
+        orow[j] = live ? p.perm[(int64_t)(gw + j) * 16 + l15] : -1;
+        int4* dst = reinterpret_cast<int4*>(tbl + j * TROW);
+        dst[lane] = v0;
+        if (lane + 64 < TROW / 4) dst[lane + 64] = v1;
+      }
+      if (lane < 8) reinterpret_cast<int4*>(tbl + G * TROW)[lane] = make_int4(-1, -1, -1, -1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+
+    // ---- step generator (scalar, identical in every wave): set bits of the union x channel blocks
+    uint32_t mk = U & 0x07FFFFFFu;
+    const int n_steps = __popc(mk) * NCB;
+    int gen_k = 0, gen_cb = 0;
+    auto gen = [&](int& k, int& acb, int& woff) {          // k = 27: step past the end (no traffic, no arithmetic)
+      const bool need = (gen_cb == 0);
+      const bool take = need && (mk != 0);
+      const bool valid = !need || take;
+      gen_k = take ? __builtin_ctz(mk | 0x80000000u) : gen_k;
+      mk = take ? (mk & (mk - 1)) : mk;
+      k = valid ? gen_k : 27;
+      acb = gen_cb * 128;
+      woff = valid ? (gen_k * NCB + gen_cb) * SLAB : -1;
+      gen_cb = (valid && gen_cb + 1 < NCB) ? gen_cb + 1 : 0;
+    };
+    // neighbour rows of a step for this lane's two DMA pieces per group (issued; awaited by idx_wait)
+    auto idx_issue = [&](int k, int32_t (&i0)[G], int32_t (&i1)[G]) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const uint32_t tb = tb0 + (uint32_t)((k < 27 ? j * TROW + k * 16 : G * TROW) * 4);
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:32" : "=&v"(i0[j]), "=&v"(i1[j]) : "v"(tb) : "memory");
+      }
+    };
+    auto idx_wait = [&](int32_t (&i0)[G], int32_t (&i1)[G]) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(i0[j]), "+v"(i1[j])::"memory");
+    };
+    // DMA of one step into ring slot S: this wave's pieces of the slab, the rows of its groups
+    auto issue = [&](auto S, int acb, int woff, const int32_t (&i0)[G], const int32_t (&i1)[G]) {
+      constexpr int s = decltype(S)::value;
+#pragma unroll
+      for (int q = 0; q < WPP; ++q) {
+        const int pc = wave + NW * q;
+        const bool ok = (NPIECE % NW == 0 || pc < NPIECE) && woff >= 0;
+        const int vo = ok ? w_lane : w_oob;
+        const int so = ok ? woff + pc * 1024 : 0;
+        char* dst = ok ? smem + s * SLAB + pc * 1024 : smem + GEO::SCRATCH;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_char*)dst, 16, vo, so, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int32_t r0 = i0[j], r1 = i1[j];        // (an array-reference element as a builtin argument fails the host-side instantiation)
+        __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(ring + (s * G + j) * 2048), 16, r0, dma_chunk, acb, 0, 0);
+        __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(ring + (s * G + j) * 2048 + 1024), 16, r1, dma_chunk, acb, 0, 0);
+      }
+    };
+
+    f32x4 acc[G][NS][2];
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[j][ns][0] = acc[j][ns][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto wread = [&](auto S, auto NSI, f32x4 (&w)[6]) {      // the six fragments of column slice NSI of slab S (issued)
+      constexpr int off = decltype(NSI)::value * 6144;
+      static_assert(off + 5 * 1024 < 65536, "ds_read offset field");
+      const uint32_t a = wrd + (uint32_t)(decltype(S)::value * SLAB);
+      asm volatile(
+          "ds_read_b128 %0, %6 offset:%7\n\t"
+          "ds_read_b128 %1, %6 offset:%7+1024\n\t"
+          "ds_read_b128 %2, %6 offset:%7+2048\n\t"
+          "ds_read_b128 %3, %6 offset:%7+3072\n\t"
+          "ds_read_b128 %4, %6 offset:%7+4096\n\t"
+          "ds_read_b128 %5, %6 offset:%7+5120"
+          : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5])
+          : "v"(a), "n"(off)
+          : "memory");
+    };
+    auto wwait = [&](f32x4 (&w)[6]) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5])::"memory");
+    };
+    auto mfma = [](const f32x4& wf, const bf16x8_t& af, f32x4& c) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), af, c, 0, 0, 0);
+    };
+
+    // ---- one step: rows of slot S (offset k) x slab S
+    auto compute = [&](auto S, int k) {
+      constexpr int s = decltype(S)::value;
+      bool has[G];
+      f32x4 ra0[G], ra1[G];
+      f32x4 w[6];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        has[j] = ((gm[j] >> k) & 1u) != 0;
+        const uint32_t r0 = rd0 + (uint32_t)((s * G + j) * 2048), r1 = rd1 + (uint32_t)((s * G + j) * 2048);
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(ra0[j]), "=&v"(ra1[j]) : "v"(r0), "v"(r1) : "memory");
+      }
+      wread(S, std::integral_constant<int, 0>{}, w);
+#pragma unroll
+      for (int j = 0; j < G; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0[j]), "+v"(ra1[j])::"memory");
+      wwait(w);
+      bf16x8_t ah[G], am[G], al[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+        if (has[j]) split8(ra0[j], ra1[j], ah[j], am[j], al[j]);
+      [&]<int... NSI>(std::integer_sequence<int, NSI...>) {
+        (([&] {
+           f32x4 wn[6];
+           if constexpr (NSI + 1 < NS) wread(S, std::integral_constant<int, NSI + 1>{}, wn);
+           __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+           for (int j = 0; j < G; ++j) {
+             if (!has[j]) continue;                      // wave-uniform
+             // small terms first; w[2*part + nt]
+             if constexpr (TERMS >= 9) {
+               mfma(w[4], al[j], acc[j][NSI][0]); mfma(w[5], al[j], acc[j][NSI][1]);      // lo * lo
+               mfma(w[4], am[j], acc[j][NSI][0]); mfma(w[5], am[j], acc[j][NSI][1]);      // lo * mid
+               mfma(w[2], al[j], acc[j][NSI][0]); mfma(w[3], al[j], acc[j][NSI][1]);      // mid * lo
+             }
+             if constexpr (TERMS >= 6) {
+               mfma(w[4], ah[j], acc[j][NSI][0]); mfma(w[5], ah[j], acc[j][NSI][1]);      // w lo * a hi
+               mfma(w[0], al[j], acc[j][NSI][0]); mfma(w[1], al[j], acc[j][NSI][1]);      // w hi * a lo
+               mfma(w[2], am[j], acc[j][NSI][0]); mfma(w[3], am[j], acc[j][NSI][1]);      // mid * mid
+             }
+             mfma(w[2], ah[j], acc[j][NSI][0]); mfma(w[3], ah[j], acc[j][NSI][1]);        // w mid * a hi
+             mfma(w[0], am[j], acc[j][NSI][0]); mfma(w[1], am[j], acc[j][NSI][1]);        // w hi * a mid
+             mfma(w[0], ah[j], acc[j][NSI][0]); mfma(w[1], ah[j], acc[j][NSI][1]);        // hi * hi
+           }
+           __builtin_amdgcn_sched_barrier(0);
+           if constexpr (NSI + 1 < NS) {
+             wwait(wn);
+#pragma unroll
+             for (int i = 0; i < 6; ++i) w[i] = wn[i];
+           }
+         }()), ...);
+      }(std::make_integer_sequence<int, NS>{});
+    };
+
+    // ---- prologue: steps 0..LA-1 in flight, rows of step LA read
+    int kring[DA];
+    int pend_acb, pend_woff, pend_k;
+    int32_t pi0[G], pi1[G];
+    {
+      int k, acb, woff;
+      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        (([&] {
+           gen(k, acb, woff);
+           idx_issue(k, pi0, pi1);
+           idx_wait(pi0, pi1);
+           issue(std::integral_constant<int, Is>{}, acb, woff, pi0, pi1);
+           kring[Is] = k;
+         }()), ...);
+      }(std::make_integer_sequence<int, LA>{});
+      gen(pend_k, pend_acb, pend_woff);
+      idx_issue(pend_k, pi0, pi1);
+      idx_wait(pi0, pi1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * NV) : "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    // ---- main loop, unrolled by the ring depth
+    const int n_iter = (n_steps + DA - 1) / DA;
+    for (int it = 0; it < n_iter; ++it) {
+      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        (([&] {
+           constexpr int si = (Is + LA) % DA;            // slot of the step issued now
+           issue(std::integral_constant<int, si>{}, pend_acb, pend_woff, pi0, pi1);
+           kring[si] = pend_k;
+           gen(pend_k, pend_acb, pend_woff);
+           int32_t n0[G], n1[G];
+           idx_issue(pend_k, n0, n1);
+           __builtin_amdgcn_sched_barrier(0);
+           compute(std::integral_constant<int, Is>{}, kring[Is]);
+           __builtin_amdgcn_sched_barrier(0);
+           idx_wait(n0, n1);
+#pragma unroll
+           for (int j = 0; j < G; ++j) { pi0[j] = n0[j]; pi1[j] = n1[j]; }
+           asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * NV) : "memory");
+           __builtin_amdgcn_s_barrier();
+         }()), ...);
+      }(std::make_integer_sequence<int, DA>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // steps past the end are still landing
+
+    // ---- epilogue: BN scale/shift (+ReLU), one 16-byte store per tile; optional per-group column sums
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      if (!(gm[j] >> 31)) continue;
+      const int32_t row = orow[j];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        float sums[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int c0 = ns * 32 + nt * 16 + 4 * g4;
+          f32x4 v = acc[j][ns][nt];
+          if (p.scale) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c0);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + c0);
+            v = v * sc + sh;
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+          }
+          if (row >= 0) *reinterpret_cast<f32x4*>(p.out + (int64_t)row * COUT + c0) = v;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sums[nt][u] = row >= 0 ? v[u] : 0.f;
+        }
+        if (p.psum) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sums[nt][u] = sp_row16_sum(sums[nt][u]);
+          if (l15 == 0) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              *reinterpret_cast<f32x4*>(p.psum + (int64_t)(gw + j) * COUT + ns * 32 + nt * 16 + 4 * g4) =
+                  (f32x4){sums[nt][0], sums[nt][1], sums[nt][2], sums[nt][3]};
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_barrier();                        // the next task rewrites tables and slabs
+  }
+}
+
+template <int CIN, int COUT, int G, int NW, int DA, int TERMS>
+static int launch_split(const SplitArgs& a, int64_t groups_hint, hipStream_t stream) {
+  using GEO = SplitGeom<COUT, G, NW, DA>;
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_split_kernel<CIN, COUT, G, NW, DA, TERMS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  const int64_t ntask = cdiv(groups_hint, NW * G);
+  int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 65536);
+  grid = (grid + 7) / 8 * 8;
+  hipEvent_t* pev = prof_kernel_events();
+  if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
+    hipExtLaunchKernelGGL((sconv_split_kernel<CIN, COUT, G, NW, DA, TERMS>), dim3((unsigned)grid), dim3(NW * 64), GEO::LDS_BYTES, stream,
+                          pev[0], pev[1], 0, a);
+    pev[0] = pev[1] = nullptr;
+  } else {
+    hipLaunchKernelGGL((sconv_split_kernel<CIN, COUT, G, NW, DA, TERMS>), dim3((unsigned)grid), dim3(NW * 64), GEO::LDS_BYTES, stream, a);
+  }
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+bool sconv_split_supported(int cin, int cout) {
+  auto ok = [](int c) { return c == 32 || c == 64 || c == 128; };
+  return ok(cin) && ok(cout);
+}
+
+// cfg = terms_sel * 1000 + G * 100 + NW * 10 + DA (terms_sel 0: 6 terms, 1: 3, 2: 9); 0 = product choice
+int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
+                        int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
+                        int cfg) {
+  EGONN_REQUIRE(rg.built, EGONN_ERR_STATE, "sconv: row-group tables not built");
+  EGONN_REQUIRE(sconv_split_supported(cin, cout), EGONN_ERR_INVALID, "sconv(split): channel plan %d->%d not supported", cin, cout);
+  EGONN_REQUIRE((uint64_t)n_in_cap * cin * 4 < (1ull << 32) - (1ull << 20), EGONN_ERR_INVALID,
+                "sconv: input feature map of %lld rows exceeds the 4 GiB buffer-resource range", (long long)n_in_cap);
+  if (groups_hint <= 0) return EGONN_OK;
+  SplitArgs a;
+  a.in = in; a.snbr = rg.snbr; a.gmask = rg.gmask; a.perm = rg.perm; a.meta = rg.meta; a.Wsp = Wsp;
+  a.scale = scale; a.shift = shift; a.out = out; a.psum = psum;
+  a.in_rows = (uint32_t)n_in_cap;
+  a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * 6);
+  a.K = rg.K; a.relu = relu ? 1 : 0; a.cap_groups = rg.cap_groups;
+  if (cfg == 0) cfg = sconv_split_default_cfg(cin, cout, groups_hint);
+  const int terms = cfg / 1000, shape = cfg % 1000;
+#define EGONN_SP_SHAPE(CI, CO, GG, NWW, DAA)                                                              \
+  if (cin == CI && cout == CO && shape == GG * 100 + NWW * 10 + DAA) {                                    \
+    if (terms == 0) return launch_split<CI, CO, GG, NWW, DAA, 6>(a, groups_hint, stream);                 \
+  }
+#define EGONN_SP_TERMS(CI, CO, GG, NWW, DAA)                                                              \
+  if (cin == CI && cout == CO && shape == GG * 100 + NWW * 10 + DAA) {                                    \
+    if (terms == 1) return launch_split<CI, CO, GG, NWW, DAA, 3>(a, groups_hint, stream);                 \
+    if (terms == 2) return launch_split<CI, CO, GG, NWW, DAA, 9>(a, groups_hint, stream);                 \
+  }
+#define EGONN_SP_PLAN(CI, CO)        \
+  EGONN_SP_SHAPE(CI, CO, 1, 8, 3)    \
+  EGONN_SP_SHAPE(CI, CO, 2, 8, 2)    \
+  EGONN_SP_SHAPE(CI, CO, 1, 4, 3)    \
+  EGONN_SP_SHAPE(CI, CO, 2, 4, 3)
+  EGONN_SP_PLAN(32, 32)
+  EGONN_SP_PLAN(32, 64)
+  EGONN_SP_PLAN(64, 64)
+  EGONN_SP_PLAN(64, 128)
+  EGONN_SP_PLAN(128, 128)
+  EGONN_SP_PLAN(64, 32)
+  EGONN_SP_PLAN(128, 64)
+  EGONN_SP_SHAPE(32, 32, 2, 8, 3)
+  EGONN_SP_SHAPE(32, 32, 4, 4, 2)
+  EGONN_SP_TERMS(64, 64, 1, 8, 3)
+  EGONN_SP_TERMS(32, 32, 1, 8, 3)
+#undef EGONN_SP_PLAN
+#undef EGONN_SP_SHAPE
+#undef EGONN_SP_TERMS
+  set_error("sconv(split): no instantiation for %d->%d cfg %d", cin, cout, cfg);
+  return EGONN_ERR_INVALID;
+}
+
+int sconv_split_default_cfg(int cin, int cout, int64_t groups_hint) {
+  (void)cin; (void)cout; (void)groups_hint;
+  return 183;                                            // G = 1, 8 waves, 3 ring slots
+}
+
+}  // namespace egonn

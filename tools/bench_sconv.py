@@ -48,7 +48,9 @@ for (kind, lvl, ci, co) in cfgs:
     want = ref.sparse_conv(kind, lvl, x, w) if (n_out * co * K < 6e8 and not quick) else None
     ng = ctx.map_groups(kind, lvl)[0]
     variants = [int(v) for v in os.environ["AB"].split(",")] if os.environ.get("AB") else [0]
-    for dt, var in [(d, v) for d in (torch.float32, torch.bfloat16) for v in variants]:
+    dts = (torch.float32,) if os.environ.get("F32ONLY") else (torch.float32, torch.bfloat16)
+    for dt, var in [(d, v) for d in dts for v in variants]:
+        if var >= 1000 and dt != torch.float32: continue
         ctx.lib.egonn_debug_set_naive_conv(ctx.h, var)
         xx = x.to(dt).contiguous()
         got = ctx.sparse_conv(kind, lvl, xx, w)
