@@ -1183,8 +1183,10 @@ const char* sconv_kernel_name(int cin, int cout, int bf16, int64_t groups_hint, 
 bool sconv_uses_split(int cin, int cout, int bf16, int64_t groups_hint, int variant) {
   if (bf16 || !sconv_split_supported(cin, cout)) return false;
   if (variant >= 1000) return true;
-  (void)groups_hint;
-  return false;
+  if (variant != 0) return false;
+  // product choice (tools/bench_sconv.py, profiles/r03d_lock_ab.json): the lock-step split kernel wins on the launches that
+  // fill the chip several times over; below that the exact kernels' K-split waves hide more latency
+  return groups_hint >= 4096;
 }
 
 int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, const void* Wsp, int cin, int cout,

@@ -30,7 +30,7 @@ for d in sorted(glob.glob("gpurun_out/sw*/")):
     if not dbs: continue
     c = sqlite3.connect(dbs[0])
     for name, cn, v in c.execute("select kernel_name, counter_name, avg(value) from counters_collection group by kernel_name, counter_name"):
-        m = re.search(r"sconv_(rg|dma|wg)_kernel<[^>]*>|conv0_k5_kernel<[^>]*>", name)
+        m = re.search(r"sconv_(rg|dma|wg|split|wide)_kernel<[^>]*>|conv0_k5_kernel<[^>]*>", name)
         if m: res[m.group(0).replace(" ", "")][cn] = v
 for k, d in res.items():
     print(k)
