@@ -117,6 +117,7 @@ struct RGBuild {
   const int32_t* nbr;         // [n][K] kernel map
   const int32_t* n_dev;       // device: rows of the output level
   const int32_t* boff;        // device: [B+1] per-sample offsets of the output level
+  int32_t cap_rows = 0;       // rows the level's arrays (and the map) can hold: rows beyond it are never touched
 };
 int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream);
 

@@ -491,8 +491,10 @@ __global__ __launch_bounds__(256) void nbr27_kernel(const Nbr27Pair a) {
   // of latencies at full occupancy (a block has ~6 voxels), so the number of dependent trips is its run time.
   // (Measured and rejected: persistent workgroups with the loads issued one block ahead and a (position, offset) lookup
   // table in LDS — 70 vs 62 us per step at batch 16, 136 vs 143 at batch 64.)
-  const int32_t s = bstart[j];
-  const int32_t e = (j + 1 < nblocks) ? bstart[j + 1] : nvox;
+  // (clamped: when level `level` overflows its reservation but level + 2 does not, bstart still holds unclipped rows
+  //  and the table write below would leave the cap_vox x 27 allocation)
+  const int32_t s = min(bstart[j], nvox);
+  const int32_t e = min((j + 1 < nblocks) ? bstart[j + 1] : nvox, nvox);
   const int32_t idx = (lane < 27) ? badj[(int64_t)j * 27 + lane] : -1;
   const int32_t items = (e - s) * 27;
   uint64_t key0 = 0;                                      // key of the voxel of this lane's first (voxel, offset) slot
@@ -927,6 +929,7 @@ int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, h
     jobs[nj].nbr = nbr;
     jobs[nj].n_dev = ctx->dev_counts + l;
     jobs[nj].boff = V.boff;
+    jobs[nj].cap_rows = (int32_t)P.cap[l];
     ++nj;
   }
   if (nj == 0) return EGONN_OK;

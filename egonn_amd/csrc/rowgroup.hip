@@ -47,6 +47,8 @@ struct RGJob {
   uint32_t* gmask;
   int32_t* meta;            // [0] = number of groups, [1 + b] = first group of sample b (b = 0..B)
   int K, win, wbase;        // wbase: first block of this job in the launch
+  int cap_rows, cap_groups; // capacity of the level / of the tables: a batch that exceeds a reservation is clipped, never
+                            // written out of bounds (egonn_plan_status reports it)
 };
 struct RGArgs {
   RGJob job[RG_MAX_JOBS];
@@ -84,13 +86,15 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
   const RGJob& J = a.job[j];
   const int w = blockIdx.x - J.wbase;
   const int K = J.K, WIN = J.win, GPW = WIN / 16, B = a.B;
+  const int nlim = min(*J.n_dev, J.cap_rows);           // rows that exist: per-sample offsets are clipped to it
+  auto boff_at = [&](int b) { return min(J.boff[b], nlim); };
 
   // ---- window -> (sample, first row); wave 0 scans the samples 64 at a time
   if (tid < 64) {
     int cum = 0, found_b = -1, found_first = 0;
     for (int b0 = 0; b0 < B; b0 += 64) {
       const int b = b0 + lane;
-      const int nb = (b < B) ? (J.boff[b + 1] - J.boff[b]) : 0;
+      const int nb = (b < B) ? (boff_at(b + 1) - boff_at(b)) : 0;
       const int nw = (nb + WIN - 1) / WIN;
       int incl = nw;
 #pragma unroll
@@ -99,13 +103,13 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
         if (lane >= o) incl += v;
       }
       const int first = cum + incl - nw;
-      if (w == 0 && b < B) J.meta[1 + b] = first * GPW;
+      if (w == 0 && b < B) J.meta[1 + b] = min(first * GPW, J.cap_groups);
       if (b < B && w >= first && w < first + nw) { found_b = b; found_first = first; }
       cum += __shfl(incl, 63, 64);
     }
     if (w == 0 && lane == 0) {
-      J.meta[0] = cum * GPW;
-      J.meta[1 + B] = cum * GPW;
+      J.meta[0] = min(cum * GPW, J.cap_groups);
+      J.meta[1 + B] = min(cum * GPW, J.cap_groups);
     }
     // exactly one lane (or none) found the window
     const unsigned long long m = __ballot(found_b >= 0);
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
   __syncthreads();
   const int sb = s_info[0];
   if (sb < 0) return;                                   // window slot beyond the last sample
-  const int r0 = J.boff[sb] + (w - s_info[1]) * WIN;
-  const int rows = min(WIN, J.boff[sb + 1] - r0);
+  const int r0 = boff_at(sb) + (w - s_info[1]) * WIN;
+  const int rows = min(WIN, boff_at(sb + 1) - r0);
 
   stamp(1);
   // ---- the window's table -> LDS (coalesced dword loads; rows beyond the sample are never indexed)
@@ -273,6 +277,8 @@ int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream) {
     J.nbr = b.nbr; J.n_dev = b.n_dev; J.boff = b.boff;
     J.perm = b.rg->perm; J.snbr = b.rg->snbr; J.gmask = b.rg->gmask; J.meta = b.rg->meta;
     J.K = b.rg->K; J.win = b.rg->win; J.wbase = nb;
+    J.cap_rows = b.cap_rows > 0 ? b.cap_rows : INT32_MAX;
+    J.cap_groups = b.rg->cap_groups;
     nb += b.rg->cap_groups / (b.rg->win / 16);
   }
   a.nblocks = nb;

@@ -32,6 +32,7 @@
 // workgroup (workgroup = the KSP waves of a tile), and every XCD takes a contiguous eighth of the tasks (block b runs on
 // XCD b % 8: consecutive groups — Z-order neighbours — share an L2).
 // Optional epilogue: per-group column sums of the stored values (fixed order) for the ECA / GeM pooling.
+#include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
 #include <utility>
@@ -117,6 +118,7 @@ struct SconvArgs {
   float* psum;               // [groups][COUT] column sums of the stored values (nullable)
   uint32_t in_bytes, w_bytes;
   int K, relu;
+  int cap_groups = 0;                    // groups the tables hold: meta[0] is clipped to it (a batch beyond its reservation)
   unsigned long long* trace = nullptr;   // measurement builds only (tools/sconv_trace.py): 8 u64 per wave task
 };
 
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_rg_kernel(const SconvArgs p) {
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wp), 0, (int)p.w_bytes, 0x00020000);
 
-  const int ngroups = __builtin_amdgcn_readfirstlane(p.meta[0]);       // a multiple of 16
+  const int ngroups = __builtin_amdgcn_readfirstlane(min(p.meta[0], p.cap_groups));   // a multiple of 16
   const int ntiles = (ngroups / G) * NS;
   const int ntask = (ntiles + TPW - 1) / TPW;            // workgroup tasks
   // every XCD (block b runs on XCD b % 8) takes one contiguous eighth of the tasks: its slice of the feature map
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_dma_kernel(const SconvArgs p) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), (short)(CIN * 4), (int)(p.in_bytes / (CIN * 4)), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wp), 0, (int)p.w_bytes, 0x00020000);
 
-  const int ngroups = __builtin_amdgcn_readfirstlane(p.meta[0]);
+  const int ngroups = __builtin_amdgcn_readfirstlane(min(p.meta[0], p.cap_groups));
   const int ntiles = ngroups * NS;
   const int ntask = (ntiles + TPW - 1) / TPW;
   // one workgroup per task (the hardware dispatcher balances the uneven tasks), contiguous eighth of the tasks per XCD.
@@ -836,7 +838,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_wg_kernel(const SconvArgs p) {
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wp), 0, (int)p.w_bytes, 0x00020000);
 
-  const int ngroups = __builtin_amdgcn_readfirstlane(p.meta[0]);
+  const int ngroups = __builtin_amdgcn_readfirstlane(min(p.meta[0], p.cap_groups));
   const int ntask = ngroups / NW;                        // groups in use are a multiple of 16
   const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3; // gridDim.x is a multiple of 8; one contiguous eighth per XCD
   const int cpx = (ntask + 7) >> 3;
@@ -1129,7 +1131,7 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
   a.scale = scale; a.shift = shift; a.out = out; a.psum = psum;
   a.in_bytes = (uint32_t)ib;
   a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * (bf16 ? 2 : 4));
-  a.K = rg.K; a.relu = relu ? 1 : 0;
+  a.K = rg.K; a.relu = relu ? 1 : 0; a.cap_groups = rg.cap_groups;
   a.trace = variant == 9 ? g_sconv_trace : nullptr;
 
   // Measured (profiles/r02b_sconv.json, batch 16): in fp32 the per-wave kernel wins everywhere (the lock-step of the
@@ -1184,9 +1186,15 @@ bool sconv_uses_split(int cin, int cout, int bf16, int64_t groups_hint, int vari
   if (bf16 || !sconv_split_supported(cin, cout)) return false;
   if (variant >= 1000) return true;
   if (variant != 0) return false;
-  // product choice (tools/bench_sconv.py, profiles/r03d_lock_ab.json): the lock-step split kernel wins on the launches that
-  // fill the chip several times over; below that the exact kernels' K-split waves hide more latency
-  return groups_hint >= 4096;
+  // product choice.  One launch alone (tools/bench_sconv.py, profiles/r03d_lock_ab.json) the lock-step split kernel wins
+  // from ~4 000 groups up (L1 k3 60 -> 54 us, L2 64->64 89 -> 79); with four batches in flight it pays much earlier because
+  // it leaves the matrix pipe to the other batches: scans/s at thresholds inf / 4096 / 2000 / 700 / 200 =
+  // 21.8 k / 23.3 k / 24.3 k / 24.8 k / 23.6 k (profiles/r03e_split_threshold.txt)
+  static const int64_t min_groups = [] {                 // EGONN_SPLIT_MIN_GROUPS: measurement override
+    const char* e = getenv("EGONN_SPLIT_MIN_GROUPS");
+    return e ? (int64_t)atoll(e) : (int64_t)700;
+  }();
+  return groups_hint >= min_groups;
 }
 
 int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, const void* Wsp, int cin, int cout,

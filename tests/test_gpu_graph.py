@@ -87,6 +87,32 @@ def test_graph_reports_batches_that_do_not_fit(gpu):
         gx.run(*_batch([1, 2, 3], [10, 10, 10]))   # wrong number of scans
 
 
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 5])
+def test_graph_single_level_overflow_is_clipped(gpu, level):
+    """A batch that exceeds the reservation of ONE level only (the others have room): every table builder and conv kernel
+    clips to the capacity (nbr27 / row-group builder / sconv group counts), the overflow is reported, nothing
+    faults, and the next fitting batch in the same context is bitwise the eager result."""
+    m = _model(gpu, 57)
+    ex = gpu.DescriptorExtractor(m, n_k=32)
+    small = _batch([820, 821], [4000, 4000])
+    big = _batch([822, 823], [20000, 20000])
+    caps = ex.calibrate(big[0], big[1], margin=1.5)
+    tight = ex.calibrate(small[0], small[1], margin=1.05)
+    caps[level] = tight[level]                  # only this level is too small for `big`
+    gx = ex.graph(batch_size=2, max_points=60000, level_capacity=caps)
+    gx.run(*small)
+    gx.status()
+    for _ in range(2):
+        gx.run(*big)
+        with pytest.raises(RuntimeError, match="reserve"):
+            gx.status()
+    out = gx.run(*small)
+    gx.status()
+    want = ex.extract_packed(small[0], small[1], slot=1)
+    for k in KEYS:
+        assert torch.equal(out[k], want[k]), (level, k)
+
+
 def test_config2_bf16_batch64_graph(gpu):
     """BASELINE configs[2]: bf16 feature maps, batch 64 x 50k points, on-device quantisation, captured forward.
     Stated tolerance against the fp32 path on the same clouds: global descriptor 1-cos <= 2e-4, selected local
@@ -274,3 +300,67 @@ def test_topk_radix_select_edge_cases(gpu, k):
         if kk:
             tv = torch.topk(torch.from_numpy(seg), kk, largest=False).values.numpy()
             assert np.array_equal(seg[rows[b, :kk] - off[b]], tv)
+
+
+@pytest.mark.gpu
+def test_split_bf16_conv_matches_exact_fp32(gpu):
+    """The split-bf16 kernels (sconv_split.hip: fp32 operands as hi+mid+lo bf16, six products on the bf16 matrix pipe, fp32
+    accumulate) against the exact fp32 kernels on every instantiated channel plan and map kind: the maximum deviation from
+    the plain one-thread-per-output kernel, relative to the largest output, stays below 3e-6 (measured 5e-7 .. 1.6e-6, the
+    exact MFMA kernel itself: 3e-7 .. 1.2e-6 — both are summation-order noise of fp32 accumulation); the two decompositions
+    of the split kernel (lock-step workgroups of 4 / 8 waves, wave-wide with G = 1 / 2) are bitwise identical, reruns are
+    bitwise identical, the per-group column sums match, and the 9-product variant changes nothing above 1e-7."""
+    B = 4
+    from egonn_amd.synth import lidar_scan
+    scans = [lidar_scan(300 + i, 30000) for i in range(B)]
+    off = [0]
+    for s in scans:
+        off.append(off[-1] + len(s))
+    pts = torch.from_numpy(np.concatenate(scans)).cuda()
+    ctx = gpu._lib.Context(coord_bits=12)
+    ctx.voxelize(pts, off, 0, [0.1])
+    ref = gpu._lib.Context(coord_bits=12)
+    ref.voxelize(pts, off, 0, [0.1])
+    ref.set_naive_conv(True)
+    torch.manual_seed(11)
+    worst = 0.0
+    plans = [(0, 1, 32, 32), (1, 1, 32, 32), (0, 2, 32, 64), (0, 2, 64, 64), (1, 3, 64, 64), (2, 3, 64, 64), (0, 3, 64, 128),
+             (0, 4, 128, 128), (1, 5, 128, 128), (2, 5, 128, 128), (0, 3, 64, 32), (0, 4, 128, 64)]
+    for kind, lvl, ci, co in plans:
+        lin = lvl if kind == 0 else (lvl - 1 if kind == 1 else lvl + 1)
+        K = 27 if kind == 0 else 8
+        x = torch.randn(ctx.level_count(lin), ci, device="cuda") * torch.exp(torch.randn(ci, device="cuda"))   # uneven channel scales
+        w = torch.randn(K, ci, co, device="cuda") / np.sqrt(ci * (9 if K == 27 else 2))
+        sc, sh = torch.rand(co, device="cuda") + 0.5, torch.randn(co, device="cuda") * 0.1
+        want = ref.sparse_conv(kind, lvl, x, w, sc, sh, relu=False)
+        scale = float(want.abs().max())
+        ctx.lib.egonn_debug_set_naive_conv(ctx.h, 16)              # exact fp32 MFMA kernel
+        exact, exact_sums = ctx.sparse_conv(kind, lvl, x, w, sc, sh, relu=False, group_sums=True)
+        ctx.lib.egonn_debug_set_naive_conv(ctx.h, 1142)            # split, lock-step workgroups of 4 waves (the product kernel)
+        got, sums = ctx.sparse_conv(kind, lvl, x, w, sc, sh, relu=False, group_sums=True)
+        again, _ = ctx.sparse_conv(kind, lvl, x, w, sc, sh, relu=False, group_sums=True)
+        assert torch.equal(got, again), (kind, lvl, ci, co)
+        e_split = float((got - want).abs().max()) / scale
+        e_exact = float((exact - want).abs().max()) / scale
+        worst = max(worst, e_split)
+        assert e_split < 3e-6, (kind, lvl, ci, co, e_split, e_exact)
+        assert float((got - exact).abs().max()) / scale < 4e-6, (kind, lvl, ci, co)
+        assert torch.allclose(sums.double().sum(0), got.double().sum(0), rtol=1e-5, atol=1e-2 * max(scale, 1.0))
+        for var in (1182, 1100, 1200):                             # other decompositions of the same arithmetic
+            ctx.lib.egonn_debug_set_naive_conv(ctx.h, var)
+            v, s2 = ctx.sparse_conv(kind, lvl, x, w, sc, sh, relu=False, group_sums=True)
+            assert torch.equal(v, got) and torch.equal(s2, sums), (var, kind, lvl, ci, co)
+    for kind, lvl, ci, co in [(0, 1, 32, 32), (0, 2, 64, 64)]:       # 3 / 9 products (measurement variants)
+        x = torch.randn(ctx.level_count(lvl), ci, device="cuda")
+        w = torch.randn(27, ci, co, device="cuda") / np.sqrt(ci * 9)
+        want = ref.sparse_conv(kind, lvl, x, w)
+        scale = float(want.abs().max())
+        G = 4 if ci == 32 else 2
+        errs = {}
+        for terms, code in ((6, 1000), (3, 2000), (9, 3000)):
+            ctx.lib.egonn_debug_set_naive_conv(ctx.h, code + G * 100)
+            errs[terms] = float((ctx.sparse_conv(kind, lvl, x, w) - want).abs().max()) / scale
+        assert errs[6] < 3e-6 and errs[9] < 3e-6 and abs(errs[9] - errs[6]) < 5e-7, errs
+        assert 1e-6 < errs[3] < 2e-4, errs                          # three products: bf16x3-class (2^-16 relative per product)
+    ctx.lib.egonn_debug_set_naive_conv(ctx.h, 0)
+    print(f"split-bf16 worst relative deviation from the plain fp32 kernel: {worst:.2e}")
