@@ -351,6 +351,11 @@ def main():
                             "kind": "port", "sample": f"{k} scans on the numpy oracle (C oracle unavailable: {e}), "
                                                       f"{c1 - c0:.1f} s of CPU work"}
 
+    rccl_ranks_seen = None
+    if distributed:                                        # an actual RCCL all-reduce over the job's ranks (SUM of ones)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks_seen = int(ones.item())
     if rank == 0:
         total_scans = args.batch * world * args.steps
         cfg = "configs[1]" if (args.dtype == "f32" and args.batch == 16) else \
@@ -383,6 +388,7 @@ def main():
             "latency": dict(host, note="one batch in flight: host time to enqueue a batch / time until its results are ready"),
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "rccl_ranks_seen": rccl_ranks_seen,
         }
         print(json.dumps(line), flush=True)
     if distributed:

@@ -134,26 +134,41 @@ class _AllGatherEmbeddings(torch.autograd.Function):
     gradient."""
 
     @staticmethod
-    def forward(ctx, local):
+    def forward(ctx, local, sizes):
         rank, world = _world()
         ctx.n_local = local.shape[0]
         if world == 1:
             ctx.lo = 0
             return local.clone()
-        counts = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-        sizes = [int(c.item()) for c in _all_gather_list(counts, world)]
+        if sizes is None:                                 # shard sizes unknown: one extra (tiny) collective + host syncs
+            counts = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+            sizes = [int(c.item()) for c in _all_gather_list(counts, world)]
+        sizes = [int(v) for v in sizes]
+        if len(sizes) != world or sizes[rank] != local.shape[0]:
+            raise ValueError(f"all_gather_embeddings: shard sizes {sizes} do not match rank {rank}'s {local.shape[0]} rows")
         ctx.lo = sum(sizes[:rank])
         mx = max(sizes)
-        pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        pad[: local.shape[0]] = local
-        parts = _all_gather_list(pad, world)
-        return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+        pad = local
+        if local.shape[0] != mx:
+            pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            pad[: local.shape[0]] = local
+        if _staged(pad):
+            parts = _all_gather_list(pad, world)
+        else:                                             # ONE collective: RCCL all-gather of the padded blocks
+            out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(out, pad.contiguous())
+            if all(v == mx for v in sizes):
+                return out
+            parts = [out[r * mx:(r + 1) * mx] for r in range(world)]
+        return torch.cat([p[:v] for p, v in zip(parts, sizes)], dim=0)
 
     @staticmethod
     def backward(ctx, grad):
-        return grad[ctx.lo: ctx.lo + ctx.n_local].contiguous()
+        return grad[ctx.lo: ctx.lo + ctx.n_local].contiguous(), None
 
 
-def all_gather_embeddings(local: torch.Tensor) -> torch.Tensor:
-    """(b_local, D) -> (sum b_local, D) on every rank, differentiable (see _AllGatherEmbeddings)."""
-    return _AllGatherEmbeddings.apply(local)
+def all_gather_embeddings(local: torch.Tensor, sizes: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """(b_local, D) -> (sum b_local, D) on every rank, differentiable (see _AllGatherEmbeddings).
+    sizes: rows of every rank's shard, known to all ranks from the sampler (e.g. `shard_bounds`): the exchange is then
+    exactly one all-gather with no host synchronisation; without it the sizes are exchanged first."""
+    return _AllGatherEmbeddings.apply(local, None if sizes is None else tuple(int(v) for v in sizes))

@@ -457,16 +457,22 @@ class TrainStep:
         self.loss_fn = BatchHardTripletLossWithMasks(margin)
 
     def __call__(self, batch: Dict[str, torch.Tensor], positives_mask: torch.Tensor, negatives_mask: torch.Tensor,
-                 step_optimizer: bool = True):
+                 step_optimizer: bool = True, shard_sizes=None):
+        """shard_sizes: scans per rank (every rank knows them from the sampler); default: the contiguous balanced partition
+        `distributed.shard_bounds` of the B = positives_mask.shape[0] scans — the embedding exchange is then ONE all-gather."""
         import torch.distributed as dist
-        from .distributed import all_gather_embeddings
+        from .distributed import all_gather_embeddings, shard_bounds
         sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         model = self.model
         model.train()
         model.sync_bn_group = dist.group.WORLD if sharded else None
         self.optimizer.zero_grad(set_to_none=True)
         y = model(batch, disable_local_head=True)
-        emb = all_gather_embeddings(y['global'])
+        if sharded and shard_sizes is None:
+            world = dist.get_world_size()
+            bounds = [shard_bounds(int(positives_mask.shape[0]), r, world) for r in range(world)]
+            shard_sizes = [hi - lo for lo, hi in bounds]
+        emb = all_gather_embeddings(y['global'], shard_sizes if sharded else None)
         dev = emb.device
         loss, stats, _ = self.loss_fn(emb, positives_mask.to(dev), negatives_mask.to(dev))
         loss.backward()

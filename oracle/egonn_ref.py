@@ -231,8 +231,15 @@ class EgoNNOracle:
         t = ops.global_avg_pool(t, c4, batch_size)
         return np.power(t, F32(1.0) / p).astype(F32)
 
+    # -- reference layers/pooling.py:46-56 (MAC: per-sample max) and :59-69 (SPoC: per-sample mean)
+    def mac(self, x, c4, batch_size):
+        return ops.global_max_pool(np.asarray(x, dtype=F32), c4, batch_size).astype(F32)
+
+    def spoc(self, x, c4, batch_size):
+        return ops.global_avg_pool(np.asarray(x, dtype=F32), c4, batch_size).astype(F32)
+
     def forward(self, coords: np.ndarray, features: np.ndarray, disable_global_head=False,
-                disable_local_head=False, return_internals=False):
+                disable_local_head=False, return_internals=False, pool_method: str = "GeM"):
         c4 = np.asarray(coords, dtype=np.int32)
         lv = SparseLevels(c4)
         x = self.trunk(np.asarray(features, dtype=F32), lv)
@@ -240,7 +247,8 @@ class EgoNNOracle:
         if not disable_global_head:
             g = self.head(x, lv, "global_head", GLOBAL_LEVELS)
             g = self._mlp(g, "global_descriptor_decoder")
-            y["global"] = self.gem(g, lv.coords[min(GLOBAL_LEVELS)], lv.batch_size)
+            pool = {"GeM": self.gem, "MAC": self.mac, "SPoC": self.spoc}[pool_method]    # layers/pooling.py:13-43 PoolingWrapper
+            y["global"] = pool(g, lv.coords[min(GLOBAL_LEVELS)], lv.batch_size)
         if not disable_local_head:
             lvl = min(LOCAL_LEVELS)
             xl = self.head(x, lv, "local_head", LOCAL_LEVELS)

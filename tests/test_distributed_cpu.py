@@ -94,6 +94,16 @@ def _gather_worker(rank, world, port, q):
         g = all_gather_embeddings(local)
         w = torch.arange(35.0).reshape(7, 5)
         (g * w).sum().backward()                                      # same "loss" on every rank
+        # shard sizes known to every rank (the sampler's partition): ONE collective, no size exchange
+        local2 = full[lo:hi].clone().requires_grad_(True)
+        g2 = all_gather_embeddings(local2, sizes=[4, 3])
+        (g2 * w).sum().backward()
+        assert torch.equal(g2, g) and torch.equal(local2.grad, local.grad)
+        try:
+            all_gather_embeddings(local2, sizes=[3, 4] if rank == 0 else [4, 4])
+            raise AssertionError("mismatching shard sizes must be rejected")
+        except ValueError:
+            pass
         q.put((rank, g.detach().numpy(), local.grad.numpy(), w[lo:hi].numpy(), full.numpy()))
     finally:
         dist.destroy_process_group()

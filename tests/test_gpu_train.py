@@ -262,15 +262,21 @@ def _masks():
     return pos, neg
 
 
-def _sharded_worker(rank, world, port, out_path):
+def _sharded_worker(rank, world, port, out_path, backend="gloo"):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)       # 2 ranks sharing the one GPU of the box:
-    try:                                                               # RCCL needs one GPU per rank, gloo is host-staged
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # gloo: 2 ranks sharing the one GPU of the box (host-staged collectives); nccl (= RCCL): one GPU per rank
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
         from egonn_amd.train import TrainStep
-        dev = torch.device("cuda", 0)
         case = H.load_case("egonn_train_cart03")
         coords = torch.from_numpy(case["coords"])
         model = _make_model(dev, int(case["weight_seed"]))
@@ -285,10 +291,14 @@ def _sharded_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_sharded_step_equals_single_process_step(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_sharded_step_equals_single_process_step(tmp_path, backend):
     """2 ranks (scans [0,1] | [2]) with SyncBN + embedding all-gather + gradient all-reduce reproduce the gradients,
-    the loss and the BatchNorm running statistics of one process stepping the whole batch."""
+    the loss and the BatchNorm running statistics of one process stepping the whole batch.  backend nccl = RCCL with one
+    GPU per rank: runs on the first box with >= 2 GPUs (skipped on the 1-GPU boxes)."""
     import socket
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank: >= 2 GPUs")
     import torch.multiprocessing as tmp_mp
     import __graft_entry__ as ge
     ge.build()
@@ -310,7 +320,7 @@ def test_sharded_step_equals_single_process_step(tmp_path):
         port = s.getsockname()[1]
     out = str(tmp_path / "res")
     ctx = tmp_mp.get_context("spawn")
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, out, backend)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

@@ -54,6 +54,67 @@ def test_strided_conv_and_transpose_known_answer():
     assert np.isclose(up[3, 0], pf[(0, 0, 0, 0)] * k[7, 0, 0])
 
 
+def _dense_case(seed, box=10, n=260, cin=3, b=2, lo=-5):
+    """random sparse set in a box (negative coordinates included), its features, and the same data as a dense volume
+    [b, cin, X, Y, Z] whose index 0 is coordinate `lo`"""
+    rng = np.random.default_rng(seed)
+    c = np.unique(np.c_[rng.integers(0, b, n), rng.integers(lo, lo + box, (n, 3))], axis=0).astype(np.int32)
+    f = rng.standard_normal((len(c), cin)).astype(np.float32)
+    vol = np.zeros((b, cin, box, box, box), np.float32)
+    vol[c[:, 0], :, c[:, 1] - lo, c[:, 2] - lo, c[:, 3] - lo] = f
+    return c, f, vol, lo
+
+
+@pytest.mark.parametrize("k", [3, 5])
+def test_conv_matches_dense_conv3d(k):
+    """Independent cross-check of oracle/me_ops.conv_forward + kernel_map: the same convolution computed
+    by torch.nn.functional.conv3d on the densified volume.  conv3d is a cross-correlation, out[x] = sum_d in[x + d] w[d],
+    which is the form A.5 states for ME; with the volume laid out [X, Y, Z] the dense weight is w[co][ci][kx][ky][kz] =
+    kernel[kx + k*ky + k*k*kz][ci][co] (first spatial axis fastest).  A transposed / flipped / y-fastest restatement fails
+    this test; it does not pin MinkowskiEngine itself (absent), only that the restatement is the convolution it claims."""
+    import torch.nn.functional as F
+    c, f, vol, lo = _dense_case(100 + k)
+    cin, cout = f.shape[1], 4
+    rng = np.random.default_rng(7)
+    kern = rng.standard_normal((k ** 3, cin, cout)).astype(np.float32)
+    out = ops.conv_forward(f, kern, ops.kernel_map(c, c, k, 1), len(c))
+    w = torch.from_numpy(kern).reshape(k, k, k, cin, cout).permute(4, 3, 2, 1, 0).contiguous()    # [kz][ky][kx] -> [co][ci][kx][ky][kz]
+    dense = F.conv3d(torch.from_numpy(vol).double(), w.double(), padding=k // 2).numpy()
+    want = dense[c[:, 0], :, c[:, 1] - lo, c[:, 2] - lo, c[:, 3] - lo]
+    np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-4)
+    # an asymmetric kernel makes the check sensitive to the axis order: the y-fastest reading must NOT match
+    w_bad = torch.from_numpy(kern).reshape(k, k, k, cin, cout).permute(4, 3, 1, 2, 0).contiguous()
+    bad = F.conv3d(torch.from_numpy(vol).double(), w_bad.double(), padding=k // 2).numpy()
+    assert np.abs(bad[c[:, 0], :, c[:, 1] - lo, c[:, 2] - lo, c[:, 3] - lo] - out).max() > 0.1
+
+
+def test_strided_and_transposed_conv_match_dense():
+    """k=2,s=2 (non-centred even kernel, floor parents — also for negative coordinates) against conv3d(stride=2) on the volume
+    aligned to even coordinates, and the transposed convolution onto the cached fine map against conv_transpose3d(stride=2)
+    read back at the fine voxels (A.5 / A.6)."""
+    import torch.nn.functional as F
+    c, f, vol, lo = _dense_case(31, box=10, lo=-6)         # lo even: dense index 2X' <-> coordinate lo + 2X'
+    cin, cout = f.shape[1], 5
+    rng = np.random.default_rng(9)
+    kern = rng.standard_normal((8, cin, cout)).astype(np.float32)
+    parents = ops.stride_coords(c, 2)
+    maps = ops.kernel_map(c, parents, 2, 1)
+    out = ops.conv_forward(f, kern, maps, len(parents))
+    w = torch.from_numpy(kern).reshape(2, 2, 2, cin, cout).permute(4, 3, 2, 1, 0).contiguous()
+    dense = F.conv3d(torch.from_numpy(vol).double(), w.double(), stride=2).numpy()
+    pi = (parents[:, 1:] - lo) // 2
+    np.testing.assert_allclose(out, dense[parents[:, 0], :, pi[:, 0], pi[:, 1], pi[:, 2]], rtol=1e-4, atol=1e-4)
+    # transposed: features on the parents, kernel (8, cout, cin2)
+    g = rng.standard_normal((len(parents), cout)).astype(np.float32)
+    kt = rng.standard_normal((8, cout, 2)).astype(np.float32)
+    up = ops.conv_transpose_forward(g, kt, maps, len(c))
+    pv = np.zeros((vol.shape[0], cout, 5, 5, 5), np.float32)
+    pv[parents[:, 0], :, pi[:, 0], pi[:, 1], pi[:, 2]] = g
+    wt = torch.from_numpy(kt).reshape(2, 2, 2, cout, 2).permute(3, 4, 2, 1, 0).contiguous()       # conv_transpose3d: [in][out][kx][ky][kz]
+    dense_up = F.conv_transpose3d(torch.from_numpy(pv).double(), wt.double(), stride=2).numpy()
+    np.testing.assert_allclose(up, dense_up[c[:, 0], :, c[:, 1] - lo, c[:, 2] - lo, c[:, 3] - lo], rtol=1e-4, atol=1e-4)
+
+
 def test_sparse_quantize_first_occurrence_and_negative_floor():
     pc = np.array([[0.05, 0.0, 0.0], [-0.05, 0.0, 0.0], [0.06, 0.01, 0.0], [0.31, 0.0, -0.11]], np.float32)
     d, idx = ops.sparse_quantize(pc, 0.1)
@@ -234,3 +295,44 @@ def test_c_oracle_polar_matches_reference_fixture():
     g2, kp2, de2, kc2, sg2 = ref.compute_embedding_with_sigma(ref.EgoNNOracle(w, ref.PolarQuantizer(step)), pc, 128)
     assert np.array_equal(sc, kc2[:, 1:]) and np.allclose(kp, kp2, atol=1e-4) and np.allclose(sg, sg2, rtol=1e-4, atol=1e-6)
     assert H.cosine_err(de, de2).max() < 1e-6
+
+
+def test_c_oracle_under_sanitizers(tmp_path):
+    """SURVEY.md §5 / VERDICT r2 6-iv: oracle/egonn_cpu.c built with -fsanitize=address,undefined (plain gcc on its one source
+    file + the stand-alone driver oracle/egonn_cpu_san_main.c) and run over ragged / tiny / empty / polar inputs: no
+    sanitizer report, and the level counts / output sums equal the regular build's."""
+    import os, shutil, struct, subprocess
+    from oracle import egonn_cpu
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    here = os.path.dirname(egonn_cpu.SRC)
+    exe = str(tmp_path / "egonn_cpu_san")
+    cmd = ["gcc", "-O1", "-g", "-fopenmp", "-std=c11", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-mavx2", "-mfma",
+           "-o", exe, egonn_cpu.SRC, os.path.join(here, "egonn_cpu_san_main.c"), "-lm"]
+    subprocess.run(cmd, check=True)
+    w = H.seeded_weights(5)
+    keys = egonn_cpu.weight_order()
+    from egonn_amd.synth import lidar_scan
+    rng = np.random.default_rng(3)
+    cases = [("lidar4k", lidar_scan(11, 4000), [0.1]), ("lidar_polar", lidar_scan(12, 3000), [1.0, 0.3, 0.2]),
+             ("one_point", np.array([[1.0, 2.0, 0.5]], np.float32), [0.1]),
+             ("two_far", np.array([[0.0, 0.0, 0.0], [70.0, -60.0, 3.0]], np.float32), [0.1]),
+             ("dup_points", np.repeat(rng.standard_normal((5, 3)).astype(np.float32), 40, axis=0), [0.1]),
+             ("negatives", (rng.standard_normal((800, 3)) * 3 - 5).astype(np.float32), [0.3])]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
+               OMP_NUM_THREADS="2")
+    for name, pc, step in cases:
+        f = tmp_path / (name + ".bin")
+        st = (step * 3)[:3]
+        with open(f, "wb") as fh:
+            fh.write(struct.pack("<qi3fii", len(pc), 1 if len(step) == 3 else 0, *st, 64, len(keys)))
+            for k in keys:
+                a = np.ascontiguousarray(w[k], dtype=np.float32).reshape(-1)
+                fh.write(struct.pack("<q", a.size)); fh.write(a.tobytes())
+            fh.write(np.ascontiguousarray(pc, np.float32).tobytes())
+        r = subprocess.run([exe, str(f)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "ERROR" not in r.stderr and "runtime error" not in r.stderr, (name, r.stderr[-2000:])
+        g, kp, de, sc, sg, cnt = egonn_cpu.CpuOracle(w, step if len(step) == 3 else step[0]).compute_embedding(pc, 64, 2)
+        tok = r.stdout.split()
+        assert int(tok[1]) == len(kp) and [int(t) for t in tok[3:11]] == cnt.tolist(), (name, r.stdout)
+        assert np.isclose(float(tok[12]), float(g.astype(np.float64).sum()), rtol=1e-4, atol=1e-4), (name, r.stdout)
