@@ -43,6 +43,19 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense MFMA peaks (MI355X_MICROARCH.md): exact-fp32 / bf16
 
 
+def mfma_peak(layer: str, dtype: str) -> float:
+    """Dense matrix-pipe peak in ALGORITHMIC flops (2 * pairs * Cin * Cout) for the arithmetic a tagged launch ran:
+    exact fp32 MFMA 157.3 TFLOP/s; bf16 maps 2500; the split-bf16 fp32 kernels issue six bf16 products per fp32 product
+    (sconv_split.hip) -> 2500 / 6; the first layer's unit-feature kernel three (conv.hip) -> 2500 / 3."""
+    if dtype == "bf16":
+        return MFMA_PEAK_TFLOPS["bf16"]
+    if layer.startswith(("sconv_split", "sconv_wide")):
+        return MFMA_PEAK_TFLOPS["bf16"] / 6.0
+    if layer.startswith("conv0_k5"):
+        return MFMA_PEAK_TFLOPS["bf16"] / 3.0
+    return MFMA_PEAK_TFLOPS["f32"]
+
+
 def _masked_stream(dev, slot, n_slots, layout):
     """A HIP stream restricted to one CU partition, wrapped for torch (None = let the extractor make a plain stream)."""
     if layout == "none":
@@ -87,6 +100,8 @@ def parse():
                    help="A/B measurements only: egonn_debug_set_naive_conv code (2 register-ring kernel, 16 LDS-DMA kernel with "
                         "split-phase fetch, 32 LDS-DMA kernel with 3 ring slots; all bitwise identical); 0 = product choice")
     p.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median one is reported")
+    p.add_argument("--no-extras", action="store_true",
+                   help="skip the bounded side measurements of the other BASELINE configs (extra.configs[2], configs[3]_1gpu, db)")
     return p.parse_args()
 
 
@@ -105,7 +120,7 @@ def layer_rows(recs, dtype):
     for k, v in table.items():
         us = float(np.mean(v["ms"])) * 1e3
         t_hbm = v["bytes"] / (HBM_PEAK_GBS * 1e9) * 1e6
-        t_mfma = v["flops"] / (MFMA_PEAK_TFLOPS[dtype] * 1e12) * 1e6
+        t_mfma = v["flops"] / (mfma_peak(k, dtype) * 1e12) * 1e6
         rows.append({"layer": k, "us": round(us, 2), "alg_bytes": v["bytes"], "flops": v["flops"],
                      "hbm_frac": round(t_hbm / us, 4), "mfma_frac": round(t_mfma / us, 4),
                      "bound": "hbm" if t_hbm >= t_mfma else "mfma", "frac": round(max(t_hbm, t_mfma) / us, 4)})
@@ -187,14 +202,20 @@ def main():
     # ---------------- the timed step
     graphs = []
     if args.mode == "graph":
-        caps = ex.calibrate(points, offsets, margin=1.25)
+        # capacities from OTHER scans than the timed ones (a deployment calibrates once, then streams unseen batches)
+        cal = make_scans(rank + 7919, args.batch, args.points)
+        cal_off = [0]
+        for sc in cal:
+            cal_off.append(cal_off[-1] + len(sc))
+        cal_pts = torch.from_numpy(np.concatenate(cal, axis=0)).to(dev).contiguous()
+        caps = ex.calibrate(cal_pts, cal_off, margin=1.25)
+        del cal_pts
         for i in range(S):
             gx = ex.graph(args.batch, points.shape[0], caps, slot=100 + i, stream=_masked_stream(dev, i, S, args.cu_partition))
             if args.conv_variant:
                 gx.ctx.set_naive_conv(args.conv_variant)
-            gx.ctx.profile_enable(3, dominant + "/")       # event brackets around the dominant kernel, captured with it
-            gx.run(points, offsets)                        # eager once + capture + first replay; the batch now lives
-            gx.status()                                    # in the graph's own input buffer (resident in HBM)
+            gx.run(points, offsets)                        # eager once + capture + first replay
+            gx.status()
             graphs.append(gx)
         torch.cuda.synchronize()
         g0 = time.perf_counter()
@@ -204,9 +225,9 @@ def main():
         g2 = time.perf_counter()
         host.update({"graph_launch_ms": round((g1 - g0) * 1e3, 3), "graph_latency_ms": round((g2 - g0) * 1e3, 3)})
 
-        def run_steps(k):
-            for i in range(k):
-                graphs[i % S].replay()
+        def run_steps(k):                                  # every step loads its batch (9.6 MB device copy + the scan
+            for i in range(k):                             # offsets) into the graph's input buffers, then ONE graph launch
+                graphs[i % S].run(points, offsets)
     else:
         ctx.profile_enable(2, dominant + "/")              # HIP events attached to the dominant kernel's dispatches
 
@@ -238,13 +259,13 @@ def main():
     elapsed = float(np.median(elapsed_all))
 
     # ---------------- roofline of the dominant kernel: launches of the timed region(s)
+    # graph mode: event records cannot be read back from inside a captured graph, so the dominant kernel is timed by an
+    # exclusive eager pass right after the timed regions (HIP events attached to its dispatches, one batch in flight) —
+    # the figure rocprofv3 --kernel-trace reports for it; eager mode: the events of the timed regions' own dispatches.
     if args.mode == "graph":
-        recs, timing = [], ("HIP event-record nodes captured around the dominant kernel's launches: durations of the last "
-                            "replay of every in-flight graph of the last timed region")
         for g in graphs:
             g.status()
-            recs += g.ctx.profile_fetch()
-            g.ctx.profile_enable(0)
+        recs = []
     else:
         recs, timing = ctx.profile_fetch(), "HIP events attached to every dispatch of the dominant kernel in the timed regions"
     ctx.profile_enable(2, dominant + "/")
@@ -254,13 +275,13 @@ def main():
     excl = ctx.profile_fetch()                             # same kernel, one batch in flight (what rocprofv3 reports)
     ctx.profile_enable(0)
     if not recs:
-        recs, timing = excl, "graph event records unavailable: exclusive eager pass after the timed regions"
+        recs, timing = excl, "exclusive eager pass after the timed regions: HIP events attached to the dominant kernel's dispatches, one batch in flight"
 
     def summarise(rr):
         ms = np.array([r[1] for r in rr]); by = np.array([r[2] for r in rr]); fl = np.array([r[3] for r in rr])
         us = float(ms.mean()) * 1e3
         t_hbm = float(by.mean()) / (HBM_PEAK_GBS * 1e9) * 1e6
-        t_mfma = float(fl.mean()) / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12) * 1e6
+        t_mfma = float(fl.mean()) / (mfma_peak(dominant, args.dtype) * 1e12) * 1e6
         return us, float(by.mean()), float(fl.mean()), t_hbm, t_mfma
 
     us, by, fl, t_hbm, t_mfma = summarise(recs)
@@ -294,13 +315,16 @@ def main():
     roofline = {
         "bound": bound, "kernel": dominant,
         "achieved": round(by / (us * 1e-6) / 1e9, 1) if bound == "hbm" else round(fl / (us * 1e-6) / 1e12, 2),
-        "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFLOPS[args.dtype],
+        "peak": HBM_PEAK_GBS if bound == "hbm" else round(mfma_peak(dominant, args.dtype), 1),
         "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
         "frac": round(max(t_hbm, t_mfma) / us, 4),
         "traffic": traffic, "traffic_source": traffic_src,
         "hbm": {"achieved_GBps": round(by / (us * 1e-6) / 1e9, 1), "frac": round(t_hbm / us, 4)},
-        "mfma": {"achieved_TFLOPs": round(fl / (us * 1e-6) / 1e12, 2), "peak_TFLOPs": MFMA_PEAK_TFLOPS[args.dtype],
-                 "frac": round(t_mfma / us, 4)},
+        "mfma": {"achieved_TFLOPs": round(fl / (us * 1e-6) / 1e12, 2), "peak_TFLOPs": round(mfma_peak(dominant, args.dtype), 1),
+                 "frac": round(t_mfma / us, 4),
+                 "note": "algorithmic flops (2 x pairs x Cin x Cout) against the dense matrix-pipe peak of the arithmetic the kernel "
+                         "runs: exact fp32 MFMA 157.3 TFLOP/s; split-bf16 fp32 kernels issue 6 bf16 products per fp32 product -> "
+                         "2500/6; bf16 maps 2500"},
         "launches": len(recs), "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": by, "flops_per_launch": fl,
         "timing": timing, "batches_in_flight": S,
         "layers": sorted(layers, key=lambda r: -r["us"]),
@@ -351,6 +375,33 @@ def main():
                             "kind": "port", "sample": f"{k} scans on the numpy oracle (C oracle unavailable: {e}), "
                                                       f"{c1 - c0:.1f} s of CPU work"}
 
+    # ---------------- bounded side measurements of the other BASELINE configs (same process tree, after the headline)
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extras and args.dtype == "f32" and args.batch == 16:
+        import subprocess
+        del graphs
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        extra = {}
+
+        def side(cmd, pick):
+            try:
+                r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=420, cwd=REPO)
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                return pick(json.loads(lines[-1])) if lines else {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:                          # pragma: no cover
+                return {"error": str(e)[:300]}
+        extra["configs[2]"] = side([os.path.join(REPO, "bench.py"), "--dtype", "bf16", "--batch", "64", "--steps", "30", "--warmup", "3",
+                                    "--repeats", "3", "--no-cpu-baseline", "--no-extras"],
+                                   lambda d: {"value": d["value"], "unit": "scans/s", "ms_per_step": d["ms_per_step"], "batch": 64, "dtype": "bf16",
+                                              "roofline": {k: d["roofline"][k] for k in ("kernel", "bound", "frac", "avg_launch_us")},
+                                              "note": "bf16 maps, batch 64, on-device quantisation, hipGraph-captured step, 4 batches in flight"})
+        extra["configs[3]_1gpu"] = side([os.path.join(REPO, "tools", "bench_train.py"), "--batch", "32", "--steps", "8"],
+                                        lambda d: dict(d, note="per-GPU share of configs[3] (32 of the 256 scans): forward with batch-statistics "
+                                                                "BN + batch-hard triplet loss + backward + Adam on ONE GPU; no collective runs"))
+        db = os.path.join(REPO, "tools", "bench_ingest.py")
+        if os.path.exists(db):
+            extra["db"] = side([db, "--json"], lambda d: d)
     rccl_ranks_seen = None
     if distributed:                                        # an actual RCCL all-reduce over the job's ranks (SUM of ones)
         ones = torch.ones(1, device=dev)
@@ -380,8 +431,15 @@ def main():
                        "batch_per_gpu": args.batch, "points_per_scan": args.points, "voxel_m": args.voxel,
                        "voxels_per_level": n_levels, "parallelism": f"scan-sharded x{world} (no collective)",
                        "batches_in_flight": S, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                       "launch": "one hipGraphLaunch per step (captured voxelise + forward + select; level sizes stay on the device)"
-                                 if args.mode == "graph" else "eager: ~150 launches + one size query per step"},
+                       "launch": "per step: the batch (already in HBM) is copied into the graph's input buffers, then one hipGraphLaunch "
+                                 "(captured voxelise + forward + select; level sizes stay on the device; capacities calibrated on other scans)"
+                                 if args.mode == "graph" else "eager: ~150 launches + one size query per step",
+                       "conv_arithmetic": ("bf16 maps and kernels, fp32 accumulate" if args.dtype == "bf16" else
+                                           "fp32 in / fp32 out; sparse convs of levels 1-4 (a function of the layer, not of the batch): operands "
+                                           "split exactly into 3 bf16 parts, the 6 products >= 2^-16 on v_mfma_f32_16x16x32_bf16 with "
+                                           "fp32 accumulation (max deviation from the exact-fp32 kernel 1.6e-6 of the largest output, "
+                                           "tests/test_gpu_graph.py); levels 5-7 and the heads: exact v_mfma_f32_16x16x4_f32; conv_variant="
+                                           + str(args.conv_variant))},
             "repeats": {"timed_regions": len(elapsed_all), "reported": "median",
                         "scans_per_s": [round(total_scans / e, 1) for e in elapsed_all],
                         "min": round(total_scans / max(elapsed_all), 1), "max": round(total_scans / min(elapsed_all), 1)},
@@ -389,6 +447,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "rccl_ranks_seen": rccl_ranks_seen,
+            "extra": extra,
         }
         print(json.dumps(line), flush=True)
     if distributed:

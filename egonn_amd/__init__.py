@@ -10,8 +10,9 @@ from .quantization import CartesianQuantizer, PolarQuantizer, Quantizer
 from .model import MinkGL, MinkHead, MinkTrunk, model_factory, create_egonn_model
 from .minkloc import MinkFPN, MinkLoc, MinkLoc3D
 from .evaluator import DescriptorExtractor, GraphExtractor
+from .stream import StreamingExtractor
 from .local_loss import KeypointLoss, CorrespondenceLoss, KeypointCorrLoss, make_local_loss
 
 __all__ = ["ModelParams", "model_factory", "create_egonn_model", "MinkGL", "MinkHead", "MinkTrunk",
-           "CartesianQuantizer", "PolarQuantizer", "Quantizer", "DescriptorExtractor", "GraphExtractor", "MinkFPN", "MinkLoc", "MinkLoc3D",
+           "CartesianQuantizer", "PolarQuantizer", "Quantizer", "DescriptorExtractor", "GraphExtractor", "StreamingExtractor", "MinkFPN", "MinkLoc", "MinkLoc3D",
            "KeypointLoss", "CorrespondenceLoss", "KeypointCorrLoss", "make_local_loss"]

@@ -151,8 +151,15 @@ __global__ void points_to_keys_kernel(const float* __restrict__ pts, int64_t n_c
   uint64_t key;
   const bool finite = isfinite(x) & isfinite(y) & isfinite(z);
   if (!encode_key(lo, cx, cy, cz, cb, key) || !finite) {
+    // out of the coordinate range / not a number: reported (egonn_voxelize raises EGONN_ERR_RANGE, egonn_plan_status for
+    // reserved plans), and the point is CLAMPED into its own sample's range so that every later kernel of a reserved
+    // (sync-free) plan still sees a well-formed key: a sentinel key would carry a sample index far beyond the batch and
+    // index the per-sample arrays out of bounds (found by tests/test_gpu_parity.py::test_streaming_pipeline_equals_extract)
     atomicOr(flags, 1);
-    key = ~0ull >> 1;
+    const int32_t hi = (1 << (cb - 1)) - 1, lo_c = -(1 << (cb - 1));
+    const int32_t qx = finite ? min(max(cx, lo_c), hi) : 0, qy = finite ? min(max(cy, lo_c), hi) : 0,
+                  qz = finite ? min(max(cz, lo_c), hi) : 0;
+    encode_key(lo, qx, qy, qz, cb, key);
   }
   keys[i] = key;
   vals[i] = (uint32_t)i;
@@ -310,17 +317,20 @@ __global__ __launch_bounds__(PYR_BLOCK) void pyramid_apply_kernel(const uint64_t
       excl[l] = run[l] + __popcll(m & lt);
       run[l] += __popcll(m);
     }
+    // A batch that exceeds the reservation of a level: rows beyond the capacity are NOT written, and every index that is
+    // written (first child, parent, per-sample offset) is clipped to the capacity of the level it points into, so that all
+    // later kernels of a reserved (sync-free) plan stay inside their tables; the overflow is flagged (egonn_plan_status).
     if (i < n && h > 0) {
-      out.perm0[excl[0]] = (int32_t)vals[i];
+      if (excl[0] < out.cap[0]) out.perm0[excl[0]] = (int32_t)vals[i];
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
-        if (l < h) {
+        if (l < h && excl[l] < out.cap[l]) {
           out.keys[l][excl[l]] = key >> (3 * l);
-          if (l >= 1) out.cstart[l][excl[l]] = excl[l - 1];
+          if (l >= 1) out.cstart[l][excl[l]] = min(excl[l - 1], out.cap[l - 1]);
           if (l + 1 < NL) {
             // group index of i at level l+1: a head there -> excl, otherwise the group opened earlier
             const int32_t g = (l + 1 < h) ? excl[l + 1] : excl[l + 1] - 1;
-            out.parent[l][excl[l]] = g;
+            out.parent[l][excl[l]] = min(g, out.cap[l + 1] - 1);
           }
         }
       }
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(PYR_BLOCK) void pyramid_apply_kernel(const uint64_t
       if (b != bprev) {
         for (int32_t bb = bprev + 1; bb <= b && bb <= B; ++bb) {
 #pragma unroll
-          for (int l = 0; l < EGONN_NUM_LEVELS; ++l) out.boff[l][bb] = excl[l];
+          for (int l = 0; l < EGONN_NUM_LEVELS; ++l) out.boff[l][bb] = min(excl[l], out.cap[l]);
         }
       }
     }
@@ -344,10 +354,10 @@ __global__ __launch_bounds__(PYR_BLOCK) void pyramid_apply_kernel(const uint64_t
         if (total > out.cap[l]) atomicOr(out.flags, 2);
         if (l >= 1) {
           const int32_t below = excl[l - 1] + (h > l - 1 ? 1 : 0);
-          out.cstart[l][total] = below;
+          out.cstart[l][min(total, out.cap[l])] = min(below, out.cap[l - 1]);
         }
         if (l < EGONN_NUM_LEVELS) {
-          for (int32_t bb = blast + 1; bb <= B; ++bb) out.boff[l][bb] = total;
+          for (int32_t bb = blast + 1; bb <= B; ++bb) out.boff[l][bb] = min(total, out.cap[l]);
         }
       }
       out.counts[NL] = blast + 1;

@@ -25,9 +25,11 @@ __device__ static inline bool keep_point(const float* __restrict__ raw, int64_t 
 
 __global__ __launch_bounds__(256) void ingest_count_kernel(const float* __restrict__ raw, int64_t n, int stride,
                                                           int remove_zero, int remove_ground, float ground,
+                                                          const int64_t* __restrict__ raw_off, int batch,
                                                           int32_t* __restrict__ block_cnt) {
   __shared__ int s_w[4];
   const int t = threadIdx.x;
+  n = min(n, raw_off[batch]);               // n is a capacity: the rows in use are known on the device only
   int c = 0;
   for (int r = 0; r < 4; ++r) {
     const int64_t i = (int64_t)blockIdx.x * ING_BLOCK + r * 256 + t;
@@ -72,9 +74,11 @@ __global__ __launch_bounds__(1024) void ingest_scan_kernel(int32_t* __restrict__
 __global__ __launch_bounds__(256) void ingest_scatter_kernel(const float* __restrict__ raw, int64_t n, int stride,
                                                             int remove_zero, int remove_ground, float ground,
                                                             const int32_t* __restrict__ block_pre,
+                                                            const int64_t* __restrict__ raw_off, int batch,
                                                             float* __restrict__ out) {
   __shared__ int s_w[4];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  n = min(n, raw_off[batch]);
   int32_t pos = block_pre[blockIdx.x];
   for (int r = 0; r < 4; ++r) {
     const int64_t i = (int64_t)blockIdx.x * ING_BLOCK + r * 256 + t;
@@ -132,12 +136,12 @@ int ingest_filter(const float* raw, int64_t n, int stride, const int64_t* raw_of
   EGONN_REQUIRE(scratch_ints >= (size_t)nblk + 2, EGONN_ERR_INVALID, "ingest: scratch too small");
   if (nblk > 0) {
     hipLaunchKernelGGL(ingest_count_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, raw, n, stride, remove_zero,
-                       remove_ground, ground, scratch);
+                       remove_ground, ground, raw_off_dev, batch, scratch);
   }
   hipLaunchKernelGGL(ingest_scan_kernel, dim3(1), dim3(1024), 0, stream, scratch, (int32_t)nblk);
   if (nblk > 0)
     hipLaunchKernelGGL(ingest_scatter_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, raw, n, stride, remove_zero,
-                       remove_ground, ground, scratch, out_xyz);
+                       remove_ground, ground, scratch, raw_off_dev, batch, out_xyz);
   hipLaunchKernelGGL(ingest_offsets_kernel, dim3((unsigned)(batch + 1)), dim3(64), 0, stream, raw, n, stride,
                      remove_zero, remove_ground, ground, scratch, raw_off_dev, batch + 1, new_off_dev);
   HIP_CHECK(hipGetLastError());

@@ -14,7 +14,7 @@ bool sconv_rg_supported(int cin, int cout);
 int pack_rg_weights(const float* W, int K, int cin, int cout, int bf16, int flip, int transpose, void* out,
                     hipStream_t stream);
 extern unsigned long long* g_sconv_trace;
-const char* sconv_kernel_name(int cin, int cout, int bf16, int64_t groups_hint, int variant);
+const char* sconv_kernel_name(int cin, int cout, int bf16, int64_t groups_hint, int variant, int level, int split_max_level);
 int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wp, int cin,
                      int cout, int bf16, const float* scale, const float* shift, int relu, void* out, float* psum,
                      hipStream_t stream, int variant = 0);
@@ -25,7 +25,7 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
 int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, const void* Wsp, int cin, int cout,
               int bf16, const float* scale, const float* shift, int relu, void* out, float* psum, float* scratch,
               size_t scratch_floats, hipStream_t stream);
-bool sconv_uses_split(int cin, int cout, int bf16, int64_t groups_hint, int variant);
+bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int split_max_level);
 // sconv_split.hip: fp32 maps on the bf16 matrix pipe (three-way split operands, fp32 accumulate)
 bool sconv_split_supported(int cin, int cout);
 int pack_split_weights(const float* W, int K, int cin, int cout, int flip, int transpose, void* out, hipStream_t stream);

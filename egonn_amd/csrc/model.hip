@@ -10,6 +10,7 @@
 #include "../../include/egonn_hip.h"
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 using namespace egonn;
 
@@ -662,6 +663,22 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
 // ------------------------------------------------------------------------------------------ forward
 namespace {
 
+// EGONN_DEBUG_SYNC=1: synchronise after every stage of egonn_forward and print its name (a GPU fault aborts the process at
+// the next synchronisation: the last name printed is the stage that faulted).  Debug aid only; never set in captures.
+bool debug_sync_on() {
+  static const bool on = [] { const char* e = getenv("EGONN_DEBUG_SYNC"); return e && e[0] == '1'; }();
+  return on;
+}
+#define DBG_SYNC(...)                                                 \
+  do {                                                                \
+    if (debug_sync_on()) {                                            \
+      fprintf(stderr, "[egonn] " __VA_ARGS__);                        \
+      fprintf(stderr, "\n");                                          \
+      fflush(stderr);                                                 \
+      HIP_CHECK(hipStreamSynchronize(st));                            \
+    }                                                                 \
+  } while (0)
+
 int run_mlp(const MlpRef& r, const float* x, int64_t n, int act_out, float* hidden, float* out, hipStream_t st,
             const int32_t* n_dev) {
   EGONN_TRY(dense_forward_ex(x, 0, n, r.cin, r.w0, 1, r.mid, r.b0, nullptr, nullptr, ACT_RELU, nullptr, 0, hidden, 0, st, n_dev));
@@ -695,6 +712,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     if (do_global) { kinds[nreq] = 2; levels[nreq++] = 6; kinds[nreq] = 2; levels[nreq++] = 5; }
     if (do_local) { kinds[nreq] = 2; levels[nreq++] = 3; }
     EGONN_TRY(ensure_rowgroups(c, kinds, levels, nreq, st));
+    DBG_SYNC("row groups");
   }
 
   // ---- workspace: every intermediate gets its own buffer (HBM is plentiful; no aliasing hazards)
@@ -727,6 +745,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     ProfScope ps(c, st, "conv0_k5_kernel/L0", PK_CONV0, 0, 125, 1, 32, (int)es);
     EGONN_TRY(conv0_k5_forward(c, f0, m->conv0, 32, m->bn[0].scale, m->bn[0].shift, 1, x0, bf16, st));
   }
+  DBG_SYNC("conv0");
   const void* x[8] = {x0};
   c->level_feat[0] = x0;
   c->level_ch[0] = 32;
@@ -740,7 +759,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     FALLOC(u3, n3 * LOCAL_CH);
     {
       char tag[64];
-      snprintf(tag, sizeof(tag), "%s<%d,%d>/L3/tconv", sconv_kernel_name(LOCAL_CH, LOCAL_CH, bf16, P.lv[3].rgT.cap_groups, c->conv_variant),
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L3/tconv", sconv_kernel_name(LOCAL_CH, LOCAL_CH, bf16, P.lv[3].rgT.cap_groups, c->conv_variant, 3, c->split_max_level),
                LOCAL_CH, LOCAL_CH);
       ProfScope ps(c, st, tag, PK_TCONV, 3, 8, LOCAL_CH, LOCAL_CH, (int)es);
       EGONN_TRY(sconv_map(c, 2, 3, l4, nullptr, bf16 ? m->q_lt[4] : m->p_lt[4], m->s_lt[4], LOCAL_CH, LOCAL_CH, bf16, nullptr, nullptr, 0, u3,
@@ -763,16 +782,17 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     FALLOC(y, n * b.cin);
     char tag[64];
     {
-      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k2s2", sconv_kernel_name(b.cin, b.cin, bf16, L.rg8.cap_groups, c->conv_variant), b.cin,
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k2s2", sconv_kernel_name(b.cin, b.cin, bf16, L.rg8.cap_groups, c->conv_variant, i, c->split_max_level), b.cin,
                b.cin, i);
       ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, (int)es);
       EGONN_TRY(sconv_map(c, 1, i, x[i - 1], nullptr, bf16 ? m->q_convs[i] : m->p_convs[i], m->s_convs[i], b.cin, b.cin, bf16, m->bn[i].scale,
                           m->bn[i].shift, 1, y, nullptr, nullptr, 0, st));
     }
+    DBG_SYNC("L%d k2s2", i);
     // ECABasicBlock (layers/eca_block.py:56-73)
     FALLOC(t1, n * b.cout);
     {
-      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv1", sconv_kernel_name(b.cin, b.cout, bf16, L.rg27.cap_groups, c->conv_variant),
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv1", sconv_kernel_name(b.cin, b.cout, bf16, L.rg27.cap_groups, c->conv_variant, i, c->split_max_level),
                b.cin, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cin, b.cout, (int)es);
       EGONN_TRY(sconv_map(c, 0, i, y, nullptr, bf16 ? m->q_c1[i] : m->p_c1[i], m->s_c1[i], b.cin, b.cout, bf16, b.n1.scale, b.n1.shift, 1, t1,
@@ -781,14 +801,16 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     FALLOC(t2, n * b.cout);
     WALLOC(psum, (size_t)L.rg27.cap_groups * b.cout);
     {
-      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv2", sconv_kernel_name(b.cout, b.cout, bf16, L.rg27.cap_groups, c->conv_variant),
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv2", sconv_kernel_name(b.cout, b.cout, bf16, L.rg27.cap_groups, c->conv_variant, i, c->split_max_level),
                b.cout, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cout, b.cout, (int)es);
       EGONN_TRY(sconv_map(c, 0, i, t1, nullptr, bf16 ? m->q_c2[i] : m->p_c2[i], m->s_c2[i], b.cout, b.cout, bf16, b.n2.scale, b.n2.shift, 0, t2,
                           psum, nullptr, 0, st));
     }
     WALLOC(gate, (size_t)B * b.cout);
+    DBG_SYNC("L%d convs", i);
     EGONN_TRY(eca_gate_groups(psum, L.rg27, L.boff, B, b.cout, b.eca, b.eca_k, gate, st));
+    DBG_SYNC("L%d eca gate", i);
     const void* res = y;
     if (b.down) {
       FALLOC(rd, n * b.cout);
@@ -798,6 +820,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     }
     FALLOC(xo, n * b.cout);
     EGONN_TRY(eca_apply_gate(t2, res, gate, L.boff, B, n, b.cout, xo, bf16, st));
+    DBG_SYNC("L%d eca apply", i);
     x[i] = xo;
     c->level_feat[i] = xo;
     c->level_ch[i] = b.cout;
@@ -806,6 +829,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     //  serialise against each other; the overlap comes from the batches in flight instead)
   }
   if (do_local) EGONN_TRY(local_head(st));
+  DBG_SYNC("local head");
 
   // ---- global head + decoder + GeM (models/minkgl.py:46-60, 207-225; layers/pooling.py:82-86)
   if (do_global) {
@@ -815,7 +839,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     FALLOC(u6, P.cap[6] * GLOBAL_CH);
     {
       char tag[64];
-      snprintf(tag, sizeof(tag), "%s<%d,%d>/L6/tconv", sconv_kernel_name(GLOBAL_CH, GLOBAL_CH, bf16, P.lv[6].rgT.cap_groups, c->conv_variant),
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L6/tconv", sconv_kernel_name(GLOBAL_CH, GLOBAL_CH, bf16, P.lv[6].rgT.cap_groups, c->conv_variant, 6, c->split_max_level),
                GLOBAL_CH, GLOBAL_CH);
       ProfScope ps(c, st, tag, PK_TCONV, 6, 8, GLOBAL_CH, GLOBAL_CH, (int)es);
       EGONN_TRY(sconv_map(c, 2, 6, g7, nullptr, bf16 ? m->q_gt[7] : m->p_gt[7], m->s_gt[7], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u6,
@@ -827,7 +851,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     FALLOC(u5, P.cap[5] * GLOBAL_CH);
     {
       char tag[64];
-      snprintf(tag, sizeof(tag), "%s<%d,%d>/L5/tconv", sconv_kernel_name(GLOBAL_CH, GLOBAL_CH, bf16, P.lv[5].rgT.cap_groups, c->conv_variant),
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L5/tconv", sconv_kernel_name(GLOBAL_CH, GLOBAL_CH, bf16, P.lv[5].rgT.cap_groups, c->conv_variant, 5, c->split_max_level),
                GLOBAL_CH, GLOBAL_CH);
       ProfScope ps(c, st, tag, PK_TCONV, 5, 8, GLOBAL_CH, GLOBAL_CH, (int)es);
       EGONN_TRY(sconv_map(c, 2, 5, g6, nullptr, bf16 ? m->q_gt[6] : m->p_gt[6], m->s_gt[6], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u5,
@@ -836,6 +860,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     WALLOC(g5, P.cap[5] * GLOBAL_CH);
     EGONN_TRY(dense_forward_ex(x[5], bf16, P.cap[5], 128, m->g1x1[5], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u5, bf16,
                                g5, 0, st, cnt + 5));
+    DBG_SYNC("global head");
     WALLOC(gh, P.cap[5] * m->gdec.mid);
     WALLOC(gd, P.cap[5] * GLOBAL_DIM);
     EGONN_TRY(run_mlp(m->gdec, g5, P.cap[5], ACT_NONE, gh, gd, st, cnt + 5));
@@ -852,6 +877,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     }
   }
 
+  DBG_SYNC("global decoder + pooling");
 #undef WALLOC
 #undef FALLOC
   return EGONN_OK;

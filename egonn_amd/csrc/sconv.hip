@@ -1167,8 +1167,8 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
 
 // Name of the kernel sconv_rg_forward dispatches for this launch (the profiler tags carry it, so that bench.py's dominant
 // kernel is the kernel rocprofv3 names).  Mirrors the choice in sconv_rg_forward / launch_rg.
-const char* sconv_kernel_name(int cin, int cout, int bf16, int64_t groups_hint, int variant) {
-  if (sconv_uses_split(cin, cout, bf16, groups_hint, variant)) return "sconv_split_kernel";
+const char* sconv_kernel_name(int cin, int cout, int bf16, int64_t groups_hint, int variant, int level, int split_max_level) {
+  if (sconv_uses_split(cin, cout, bf16, level, variant, split_max_level)) return "sconv_split_kernel";
   const int ns = cout / 32, ncb = cin / 32;
   const int ksp = ncb >= 4 ? 4 : ncb;
   const bool small = groups_hint * ns * ksp < 6144;
@@ -1179,22 +1179,25 @@ const char* sconv_kernel_name(int cin, int cout, int bf16, int64_t groups_hint, 
 }
 
 // Arithmetic of an fp32 sparse convolution (ctx->conv_variant; egonn_debug_set_naive_conv):
-//   0           product choice: split-bf16 kernel (sconv_split.hip) where it is instantiated, exact fp32 MFMA kernels elsewhere
+//   0           product choice: split-bf16 kernel (sconv_split.hip) on the maps of levels <= ctx->split_max_level where it is
+//               instantiated, exact fp32 MFMA kernels elsewhere
 //   1..9        the exact fp32 kernels of this file (3 = plain one-thread-per-output kernel)
 //   1000 + cfg  split-bf16 kernel with an explicit configuration (cfg 0 = its default)
-bool sconv_uses_split(int cin, int cout, int bf16, int64_t groups_hint, int variant) {
+// The product choice is a function of the LAYER (output level, channel plan), never of the batch or of a capacity: a scan
+// gives bitwise the same descriptors alone, in any batch, and under eager or reserved (hipGraph) plans.
+// Measured (profiles/r03e_split_threshold.txt, batch 16, four batches in flight): one launch alone, the lock-step split
+// kernel wins from ~4 000 row groups up (L1 k3 60 -> 54 us, L2 64->64 89 -> 79) and loses below; with batches in flight it
+// pays much earlier because it leaves the matrix pipe to the other batches: scans/s with the split kernel on launches of
+// >= inf / 4096 / 2000 / 700 / 200 groups = 21.8 k / 23.3 k / 24.3 k / 24.8 k / 23.6 k, i.e. levels <= 0 / 2 / 3 / 4 / 6.
+bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int split_max_level) {
   if (bf16 || !sconv_split_supported(cin, cout)) return false;
   if (variant >= 1000) return true;
   if (variant != 0) return false;
-  // product choice.  One launch alone (tools/bench_sconv.py, profiles/r03d_lock_ab.json) the lock-step split kernel wins
-  // from ~4 000 groups up (L1 k3 60 -> 54 us, L2 64->64 89 -> 79); with four batches in flight it pays much earlier because
-  // it leaves the matrix pipe to the other batches: scans/s at thresholds inf / 4096 / 2000 / 700 / 200 =
-  // 21.8 k / 23.3 k / 24.3 k / 24.8 k / 23.6 k (profiles/r03e_split_threshold.txt)
-  static const int64_t min_groups = [] {                 // EGONN_SPLIT_MIN_GROUPS: measurement override
-    const char* e = getenv("EGONN_SPLIT_MIN_GROUPS");
-    return e ? (int64_t)atoll(e) : (int64_t)700;
+  static const int env_level = [] {                       // EGONN_SPLIT_MAX_LEVEL: measurement override
+    const char* e = getenv("EGONN_SPLIT_MAX_LEVEL");
+    return e ? atoi(e) : -1;
   }();
-  return groups_hint >= min_groups;
+  return level <= (env_level >= 0 ? env_level : split_max_level);
 }
 
 int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, const void* Wsp, int cin, int cout,
@@ -1219,7 +1222,7 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
   }
   EGONN_TRY(ensure_rowgroups(ctx, &kind, &level, 1, stream));
   const RowGroups& rg = kind == 0 ? V.rg27 : (kind == 1 ? V.rg8 : V.rgT);
-  if (sconv_uses_split(cin, cout, bf16, rg.cap_groups, ctx->conv_variant)) {
+  if (sconv_uses_split(cin, cout, bf16, level, ctx->conv_variant, ctx->split_max_level)) {
     if (!Wsp) {   // stand-alone operator call: pack into the caller's scratch
       const size_t wn = ((size_t)K * cin * cout * 3 + 1) / 2;
       EGONN_REQUIRE(W && scratch && scratch_floats >= wn, EGONN_ERR_STATE, "sconv: no scratch to pack the kernel into");

@@ -34,6 +34,7 @@
 // depend on the batch, the grouping of other rows or eager vs graph execution (bitwise reproducible, batch-invariant).
 // The compiler does not know that an LDS-DMA write feeds a later ds_read (it would drain vmcnt(0) in front of any LDS read
 // it can see), so every LDS read of the step loop is issued from asm with its own counted waits.
+#include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
 #include <utility>
@@ -777,7 +778,11 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
 
 int sconv_split_default_cfg(int cin, int cout, int64_t groups_hint) {
   (void)cin; (void)cout; (void)groups_hint;
-  return 142;                                            // lock-step kernel, workgroups of 4 waves
+  static const int env_cfg = [] {                        // EGONN_SPLIT_CFG: measurement override
+    const char* e = getenv("EGONN_SPLIT_CFG");
+    return e ? atoi(e) : 0;
+  }();
+  return env_cfg ? env_cfg : 142;                        // lock-step kernel, workgroups of 4 waves
 }
 
 }  // namespace egonn

@@ -126,6 +126,40 @@ class DatabaseBuilder:
         return result
 
 
+def build_database_streaming(streamer, sources: Sequence, keep_local: bool = False) -> Dict:
+    """BASELINE configs[4] with the streaming pipeline (egonn_amd/stream.py): `sources` = ALL raw scans of the database (host
+    arrays (n,4|3) f32 or `.bin` paths; every rank holds the list, only its contiguous shard is read), `streamer` a calibrated
+    StreamingExtractor.  Each rank streams its shard (S batches in flight, no host synchronisation between file and
+    descriptor), then ONE all-gather of the (n_local, 256) descriptors (RCCL over xGMI).  Returns the (N,256) matrix on the
+    extractor's device (+ rank-local keypoints / descriptors on the host with keep_local)."""
+    rank, world = _world()
+    n_scans = len(sources)
+    lo, hi = shard_bounds(n_scans, rank, world)
+    B = streamer.batch_size
+    old_keep = streamer.keep_local
+    if streamer.slots and old_keep != keep_local:
+        raise ValueError("build_database_streaming: the streamer was built with a different keep_local")
+    streamer.keep_local = keep_local
+    batches = ([sources[i] for i in range(s0, min(s0 + B, hi))] for s0 in range(lo, hi, B))
+    globals_, kps, descs, counts = [], [], [], []
+    for out in streamer.run(batches):
+        globals_.append(out["global"])
+        counts.append(out["count"])
+        if keep_local:
+            kps.append(out["keypoints"])
+            descs.append(out["descriptors"])
+    model = streamer.extractor.model
+    dev = model.context().device
+    dim = int(model.global_descriptor_size)
+    local = torch.cat(globals_, dim=0).to(dev) if globals_ else torch.zeros((0, dim), device=dev)
+    result = {"global": all_gather_rows(local, n_scans), "range": (lo, hi), "fallbacks": streamer.fallbacks}
+    if counts:
+        result["count"] = torch.cat(counts)
+    if keep_local and kps:
+        result.update(keypoints=torch.cat(kps), descriptors=torch.cat(descs))
+    return result
+
+
 class _AllGatherEmbeddings(torch.autograd.Function):
     """Forward: all-gather of the per-rank (b_local, D) global descriptors into the (B, D) matrix the batch-hard
     miner needs (training/trainer.py:163-165 computes the loss on the whole batch).  Backward: every rank evaluates

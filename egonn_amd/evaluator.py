@@ -185,6 +185,13 @@ class GraphExtractor:
                              f"({self.max_points} points, {self.B} scans)")
         if self._off_copied is not None:
             self._off_copied.synchronize()           # (waits for a 100-byte copy, not for the graph)
+        # the batch may have been produced on the caller's current stream (a cat / slice on the device): order the copy
+        # below (on self.stream) behind it, and keep the caller's tensor alive until the copy has read it
+        cur = torch.cuda.current_stream(self.ctx.device) if not hasattr(self, "_caller_stream") else self._caller_stream
+        if cur != self.stream:
+            self.stream.wait_stream(cur)
+            if points.is_cuda:
+                points.record_stream(self.stream)
         self._host_off.copy_(torch.as_tensor(list(offsets), dtype=torch.int64))
         self.points[:n].copy_(points[:n], non_blocking=True)
         self.offsets.copy_(self._host_off, non_blocking=True)
@@ -196,6 +203,7 @@ class GraphExtractor:
         """points (n,3) f32 on the device, offsets: B+1 host ints.  Returns the static output dict (valid after a sync of
         `self.stream`; overwritten by the next run)."""
         ctx = self.ctx
+        self._caller_stream = torch.cuda.current_stream(ctx.device)      # the stream the caller built `points` on
         with torch.cuda.stream(self.stream):
             self._load(points, offsets)
             if self.graph is None:

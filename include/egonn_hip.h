@@ -284,7 +284,9 @@ int egonn_gem_backward(egonn_ctx* ctx, int level, const float* x, const float* c
  * [scan_offsets[b], scan_offsets[b+1]), DEVICE int64, batch_size+1 entries); drops all-zero points (|v| <= 1e-8) and
  * points with z <= ground_plane_level; survivors keep their order.  out_points (n,3) f32 (first out_scan_offsets[B]
  * rows valid), out_scan_offsets (batch_size+1) DEVICE int64.  scratch: egonn_filter_points_scratch_ints(n) int32.
- * No host sync (the caller copies the B+1 offsets back before egonn_voxelize). */
+ * n is a CAPACITY (>= scan_offsets[batch_size]; rows beyond scan_offsets[batch_size] are never read), so that a fixed-size
+ * launch sequence serves every batch (hipGraph capture).  No host sync: out_scan_offsets can be handed to
+ * egonn_voxelize_device as they are (egonn_amd/stream.py), or copied back for egonn_voxelize. */
 int64_t egonn_filter_points_scratch_ints(int64_t n);
 int egonn_filter_points(const float* raw, int64_t n, int floats_per_point, const int64_t* scan_offsets, int batch_size,
                         int remove_zero_points, int remove_ground_plane, float ground_plane_level, float* out_points,

@@ -558,6 +558,54 @@ def test_config4_database_build_mulran_shaped(gpu):
         assert int(solo["count"][0]) == int(db["count"][i])
 
 
+def test_streaming_pipeline_equals_extract(gpu, tmp_path):
+    """egonn_amd/stream.py (BASELINE configs[4]): raw MulRan-shaped scans from host buffers AND from .bin files through the
+    streaming pipeline (pinned staging by reader threads, device filter writing its offsets on the device, hipGraph step,
+    S batches in flight, short last batch, a batch that overflows the reservation -> eager fallback) give bitwise the
+    descriptors / keypoints of ScanIngest + extract on the same scans, in order."""
+    from egonn_amd.synth import lidar_scan
+    from egonn_amd.ingest import ScanIngest
+    from egonn_amd.distributed import build_database_streaming
+    m, _ = _model(gpu, seed=61)
+    ex = gpu.DescriptorExtractor(m, n_k=64)
+    rng = np.random.default_rng(5)
+    raws = []
+    for i in range(11):
+        pc = lidar_scan(7100 + i, n_points=20000 + 1500 * (i % 4), n_azimuth=1024)
+        pc[rng.integers(0, len(pc), 50)] = 0.0                                  # all-zero returns (dropped by the filter)
+        raws.append(np.ascontiguousarray(np.concatenate([pc, rng.random((len(pc), 1), dtype=np.float32)], 1)))
+    dense = lidar_scan(7300, n_points=26000, n_azimuth=2048)                     # many more voxels than the calibration batch
+    big = [np.ascontiguousarray(np.concatenate([dense * s, np.ones((len(dense), 1), np.float32)], 1)) for s in (1.0, 1.5, 2.0, 2.4)]
+    ing = ScanIngest("mulran", m.context().device)
+
+    def want_of(batch):
+        pts, off = ing(batch)
+        out = ex.extract_packed(pts, off, slot=1)
+        return {k: out[k].cpu().clone() for k in ("global", "count", "keypoints", "descriptors")}
+
+    se = gpu.StreamingExtractor(ex, batch_size=4, max_points_per_scan=26000, dataset_type="mulran", slots=3, workers=4, keep_local=True)
+    se.calibrate(raws[:4], margin=1.15)
+    batches = [raws[0:4], raws[4:8], big, raws[8:11]]                            # third batch overflows, last one is short
+    for rnd in range(2):
+        got = list(se.run(batches))
+        assert len(got) == 4
+        for b, g in zip(batches, got):
+            w = want_of(b)
+            for k in w:
+                assert torch.equal(g[k], w[k][: len(b)]), (rnd, k)
+    assert se.fallbacks == 2                                                     # the dense batch, once per round
+    # .bin files through readinto, and the database build on top (one rank: the all-gather is the identity)
+    paths = []
+    for i, r in enumerate(raws):
+        fn = str(tmp_path / f"{i:04d}.bin"); r.tofile(fn); paths.append(fn)
+    se2 = gpu.StreamingExtractor(ex, batch_size=4, max_points_per_scan=26000, dataset_type="mulran", slots=2, workers=2, keep_local=False)
+    se2.calibrate(paths[:4], margin=1.5)
+    db = build_database_streaming(se2, paths)
+    assert db["global"].shape == (11, 256) and db["range"] == (0, 11) and db["fallbacks"] == 0
+    want = torch.cat([want_of(raws[i:i + 4])["global"] for i in range(0, 11, 4)])
+    assert torch.equal(db["global"].cpu(), want)
+
+
 def test_knn_and_recall_match_oracle():
     """on-device kNN + recall@k (eval/evaluate.py:80-88) vs the numpy restatement: indices bit-exact (ties by index)."""
     from egonn_amd import retrieval, _lib
