@@ -110,6 +110,8 @@ struct RowGroups {
   int32_t* snbr = nullptr;    // [cap_groups][K][16]   input row, -1 = no neighbour
   uint32_t* gmask = nullptr;  // [cap_groups]          OR of the 16 presence masks; bit 31 = group has real rows
   int32_t* meta = nullptr;    // [0] groups in use, [1 + b] first group of sample b (b = 0..B)
+  int32_t* order4 = nullptr;  // [cap_groups / 4] tasks of 4 consecutive groups in dispatch order: inside each contiguous eighth
+                              // (= XCD) the tasks with the most offsets first (the tail of a launch is then made of short tasks)
   bool built = false;
 };
 struct RGBuild {

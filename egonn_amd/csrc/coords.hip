@@ -933,7 +933,8 @@ int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, h
     rg.snbr = A.alloc<int32_t>((size_t)rg.cap_groups * rg.K * 16);
     rg.gmask = A.alloc<uint32_t>((size_t)rg.cap_groups);
     rg.meta = A.alloc<int32_t>((size_t)P.batch + 2);
-    EGONN_REQUIRE(rg.perm && rg.snbr && rg.gmask && rg.meta, EGONN_ERR_STATE, "plan arena too small (row groups)");
+    rg.order4 = A.alloc<int32_t>((size_t)rg.cap_groups / 4 + 16);
+    EGONN_REQUIRE(rg.perm && rg.snbr && rg.gmask && rg.meta && rg.order4, EGONN_ERR_STATE, "plan arena too small (row groups)");
     EGONN_REQUIRE(nj < RG_MAX_JOBS, EGONN_ERR_INVALID, "rowgroups: too many maps in one request");
     jobs[nj].rg = &rg;
     jobs[nj].nbr = nbr;
@@ -952,7 +953,7 @@ static size_t plan_arena_bytes(int64_t n, int B) {
   // raw+sorted keys/vals, 10 levels x (keys, parent, cstart, mask, bstart), perm, maps of levels 1..7 (<= n rows each)
   size_t per_row = 2 * (8 + 4) + NL * (8 + 4 + 4 + 8 + 4) + 4 + 9 * 27 * 4 + 7 * (8 + 8) * 4 + 4 + 27 * 12 + 8 * 4;
   // row-group tables: k=3 (27+1 ints + mask) and the two 8-slot maps, <= 2n rows over all levels + window rounding
-  per_row += 2 * ((27 + 1) * 4 + 1 + 2 * ((8 + 1) * 4 + 1));
+  per_row += 2 * ((27 + 1) * 4 + 2 + 2 * ((8 + 1) * 4 + 2));
   const size_t rg_round = (size_t)(B + 8) * 1024 * (28 + 2 * 9) * 4 * EGONN_NUM_LEVELS;
   return (size_t)(n + 8) * per_row + (size_t)(B + 1) * 4 * EGONN_NUM_LEVELS + (size_t)cdiv(n, PYR_TILE) * NL * 4 + rg_round +
          (1 << 20);

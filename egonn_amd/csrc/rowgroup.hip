@@ -262,6 +262,78 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
   }
 }
 
+// Dispatch order of the split-bf16 kernel's tasks (4 consecutive groups each; sconv_split.hip).  A launch is a few rounds
+// of tasks whose length (offsets present in the union of the task's groups) varies 5..25 steps: in table order the last
+// round is as long as its longest task and the chip idles behind it (tools/split_trace.py: 53 % packing on L1 k3).  Inside
+// every contiguous eighth of the tasks (one XCD: the locality of the Z-order slice is kept) the tasks are therefore stably
+// sorted by descending step count — longest first.  One wave per (map, eighth): counting sort with ballot ranks.
+struct RGOrderArgs {
+  const uint32_t* gmask[RG_MAX_JOBS];
+  const int32_t* meta[RG_MAX_JOBS];
+  int32_t* order[RG_MAX_JOBS];
+  int cap_groups[RG_MAX_JOBS];
+  int njobs;
+};
+__global__ __launch_bounds__(64) void rowgroup_order_kernel(const RGOrderArgs a) {
+  const int j = blockIdx.x >> 3, xcd = blockIdx.x & 7, lane = threadIdx.x;
+  if (j >= a.njobs || !a.order[j]) return;
+  const int ngroups = min(a.meta[j][0], a.cap_groups[j]);
+  const int ntask = (ngroups + 3) >> 2;
+  const int cpx = (ntask + 7) >> 3;
+  const int t0 = xcd * cpx, t1 = min(t0 + cpx, ntask);
+  const uint32_t* gm = a.gmask[j];
+  auto cost_of = [&](int t) {
+    uint32_t u = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) u |= (4 * t + q < ngroups) ? gm[4 * t + q] : 0u;
+    return (u >> 31) ? __popc(u & 0x07FFFFFFu) : 0;      // a task of padding groups only costs nothing
+  };
+  __shared__ int32_t base[32];
+  if (lane < 32) base[lane] = 0;
+  __builtin_amdgcn_wave_barrier();
+  // pass 1: tasks per cost class
+  int32_t mine = 0;                                      // lane c < 28 accumulates the count of class c
+  for (int tb = t0; tb < t1; tb += 64) {
+    const int t = tb + lane;
+    const int c = t < t1 ? cost_of(t) : -1;
+#pragma unroll
+    for (int cc = 0; cc < 28; ++cc) {
+      const int n = __popcll(__ballot(c == cc));
+      if (lane == cc) mine += n;
+    }
+  }
+  // descending order: class 27 first.  start[c] = sum of counts of classes > c
+  int32_t start = 0;
+  {
+    int32_t run = 0;
+    for (int cc = 27; cc >= 0; --cc) {
+      const int32_t n = __shfl(mine, cc, 64);
+      if (lane == cc) start = run;
+      run += n;
+    }
+  }
+  if (lane < 28) base[lane] = start;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // pass 2: stable scatter
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int tb = t0; tb < t1; tb += 64) {
+    const int t = tb + lane;
+    const int c = t < t1 ? cost_of(t) : -1;
+#pragma unroll
+    for (int cc = 0; cc < 28; ++cc) {
+      const unsigned long long m = __ballot(c == cc);
+      if (c == cc) a.order[j][t0 + base[cc] + __popcll(m & lt)] = t;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0 && m) base[cc] += __popcll(m);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
 // Builds the row-group tables of `jobs` (all in one launch).  Every job's arrays must hold cap_groups groups.
 int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream) {
   EGONN_REQUIRE(njobs >= 1 && njobs <= RG_MAX_JOBS, EGONN_ERR_INVALID, "rowgroup_build: %d jobs", njobs);
@@ -295,6 +367,18 @@ int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream) {
   if (a.trace) hipLaunchKernelGGL(rowgroup_build_kernel<true>, dim3((unsigned)nb), dim3(RG_THREADS), lds, stream, a);
   else hipLaunchKernelGGL(rowgroup_build_kernel<false>, dim3((unsigned)nb), dim3(RG_THREADS), lds, stream, a);
   HIP_CHECK(hipGetLastError());
+  RGOrderArgs oa;
+  oa.njobs = njobs;
+  bool any = false;
+  for (int j = 0; j < njobs; ++j) {
+    oa.gmask[j] = jobs[j].rg->gmask; oa.meta[j] = jobs[j].rg->meta; oa.order[j] = jobs[j].rg->order4;
+    oa.cap_groups[j] = jobs[j].rg->cap_groups;
+    any |= jobs[j].rg->order4 != nullptr;
+  }
+  if (any) {
+    hipLaunchKernelGGL(rowgroup_order_kernel, dim3((unsigned)(njobs * 8)), dim3(64), 0, stream, oa);
+    HIP_CHECK(hipGetLastError());
+  }
   return EGONN_OK;
 }
 

@@ -107,6 +107,7 @@ struct SplitArgs {
   const uint32_t* gmask;
   const int32_t* perm;
   const int32_t* meta;       // [0] = groups in use
+  const int32_t* order;      // dispatch order of the 4-group tasks (rowgroup.hip; nullable = table order)
   const void* Wsp;           // pack_split_weights
   const float* scale;        // folded BatchNorm (nullable)
   const float* shift;
@@ -197,8 +198,9 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
   const int cpx = (ntask + 7) >> 3;
 
   for (int lt = blockIdx.x >> 3; lt < cpx; lt += nper) {
-    const int task = xcd * cpx + lt;
-    if (task >= ntask) continue;                         // workgroup-uniform
+    const int tslot = xcd * cpx + lt;
+    if (tslot >= ntask) continue;                        // workgroup-uniform
+    const int task = (NW == 4 && p.order) ? __builtin_amdgcn_readfirstlane(p.order[tslot]) : tslot;   // longest tasks first
     const int g0 = task * NW;
     const int gw = g0 + wave;                            // this wave's group
     unsigned long long tr[12] = {};
@@ -718,6 +720,7 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
   if (groups_hint <= 0) return EGONN_OK;
   SplitArgs a;
   a.in = in; a.snbr = rg.snbr; a.gmask = rg.gmask; a.perm = rg.perm; a.meta = rg.meta; a.Wsp = Wsp;
+  a.order = getenv("EGONN_NO_TASK_ORDER") ? nullptr : rg.order4;       // (measurement switch)
   a.scale = scale; a.shift = shift; a.out = out; a.psum = psum;
   a.in_rows = (uint32_t)n_in_cap;
   a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * 6);
