@@ -149,9 +149,9 @@ __device__ static inline void split8(const f32x4& a0, const f32x4& a1, bf16x8_t&
   lo = __builtin_bit_cast(bf16x8_t, (uint4){l[0], l[1], l[2], l[3]});
 }
 
-template <int COUT, int NW>
+template <int NSW, int NW>
 struct SplitGeom {
-  static constexpr int NS = COUT / 32;
+  static constexpr int NS = NSW;                         // 32-column slices a workgroup owns
   static constexpr int SLAB = NS * 6144;                 // bytes of W[k][cb][all columns], three parts
   static constexpr int NPIECE = NS * 6;                  // 1 KB DMA pieces per slab
   static constexpr int WPP = (NPIECE + NW - 1) / NW;     // pieces a wave issues per step (at most)
@@ -161,10 +161,16 @@ struct SplitGeom {
   static constexpr int LDS_BYTES = WAVES_AT + NW * WAVE_LDS;
 };
 
-template <int CIN, int COUT, int NW, int TERMS, bool TRACE = false>
+// NSW: 32-column slices per workgroup (grid.y = COUT/32/NSW column parts).  Small maps (levels 3-4: a few hundred tasks, less
+// than one round of the chip) are a chain of K*CIN/32 dependent steps per task; giving every column part its own workgroup
+// shortens the step (fewer MFMAs, a smaller slab) and multiplies the workgroups in flight; the rows are then gathered once
+// per part, which small maps can afford.  Columns are independent: the results are bitwise the same for every NSW.
+template <int CIN, int COUT, int NW, int NSW, int TERMS, bool TRACE = false>
 __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p) {
-  using GEO = SplitGeom<COUT, NW>;
-  constexpr int NS = GEO::NS, NCB = CIN / 32;
+  using GEO = SplitGeom<NSW, NW>;
+  constexpr int NS = NSW, NSTOT = COUT / 32, NCB = CIN / 32;
+  static_assert(NSTOT % NSW == 0, "column parts");
+  const int ns0 = blockIdx.y * NSW;                      // first column slice of this workgroup
   constexpr int SLAB = GEO::SLAB, NPIECE = GEO::NPIECE, WPP = GEO::WPP;
   static_assert(GEO::LDS_BYTES <= 160 * 1024, "LDS budget");
   static_assert(TERMS == 3 || TERMS == 6 || TERMS == 9, "terms");
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
     // as much as a real one.  Nothing is counted: the wave drains its queue (vmcnt(0)) before the step's barrier.
     auto issue = [&](int slot, int k, int cb, int32_t i0, int32_t i1) {
       if (k >= 27) return;
-      const int woff = (k * NCB + cb) * SLAB;
+      const int woff = ((k * NCB + cb) * NSTOT + ns0) * 6144;
 #pragma unroll
       for (int q = 0; q < WPP; ++q) {
         const int pc = wave + NW * q;
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
         float sums[2][4];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const int c0 = ns * 32 + nt * 16 + 4 * g4;
+          const int c0 = (ns0 + ns) * 32 + nt * 16 + 4 * g4;
           f32x4 v = acc[ns][nt];
           if (p.scale) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c0);
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
           if (l15 == 0) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-              *reinterpret_cast<f32x4*>(p.psum + (int64_t)gw * COUT + ns * 32 + nt * 16 + 4 * g4) =
+              *reinterpret_cast<f32x4*>(p.psum + (int64_t)gw * COUT + (ns0 + ns) * 32 + nt * 16 + 4 * g4) =
                   (f32x4){sums[nt][0], sums[nt][1], sums[nt][2], sums[nt][3]};
           }
         }
@@ -429,21 +435,22 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
   }
 }
 
-template <int CIN, int COUT, int NW, int TERMS, bool TRACE = false>
+template <int CIN, int COUT, int NW, int NSW, int TERMS, bool TRACE = false>
 static int launch_split(const SplitArgs& a, int64_t groups_hint, hipStream_t stream) {
-  using GEO = SplitGeom<COUT, NW>;
-  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_split_kernel<CIN, COUT, NW, TERMS, TRACE>),
+  using GEO = SplitGeom<NSW, NW>;
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_split_kernel<CIN, COUT, NW, NSW, TERMS, TRACE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int64_t ntask = cdiv(groups_hint, NW);
-  int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 1 << 20);
-  grid = (grid + 7) / 8 * 8;
+  int64_t gridx = std::min<int64_t>(std::max<int64_t>(ntask, 8), 1 << 20);
+  gridx = (gridx + 7) / 8 * 8;
+  const dim3 grid((unsigned)gridx, (unsigned)(COUT / 32 / NSW));
   hipEvent_t* pev = prof_kernel_events();
   if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
-    hipExtLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, TERMS, TRACE>), dim3((unsigned)grid), dim3(NW * 64), GEO::LDS_BYTES, stream,
+    hipExtLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, NSW, TERMS, TRACE>), grid, dim3(NW * 64), GEO::LDS_BYTES, stream,
                           pev[0], pev[1], 0, a);
     pev[0] = pev[1] = nullptr;
   } else {
-    hipLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, TERMS, TRACE>), dim3((unsigned)grid), dim3(NW * 64), GEO::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, NSW, TERMS, TRACE>), grid, dim3(NW * 64), GEO::LDS_BYTES, stream, a);
   }
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
@@ -726,15 +733,30 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
   a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * 6);
   a.K = rg.K; a.relu = relu ? 1 : 0; a.cap_groups = rg.cap_groups;
   if (cfg == 0) cfg = sconv_split_default_cfg(cin, cout, groups_hint);
-  const int terms = cfg / 1000, shape = cfg % 1000;
-#define EGONN_SP_LOCK(CI, CO, NWW)                                                                        \
-  if (cin == CI && cout == CO && shape == 100 + NWW * 10 + 2) {                                           \
-    if (terms == 0) return launch_split<CI, CO, NWW, 6>(a, groups_hint, stream);                          \
+  const int terms = cfg / 1000;
+  int shape = cfg % 1000;
+  // lock-step kernel: shape = 100 + NW * 10 + 2 [+ 400 * log2(column parts): 0 = automatic]
+  int parts_sel = 0;
+  if (shape >= 500) { parts_sel = shape / 400; shape -= 400 * parts_sel; }
+  const int ns_tot = cout / 32;
+  int parts = 1;
+  if (parts_sel > 0) parts = std::min(ns_tot, 1 << (parts_sel - 1));
+  else if (ns_tot >= 2 && cdiv(groups_hint, 4) < 700) {  // less than one round of the chip: two column parts per task
+    parts = 2;                                           // (measured, profiles/r03i_colparts.txt: L4 128->128 101 / 80 / 93 us
+  }                                                      //  with 1 / 2 / 4 parts, 64->128 56 / 45 / 51, L3 64->64 43 / 41)
+  const int nsw = ns_tot / parts;
+#define EGONN_SP_LOCK1(CI, CO, NWW, NSWW)                                                                 \
+  if (cin == CI && cout == CO && shape == 100 + NWW * 10 + 2 && nsw == NSWW) {                            \
+    if (terms == 0) return launch_split<CI, CO, NWW, NSWW, 6>(a, groups_hint, stream);                    \
   }
+#define EGONN_SP_LOCK(CI, CO, NWW)                                                                        \
+  EGONN_SP_LOCK1(CI, CO, NWW, (CO / 32))                                                                  \
+  if constexpr (CO >= 64) { EGONN_SP_LOCK1(CI, CO, NWW, (CO / 64)) }                                      \
+  if constexpr (CO >= 128) { EGONN_SP_LOCK1(CI, CO, NWW, (CO / 128)) }
 #define EGONN_SP_LOCK_TRACE(CI, CO, NWW)                                                                  \
   if (cin == CI && cout == CO && shape == 100 + NWW * 10 + 2 && terms == 9) {                             \
     a.trace = g_sconv_trace;                                                                              \
-    return launch_split<CI, CO, NWW, 6, true>(a, groups_hint, stream);                                    \
+    return launch_split<CI, CO, NWW, (CO / 32), 6, true>(a, groups_hint, stream);                         \
   }
   EGONN_SP_LOCK_TRACE(32, 32, 4) EGONN_SP_LOCK_TRACE(32, 32, 8) EGONN_SP_LOCK_TRACE(64, 64, 4)
 #define EGONN_SP_WIDE(CI, CO, GG)                                                                         \
@@ -772,6 +794,7 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
   EGONN_SP_PLAN(128, 64)
 #undef EGONN_SP_PLAN
 #undef EGONN_SP_LOCK
+#undef EGONN_SP_LOCK1
 #undef EGONN_SP_WIDE
 #undef EGONN_SP_WIDE_TERMS
 #undef EGONN_SP_WIDE_ABL

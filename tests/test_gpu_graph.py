@@ -401,7 +401,8 @@ def test_split_bf16_conv_matches_exact_fp32(gpu):
         assert float((got - exact).abs().max()) / scale < 4e-6, (kind, lvl, ci, co)
         assert torch.allclose(sums.double().sum(0), got.double().sum(0), rtol=1e-5, atol=1e-2 * max(scale, 1.0))
         wide = (ci, co) in ((32, 32), (32, 64), (64, 64), (64, 128), (128, 128))   # plans the wave-wide variant is built for
-        for var in (1182,) + ((1100, 1200) if wide else ()):          # other decompositions of the same arithmetic
+        # other decompositions of the same arithmetic: 8-wave workgroups, one / two column parts per workgroup, wave-wide
+        for var in (1182, 1542, 1942) + ((1100, 1200) if wide else ()):
             ctx.lib.egonn_debug_set_naive_conv(ctx.h, var)
             v, s2 = ctx.sparse_conv(kind, lvl, x, w, sc, sh, relu=False, group_sums=True)
             assert torch.equal(v, got) and torch.equal(s2, sums), (var, kind, lvl, ci, co)
