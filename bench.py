@@ -300,7 +300,7 @@ def main():
                 if not (kk.startswith(kname + "<") and kk.split("<", 1)[1].startswith(ci_co + ",")):
                     continue
                 targs = kk.split("<", 1)[1].rstrip(">").split(",")
-                is_bf16 = targs[2] if not kk.startswith("sconv_dma") else "false"
+                is_bf16 = targs[2] if not kk.startswith(("sconv_dma", "sconv_split", "sconv_wide")) else "false"
                 if is_bf16 != want_bf16:
                     continue
                 tot += v["traffic_bytes_per_launch"] * v["launches"]

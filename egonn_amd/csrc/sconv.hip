@@ -119,6 +119,8 @@ struct SconvArgs {
   uint32_t in_bytes, w_bytes;
   int K, relu;
   int cap_groups = 0;                    // groups the tables hold: meta[0] is clipped to it (a batch beyond its reservation)
+  const int32_t* order4 = nullptr;       // dispatch order of tasks of 4 consecutive groups (rowgroup.hip: longest first inside
+                                         // every XCD's eighth); used by the kernels whose task is exactly such a quadruple
   unsigned long long* trace = nullptr;   // measurement builds only (tools/sconv_trace.py): 8 u64 per wave task
 };
 
@@ -211,7 +213,10 @@ __global__ __launch_bounds__(NW * 64) void sconv_rg_kernel(const SconvArgs p) {
   };
 
   for (int lt = blockIdx.x >> 3; lt < cpx; lt += nper) {
-    const int task = xcd * cpx + lt;
+    int task = xcd * cpx + lt;
+    if constexpr (G == 4 && NS == 1 && TPW == 1) {       // a task is one quadruple of groups: longest tasks first
+      if (p.order4 && task < ntask) task = __builtin_amdgcn_readfirstlane(p.order4[task]);
+    }
     const int tile = task * TPW + wave / KSP;
     const int sg = tile / NS, ns = tile - sg * NS;
     const int g0 = sg * G;
@@ -844,8 +849,11 @@ __global__ __launch_bounds__(NW * 64) void sconv_wg_kernel(const SconvArgs p) {
   const int cpx = (ntask + 7) >> 3;
 
   for (int lt = blockIdx.x >> 3; lt < cpx; lt += nper) {
-    const int task = xcd * cpx + lt;
+    int task = xcd * cpx + lt;
     if (task >= ntask) continue;
+    if constexpr (NW == 4) {                             // longest tasks first (rowgroup_order_kernel)
+      if (p.order4) task = __builtin_amdgcn_readfirstlane(p.order4[task]);
+    }
     const int g0 = task * NW;
     uint32_t U = 0, own = 0;
 #pragma unroll
@@ -1132,6 +1140,7 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
   a.in_bytes = (uint32_t)ib;
   a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * (bf16 ? 2 : 4));
   a.K = rg.K; a.relu = relu ? 1 : 0; a.cap_groups = rg.cap_groups;
+  a.order4 = getenv("EGONN_NO_TASK_ORDER") ? nullptr : rg.order4;
   a.trace = variant == 9 ? g_sconv_trace : nullptr;
 
   // Measured (profiles/r02b_sconv.json, batch 16): in fp32 the per-wave kernel wins everywhere (the lock-step of the
