@@ -283,54 +283,67 @@ __global__ __launch_bounds__(64) void rowgroup_order_kernel(const RGOrderArgs a)
   const int t0 = xcd * cpx, t1 = min(t0 + cpx, ntask);
   const uint32_t* gm = a.gmask[j];
   auto cost_of = [&](int t) {
-    uint32_t u = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) u |= (4 * t + q < ngroups) ? gm[4 * t + q] : 0u;
+    const uint4 m = (4 * t + 3 < ngroups) ? *reinterpret_cast<const uint4*>(gm + 4 * t)
+                                          : make_uint4(4 * t < ngroups ? gm[4 * t] : 0u, 4 * t + 1 < ngroups ? gm[4 * t + 1] : 0u,
+                                                       4 * t + 2 < ngroups ? gm[4 * t + 2] : 0u, 0u);
+    const uint32_t u = m.x | m.y | m.z | m.w;
     return (u >> 31) ? __popc(u & 0x07FFFFFFu) : 0;      // a task of padding groups only costs nothing
   };
-  __shared__ int32_t base[32];
-  if (lane < 32) base[lane] = 0;
+  // lanes of the same cost class among the 64 tasks of a batch: five ballots on the bits of the cost (0..27)
+  auto peers_of = [&](int c, bool act) {
+    unsigned long long p = __ballot(act);
+#pragma unroll
+    for (int bit = 0; bit < 5; ++bit) {
+      const bool on = (c >> bit) & 1;
+      const unsigned long long bal = __ballot(on);
+      p &= on ? bal : ~bal;
+    }
+    return act ? p : 0ull;
+  };
+  __shared__ int32_t cnt[32];
+  if (lane < 32) cnt[lane] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  // pass 1: tasks per cost class
-  int32_t mine = 0;                                      // lane c < 28 accumulates the count of class c
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  // pass 1: tasks per cost class (the first lane of every class adds its batch's count; one writer per address and batch)
   for (int tb = t0; tb < t1; tb += 64) {
     const int t = tb + lane;
-    const int c = t < t1 ? cost_of(t) : -1;
-#pragma unroll
-    for (int cc = 0; cc < 28; ++cc) {
-      const int n = __popcll(__ballot(c == cc));
-      if (lane == cc) mine += n;
-    }
+    const bool act = t < t1;
+    const int c = act ? cost_of(t) : 0;
+    const unsigned long long p = peers_of(c, act);
+    if (act && (p & lt) == 0) cnt[c] += __popcll(p);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  // descending order: class 27 first.  start[c] = sum of counts of classes > c
-  int32_t start = 0;
+  // descending order: class 27 first.  base[c] = tasks of classes > c
   {
-    int32_t run = 0;
+    const int32_t mine = lane < 32 ? cnt[lane] : 0;
+    int32_t start = 0, run = 0;
     for (int cc = 27; cc >= 0; --cc) {
       const int32_t n = __shfl(mine, cc, 64);
       if (lane == cc) start = run;
       run += n;
     }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32) cnt[lane] = start;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  if (lane < 28) base[lane] = start;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   // pass 2: stable scatter
-  const unsigned long long lt = (1ull << lane) - 1ull;
   for (int tb = t0; tb < t1; tb += 64) {
     const int t = tb + lane;
-    const int c = t < t1 ? cost_of(t) : -1;
-#pragma unroll
-    for (int cc = 0; cc < 28; ++cc) {
-      const unsigned long long m = __ballot(c == cc);
-      if (c == cc) a.order[j][t0 + base[cc] + __popcll(m & lt)] = t;
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0 && m) base[cc] += __popcll(m);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    const bool act = t < t1;
+    const int c = act ? cost_of(t) : 0;
+    const unsigned long long p = peers_of(c, act);
+    const int32_t b = act ? cnt[c] : 0;
+    if (act) a.order[j][t0 + b + __popcll(p & lt)] = t;
+    __builtin_amdgcn_wave_barrier();
+    if (act && (p & lt) == 0) cnt[c] = b + __popcll(p);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
