@@ -11,6 +11,7 @@
 //     ME's floor(c / 2^l) * 2^l because the bias 2^(CB-1) is a multiple of 2^9.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -56,6 +57,15 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// "set this kernel's dynamic-LDS attribute once" — once per (kernel, DEVICE), safe from several host threads (a process may
+// hold contexts on several GPUs; a racing second call only repeats an idempotent setting)
+struct AttrOnce {
+  std::atomic<uint64_t> done{0};
+  static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+  bool need() const { return !((done.load(std::memory_order_acquire) >> dev()) & 1ull); }
+  void mark() { done.fetch_or(1ull << dev(), std::memory_order_release); }
+};
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------ device arena (grow-only)

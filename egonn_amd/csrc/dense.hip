@@ -393,11 +393,11 @@ int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const floa
     const unsigned g1 = (unsigned)std::min<int64_t>(cdiv(cdiv(n, 16), 4), (blk_bytes > 72 * 1024 ? 256 : 512) / ny);
 #define EGONN_DENSE_LDS_LAUNCH(WOI, CI, INB)                                                                           \
   {                                                                                                                   \
-    static bool attr_done = false;                                                                                    \
-    if (!attr_done) {                                                                                                 \
+    static AttrOnce attr_done;                                                                                    \
+    if (attr_done.need()) {                                                                                                 \
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_lds_kernel<WOI, CI, INB>),                   \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
-      attr_done = true;                                                                                               \
+      attr_done.mark();                                                                                                \
     }                                                                                                                 \
     hipLaunchKernelGGL((dense_lds_kernel<WOI, CI, INB>), dim3(g1, ny), dim3(256), blk_bytes + 3 * (size_t)colblk * sizeof(float), stream, in, n, W, cout, bias, scale, \
                        shift, act, residual, out, io, n_dev, colblk);                                                 \
@@ -1006,10 +1006,10 @@ int local_heads_forward(const float* x, int64_t n, const int32_t* n_dev, const f
   a.out_desc = out_desc; a.out_kp = out_kp; a.out_sigma = out_sigma;
   const int64_t tiles = cdiv(n, 16);
   const size_t lds = (size_t)LH_FRAGS * 64 * sizeof(f32x4);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_done;
+  if (attr_done.need()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&local_heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+    attr_done.mark(); 
   }
   const unsigned grid = (unsigned)std::min<int64_t>(cdiv(tiles, LH_WAVES), 256);      // one workgroup per CU holds the weights
   hipLaunchKernelGGL(local_heads_kernel, dim3(grid), dim3(LH_WAVES * 64), lds, stream, a);
@@ -1172,11 +1172,11 @@ int select_topk(const float* sigma, const int32_t* boff_dev, int B, int k, const
   int S = 64;
   while (S < k) S <<= 1;
   const size_t lds = (size_t)(S + (k <= 512 ? k : 0)) * sizeof(unsigned long long);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_done;
+  if (attr_done.need()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   128 * 1024));
-    attr_done = true;
+    attr_done.mark(); 
   }
   hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(TK_THREADS), lds, stream, sigma, boff_dev, k, S, kp, desc, dc, sel_rows,
                      sel_count, out_kp, out_desc);

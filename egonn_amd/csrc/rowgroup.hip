@@ -369,11 +369,11 @@ int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream) {
   a.nblocks = nb;
   a.trace = g_sconv_trace;
   if (nb == 0) return EGONN_OK;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_done;
+  if (attr_done.need()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgroup_build_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));   // + 19 KB static
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgroup_build_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_done = true;
+    attr_done.mark(); 
   }
   size_t lds = 0;                                        // the largest window table of the launch
   for (int j = 0; j < njobs; ++j) lds = std::max(lds, (size_t)jobs[j].rg->win * jobs[j].rg->K * sizeof(int32_t));

@@ -782,11 +782,11 @@ static int launch_dma_d(const SconvArgs& a, int64_t groups_hint, hipStream_t str
   auto go = [&](auto NWC) -> int {
     constexpr int NW = decltype(NWC)::value;
     const size_t lds = NW * ((2 * 256 + 32) * 4 + D * 2048);
-    static bool attr_done = false;                       // per instantiation (the lambda is instantiated per NW)
-    if (!attr_done) {
+    static AttrOnce attr_done;                       // per instantiation (the lambda is instantiated per NW)
+    if (attr_done.need()) {
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_dma_kernel<CIN, COUT, D, KSP, NW, TRACE, PIPE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_done = true;
+      attr_done.mark(); 
     }
     const int64_t ntask = cdiv(groups_hint * NS * KSP, NW);
     int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 65536);
@@ -1037,11 +1037,11 @@ static int launch_wg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
   constexpr int NW = 4;
   constexpr int ES = BF16 ? 2 : 4;
   const size_t lds = 2 * (size_t)(32 * COUT * ES) + NW * 28 * 16 * sizeof(int32_t);
-  static bool attr_done = false;                         // per instantiation; idempotent
-  if (!attr_done) {
+  static AttrOnce attr_done;                         // per instantiation; idempotent
+  if (attr_done.need()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_wg_kernel<CIN, COUT, BF16, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+    attr_done.mark(); 
   }
   const int64_t ntask = cdiv(groups_hint, NW);
   int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 16384);
@@ -1064,11 +1064,11 @@ static int launch_rg_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stre
   constexpr int NW = KSP;                                // a workgroup = the waves that share a tile (see launch_dma_d)
   constexpr int NPIECE = (G * 27 * 4 + 63) / 64;
   const size_t lds = NW * (NPIECE * 256 + 16) * sizeof(int32_t) + (KSP > 1 ? 2 * NW * 2 * G * 64 * sizeof(f32x4) : 0);
-  static bool attr_done = false;                         // per instantiation; idempotent
-  if (!attr_done && lds > 48 * 1024) {
+  static AttrOnce attr_done;                         // per instantiation; idempotent
+  if (attr_done.need() && lds > 48 * 1024) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+    attr_done.mark(); 
   }
   const int64_t ntask = cdiv(cdiv(groups_hint, G) * NS * KSP, NW);
   // one workgroup per task up to a cap: the hardware dispatcher then balances the uneven tasks (a grid of only the

@@ -353,6 +353,10 @@ def global_branch(model, ctx, group=None, levels=None) -> torch.Tensor:
     net = model.global_descriptor_decoder.net
     x = LinearFn.apply(x, net[0].linear.weight, net[0].linear.bias, ctx, True)
     x = LinearFn.apply(x, net[2].linear.weight, net[2].linear.bias, ctx, False)
+    method = getattr(model, "global_pool_method", "GeM")
+    if method != "GeM":          # MAC / SPoC (layers/pooling.py:46-69) exist for eval-mode forwards only
+        raise NotImplementedError(f"train-mode forward is implemented for GeM pooling; this model pools with {method!r} "
+                                  "(use model.eval(), or train with pool_method='GeM' as config_egonn.txt does)")
     return GeMFn.apply(x, model.global_pooling.pooling.p, ctx, lvl)
 
 

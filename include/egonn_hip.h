@@ -114,8 +114,13 @@ int egonn_conv_transpose(egonn_ctx* ctx, int level_in, const float* in, int cin,
 /* The operator behind the two calls above, with explicit map and precision.  map_kind 0: kernel_size 3 on level_out;
  * 1: kernel_size 2 / stride 2 from level_out-1 into level_out; 2: transposed (k=2,s=2) from level_out+1 onto level_out.
  * bf16 = 1: `in` and `out` are bf16 feature maps (BASELINE configs[2]); the fp32 kernel is rounded to bf16, products
- * accumulate in fp32.  group_sums (nullable): (n_groups, cout) fp32 column sums of the stored output per group of 16
- * rows (egonn_map_groups) — the conv2 epilogue form of MinkowskiGlobalPooling (layers/eca_block.py:16,26). */
+ * accumulate in fp32.  group_sums (nullable): (n_groups, cout) fp32 column sums of the output per group of 16 rows
+ * (egonn_map_groups) — the conv2 epilogue form of MinkowskiGlobalPooling (layers/eca_block.py:16,26).  With bf16 maps the
+ * sums are taken over the fp32 values BEFORE they are rounded to bf16 for storage (the pooled mean is then the mean of the
+ * unrounded activations: closer to the fp32 path than a mean of the stored bf16 numbers; within the configs[2] tolerance).
+ * fp32 maps of levels <= 4 run on the bf16 matrix pipe with exactly split operands (six bf16 products per fp32 product, fp32
+ * accumulate: max deviation from the exact fp32 kernel 1.6e-6 of the largest output); egonn_debug_set_naive_conv selects
+ * the exact kernels. */
 int egonn_sparse_conv(egonn_ctx* ctx, int map_kind, int level_out, const void* in, int cin, const float* kernel, int cout,
                       int bf16, const float* scale, const float* shift, int relu, void* out, float* group_sums,
                       void* stream);
