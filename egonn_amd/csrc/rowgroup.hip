@@ -266,7 +266,8 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
 // of tasks whose length (offsets present in the union of the task's groups) varies 5..25 steps: in table order the last
 // round is as long as its longest task and the chip idles behind it (tools/split_trace.py: 53 % packing on L1 k3).  Inside
 // every contiguous eighth of the tasks (one XCD: the locality of the Z-order slice is kept) the tasks are therefore stably
-// sorted by descending step count — longest first.  One wave per (map, eighth): counting sort with ballot ranks.
+// sorted by descending step count — longest first.  One workgroup of 8 waves per (map, eighth), every wave a contiguous slice:
+// counting sort with ballot ranks.
 struct RGOrderArgs {
   const uint32_t* gmask[RG_MAX_JOBS];
   const int32_t* meta[RG_MAX_JOBS];
@@ -274,13 +275,17 @@ struct RGOrderArgs {
   int cap_groups[RG_MAX_JOBS];
   int njobs;
 };
-__global__ __launch_bounds__(64) void rowgroup_order_kernel(const RGOrderArgs a) {
-  const int j = blockIdx.x >> 3, xcd = blockIdx.x & 7, lane = threadIdx.x;
+static constexpr int ORD_WAVES = 8;
+__global__ __launch_bounds__(ORD_WAVES * 64) void rowgroup_order_kernel(const RGOrderArgs a) {
+  const int j = blockIdx.x >> 3, xcd = blockIdx.x & 7, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (j >= a.njobs || !a.order[j]) return;
   const int ngroups = min(a.meta[j][0], a.cap_groups[j]);
   const int ntask = (ngroups + 3) >> 2;
   const int cpx = (ntask + 7) >> 3;
   const int t0 = xcd * cpx, t1 = min(t0 + cpx, ntask);
+  // every wave owns a contiguous slice of the eighth (stable: slices in wave order)
+  const int per_wave = ((t1 - t0 + ORD_WAVES - 1) / ORD_WAVES + 63) / 64 * 64;
+  const int w0 = min(t0 + wave * per_wave, t1), w1 = min(w0 + per_wave, t1);
   const uint32_t* gm = a.gmask[j];
   auto cost_of = [&](int t) {
     const uint4 m = (4 * t + 3 < ngroups) ? *reinterpret_cast<const uint4*>(gm + 4 * t)
@@ -300,47 +305,50 @@ __global__ __launch_bounds__(64) void rowgroup_order_kernel(const RGOrderArgs a)
     }
     return act ? p : 0ull;
   };
-  __shared__ int32_t cnt[32];
-  if (lane < 32) cnt[lane] = 0;
+  __shared__ int32_t cnt[ORD_WAVES][32];
+  if (lane < 32) cnt[wave][lane] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const unsigned long long lt = (1ull << lane) - 1ull;
-  // pass 1: tasks per cost class (the first lane of every class adds its batch's count; one writer per address and batch)
-  for (int tb = t0; tb < t1; tb += 64) {
+  // pass 1: this wave's tasks per cost class (the first lane of every class adds its batch's count)
+  for (int tb = w0; tb < w1; tb += 64) {
     const int t = tb + lane;
-    const bool act = t < t1;
+    const bool act = t < w1;
     const int c = act ? cost_of(t) : 0;
     const unsigned long long p = peers_of(c, act);
-    if (act && (p & lt) == 0) cnt[c] += __popcll(p);
+    if (act && (p & lt) == 0) cnt[wave][c] += __popcll(p);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  // descending order: class 27 first.  base[c] = tasks of classes > c
-  {
-    const int32_t mine = lane < 32 ? cnt[lane] : 0;
+  __syncthreads();
+  // descending order: class 27 first.  base[w][c] = tasks of classes > c (all waves) + tasks of class c in earlier waves
+  if (wave == 0) {
+    int32_t mine[ORD_WAVES], tot = 0;
+#pragma unroll
+    for (int w = 0; w < ORD_WAVES; ++w) { mine[w] = lane < 32 ? cnt[w][lane] : 0; tot += mine[w]; }
     int32_t start = 0, run = 0;
     for (int cc = 27; cc >= 0; --cc) {
-      const int32_t n = __shfl(mine, cc, 64);
+      const int32_t n = __shfl(tot, cc, 64);
       if (lane == cc) start = run;
       run += n;
     }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 32) cnt[lane] = start;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 32) {
+#pragma unroll
+      for (int w = 0; w < ORD_WAVES; ++w) { cnt[w][lane] = start; start += mine[w]; }
+    }
   }
-  // pass 2: stable scatter
-  for (int tb = t0; tb < t1; tb += 64) {
+  __syncthreads();
+  // pass 2: stable scatter of this wave's slice
+  for (int tb = w0; tb < w1; tb += 64) {
     const int t = tb + lane;
-    const bool act = t < t1;
+    const bool act = t < w1;
     const int c = act ? cost_of(t) : 0;
     const unsigned long long p = peers_of(c, act);
-    const int32_t b = act ? cnt[c] : 0;
+    const int32_t b = act ? cnt[wave][c] : 0;
     if (act) a.order[j][t0 + b + __popcll(p & lt)] = t;
     __builtin_amdgcn_wave_barrier();
-    if (act && (p & lt) == 0) cnt[c] = b + __popcll(p);
+    if (act && (p & lt) == 0) cnt[wave][c] = b + __popcll(p);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -389,7 +397,7 @@ int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream) {
     any |= jobs[j].rg->order4 != nullptr;
   }
   if (any) {
-    hipLaunchKernelGGL(rowgroup_order_kernel, dim3((unsigned)(njobs * 8)), dim3(64), 0, stream, oa);
+    hipLaunchKernelGGL(rowgroup_order_kernel, dim3((unsigned)(njobs * 8)), dim3(ORD_WAVES * 64), 0, stream, oa);
     HIP_CHECK(hipGetLastError());
   }
   return EGONN_OK;
