@@ -17,7 +17,8 @@ for s in scans: off.append(off[-1] + len(s))
 pts = torch.from_numpy(np.concatenate(scans)).cuda()
 ctx = _lib.Context(coord_bits=12)
 ctx.voxelize(pts, off, 0, [0.1])
-cfgs = [(1, 1, 32, 32), (0, 1, 32, 32), (1, 2, 32, 32), (0, 2, 32, 64), (0, 2, 64, 64), (1, 3, 64, 64), (0, 3, 64, 64)]
+cfgs = [(1, 1, 32, 32), (0, 1, 32, 32), (1, 2, 32, 32), (0, 2, 32, 64), (0, 2, 64, 64), (1, 3, 64, 64), (0, 3, 64, 64),
+        (0, 4, 128, 128), (0, 5, 128, 128), (0, 6, 128, 128), (0, 7, 128, 128)]      # 128->128: the traced split-bf16 per-tile kernel
 kind, lvl, ci, co = cfgs[int(os.environ.get("LAYER", 1))]
 lin = lvl if kind == 0 else (lvl - 1 if kind == 1 else lvl + 1)
 K = 27 if kind == 0 else 8
@@ -28,7 +29,7 @@ ng = ctx.map_groups(kind, lvl)[0]
 ksp = min(ci // 32, 4)
 ntr = ng * (co // 32) * ksp
 buf = torch.zeros((ntr + 64, 8), dtype=torch.int64, device="cuda")
-ctx.lib.egonn_debug_set_naive_conv(ctx.h, 128)
+ctx.lib.egonn_debug_set_naive_conv(ctx.h, 2009 if ci == 128 else 128)
 for _ in range(3): ctx.sparse_conv(kind, lvl, x, w)
 buf.zero_()
 ctx.lib.egonn_debug_set_trace(buf.data_ptr())
@@ -51,6 +52,12 @@ for name, a, b in [("tables (t0->t1)", 0, 1), ("prologue issue (t1->t2)", 1, 2),
     print(f"  {name:26s} mean {x_.mean():9.0f}  p10 {np.percentile(x_, 10):9.0f}  p50 {np.percentile(x_, 50):9.0f}  p90 {np.percentile(x_, 90):9.0f} ticks")
 loop = d(2, 3)
 print(f"  items per task mean {items.mean():.1f}; item loop ticks per item {loop.sum() / items.sum():.0f}")
+if ci == 128:      # traced split build: the last two words carry the phase sums of the pipelined item loop
+    ph = [(t[:, 6] >> 32) & 0xFFFFFFFF, t[:, 6] & 0xFFFFFFFF, (t[:, 7] >> 32) & 0xFFFFFFFF, t[:, 7] & 0xFFFFFFFF]
+    nm = (t[:, 5] // 4) * 4
+    for name, v in zip(("issue (8 loads) + generate", "vmcnt wait + LDS read issue", "split + 12 MFMA issue", "LDS wait"), ph):
+        print(f"  per pipelined item: {name:30s} {v.sum() / max(nm.sum(), 1):7.0f} ticks")
+    sys.exit(0)
 # occupancy over time: wave tasks alive per tick-bin, and per SIMD
 hw = t[:, 6].astype(np.int64)
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7   # HW_ID fields (gfx9 layout)

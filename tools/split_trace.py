@@ -16,7 +16,8 @@ for s in scans: off.append(off[-1] + len(s))
 pts = torch.from_numpy(np.concatenate(scans)).cuda()
 ctx = _lib.Context(coord_bits=12)
 ctx.voxelize(pts, off, 0, [0.1])
-cfgs = [(1, 1, 32, 32), (0, 1, 32, 32), (1, 2, 32, 32), (0, 2, 32, 64), (0, 2, 64, 64), (1, 3, 64, 64), (0, 3, 64, 64)]
+cfgs = [(1, 1, 32, 32), (0, 1, 32, 32), (1, 2, 32, 32), (0, 2, 32, 64), (0, 2, 64, 64), (1, 3, 64, 64), (0, 3, 64, 64),
+        (0, 4, 128, 128), (0, 5, 128, 128), (0, 6, 128, 128), (0, 7, 128, 128)]
 kind, lvl, ci, co = cfgs[int(os.environ.get("LAYER", 1))]
 lin = lvl if kind == 0 else (lvl - 1 if kind == 1 else lvl + 1)
 K = 27 if kind == 0 else 8
