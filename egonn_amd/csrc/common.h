@@ -229,11 +229,13 @@ int ensure_level0_parent_table(Ctx* ctx, hipStream_t stream);   // coords.hip
 int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, hipStream_t stream);
 
 // ------------------------------------------------------------------ sort.hip
-// LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits).  Result lands in (keys_out, vals_out).
-// Stable.  keys_in/vals_in are clobbered.  Scratch comes from ctx->sort_arena.
+// LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits).  Result lands in (keys_out, vals_out) — or, when the caller
+// passes keys_res / vals_res, in whichever of the two buffer pairs the last pass wrote (an even number of passes ends in the
+// "in" pair: no copy; the pointers are returned).  Stable.  Both pairs are clobbered.  Scratch comes from ctx->sort_arena.
 // n_dev (nullable): device-resident element count (<= n); n then only sizes the grid and the scratch.
 int radix_sort_pairs(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
-                     int64_t n, int nbits, hipStream_t stream, const int64_t* n_dev = nullptr);
+                     int64_t n, int nbits, hipStream_t stream, const int64_t* n_dev = nullptr, uint64_t** keys_res = nullptr,
+                     uint32_t** vals_res = nullptr);
 size_t radix_sort_scratch_bytes(int64_t n);
 
 // ------------------------------------------------------------------ coords.hip

@@ -742,7 +742,9 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
   Plan& P = ctx->plan;
   const int cb = ctx->coord_bits;
   Arena& A = ctx->plan_arena;
-  EGONN_TRY(radix_sort_pairs(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, 3 * cb + batch_bits(B), stream, n_dev));
+  // (the sorted pairs land in whichever pair the last pass wrote: batches of 17-64 scans need six passes, an even number)
+  EGONN_TRY(radix_sort_pairs(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, 3 * cb + batch_bits(B), stream, n_dev, &keys_sorted,
+                             &vals_sorted));
 
   const int ntiles = (int)cdiv(n, PYR_TILE);
   int32_t* tilecnt = A.alloc<int32_t>((size_t)ntiles * NL);

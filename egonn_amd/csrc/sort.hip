@@ -228,10 +228,12 @@ size_t radix_sort_scratch_bytes(int64_t n) {
 }
 
 int radix_sort_pairs(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
-                     int64_t n, int nbits, hipStream_t stream, const int64_t* n_dev) {
+                     int64_t n, int nbits, hipStream_t stream, const int64_t* n_dev, uint64_t** keys_res, uint32_t** vals_res) {
   EGONN_REQUIRE(n >= 0 && n < (int64_t(1) << 31), EGONN_ERR_INVALID, "radix_sort: n=%lld out of range", (long long)n);
   EGONN_REQUIRE(nbits >= 1 && nbits <= 64, EGONN_ERR_INVALID, "radix_sort: nbits=%d", nbits);
   const int passes = (nbits + 7) / 8;
+  if (keys_res) *keys_res = keys_out;
+  if (vals_res) *vals_res = vals_out;
   if (n == 0) return EGONN_OK;
   const int64_t tiles = cdiv(n, SORT_TILE);
   const int64_t supers = cdiv(tiles, SORT_SUPER);
@@ -246,7 +248,11 @@ int radix_sort_pairs(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* k
   uint64_t* kb[2] = {keys_in, keys_out};
   uint32_t* vb[2] = {vals_in, vals_out};
   int src = (passes % 2 == 1) ? 0 : 1;
-  if (src == 1) {   // even number of passes: start from the "out" buffers
+  if (src == 1 && keys_res && vals_res) {   // even number of passes and a caller that takes either pair: end in the "in" pair
+    src = 0;
+    *keys_res = keys_in;
+    *vals_res = vals_in;
+  } else if (src == 1) {                    // even number of passes: start from the "out" buffers
     HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream));
   }
