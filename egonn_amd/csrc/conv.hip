@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256) void conv0_k5_unit_kernel(const uint64_t* __re
                                                              const float* __restrict__ W,            // [125][32]
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              int relu, void* __restrict__ out_v,
-                                                             const uint16_t* __restrict__ lut) {
+                                                             const uint16_t* __restrict__ lut,
+                                                             const uint4* __restrict__ wpk) {   // conv0_pack_unit (nullable)
   constexpr int MS = 29;                                   // 27 neighbour blocks + the all-zero mask (slot 27)
   constexpr int LUT_STRIDE = 136;                          // entries per row: 16-byte aligned rows, spread over the banks
   __shared__ uint64_t s_m[4][16][MS];
@@ -263,7 +264,17 @@ __global__ __launch_bounds__(256) void conv0_k5_unit_kernel(const uint64_t* __re
   }
   if (tid < 64) s_m[tid >> 4][tid & 15][27] = 0ull;
   // W fragments: wf[nt][j][split] = bf16x8 of W[k = 32 j + 8 g + e][nt * 16 + l15], split = hi / mid / lo
+  // (building them here costs a workgroup ~8 k cycles — as much as its tiles: the launch time grew linearly with the grid,
+  //  profiles/r03l_conv0.txt; the model packs them once, conv0_pack_unit, and a workgroup then loads 24 x 16 bytes per lane)
   bf16x8_c0 wf[2][4][3];
+  if (wpk) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) wf[nt][j][sp] = __builtin_bit_cast(bf16x8_c0, wpk[((nt * 4 + j) * 3 + sp) * 64 + lane]);
+  } else
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -384,6 +395,36 @@ __global__ __launch_bounds__(256) void conv0_k5_unit_kernel(const uint64_t* __re
   }
 }
 
+// W[125][32] -> the unit kernel's MFMA fragments, wpk[((nt * 4 + j) * 3 + split) * 64 + lane] = bf16x8 of
+// split(W[k = 32 j + 8 (lane >> 4) + e][16 nt + (lane & 15)]), e = 0..7 — exactly what the kernel builds when it gets none
+__global__ void conv0_pack_unit_kernel(const float* __restrict__ W, uint4* __restrict__ wpk) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * 4 * 64) return;
+  const int lane = t & 63, j = (t >> 6) & 3, nt = t >> 8;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  uint32_t h[3][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 32 * j + 8 * g4 + e;
+    float w = (k < 125) ? W[k * COUT0 + nt * 16 + l15] : 0.f;
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) {
+      const uint32_t b = bf16_rne(w);
+      h[sp][e] = b;
+      w -= __uint_as_float(b << 16);
+    }
+  }
+#pragma unroll
+  for (int sp = 0; sp < 3; ++sp)
+    wpk[((nt * 4 + j) * 3 + sp) * 64 + lane] = make_uint4(h[sp][0] | (h[sp][1] << 16), h[sp][2] | (h[sp][3] << 16),
+                                                          h[sp][4] | (h[sp][5] << 16), h[sp][6] | (h[sp][7] << 16));
+}
+int conv0_pack_unit(const float* W, void* wpk, hipStream_t stream) {
+  hipLaunchKernelGGL(conv0_pack_unit_kernel, dim3(2), dim3(256), 0, stream, W, reinterpret_cast<uint4*>(wpk));
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
 // (local voxel position, kernel offset) -> (8 * adjacent-block slot) << 6 | bit in that block's mask
 static void conv0_lut_host(uint16_t* lut) {
   for (int lk = 0; lk < 64; ++lk)
@@ -412,7 +453,7 @@ int conv0_lut_init(Ctx* ctx) {
 }
 
 int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, const float* scale,
-                     const float* shift, int relu, void* out, int out_bf16, hipStream_t stream) {
+                     const float* shift, int relu, void* out, int out_bf16, hipStream_t stream, const void* wpk) {
   const Plan& P = ctx->plan;
   EGONN_TRY(conv0_lut_init(ctx));
   EGONN_REQUIRE(cout == COUT0, EGONN_ERR_INVALID, "conv0: %d output channels not supported (expected %d)", cout, COUT0);
@@ -420,7 +461,10 @@ int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, cons
   const Level& B = P.lv[2];
   if (P.cap[0] == 0) return EGONN_OK;
   const int32_t ntiles = (int32_t)cdiv(P.cap[0], 16);
-  const unsigned grid = (unsigned)std::min<int64_t>(cdiv(ntiles, 4), 1536);
+  // two workgroups per CU, each wave walks ~11 tiles (batch 16): the per-workgroup set-up (16 KB lookup table -> LDS, W
+  // fragments, BN vectors, first tables) is paid 512 times instead of 1 536 and every CU gets the same share.  Measured
+  // (profiles/r03l_conv0.txt): 384 / 512 / 640 / 768 / 1024 / 1536 / 2560 workgroups = 39.8 / 32.8 / 42.7 / 41.0 / 37.0 / 40.3 / 45.9 us
+  const unsigned grid = (unsigned)std::min<int64_t>(cdiv(ntiles, 4), 512);
   EGONN_REQUIRE(P.g0 && P.t2m && P.t2s, EGONN_ERR_STATE, "conv0: plan has no block-neighbourhood table");
 #define EGONN_CONV0_LAUNCH(U, OB)                                                                                      \
   hipLaunchKernelGGL((conv0_k5_kernel<U, OB>), dim3(grid), dim3(256), 0, stream, feat, V.keys, P.g0, P.t2m, P.t2s,       \
@@ -432,10 +476,12 @@ int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, cons
   } else {                                                 // unit features: exact bf16 x 3 split of the kernel
     if (out_bf16)
       hipLaunchKernelGGL((conv0_k5_unit_kernel<true>), dim3(grid), dim3(256), 0, stream, V.keys, P.g0, P.t2m, ctx->dev_counts,
-                         (int32_t)P.cap[2], (int32_t)P.cap[0], W, scale, shift, relu, out, ctx->conv0_lut);
+                         (int32_t)P.cap[2], (int32_t)P.cap[0], W, scale, shift, relu, out, ctx->conv0_lut,
+                         reinterpret_cast<const uint4*>(wpk));
     else
       hipLaunchKernelGGL((conv0_k5_unit_kernel<false>), dim3(grid), dim3(256), 0, stream, V.keys, P.g0, P.t2m, ctx->dev_counts,
-                         (int32_t)P.cap[2], (int32_t)P.cap[0], W, scale, shift, relu, out, ctx->conv0_lut);
+                         (int32_t)P.cap[2], (int32_t)P.cap[0], W, scale, shift, relu, out, ctx->conv0_lut,
+                         reinterpret_cast<const uint4*>(wpk));
   }
 #undef EGONN_CONV0_LAUNCH
   HIP_CHECK(hipGetLastError());

@@ -39,7 +39,8 @@ int sconv_naive(const float* in, const int32_t* nbr, const float* W, const float
                 float* out, int64_t n_out, int K, int cin, int cout, hipStream_t stream);
 int conv0_lut_init(Ctx* ctx);      // first-layer lookup table (built once per context)
 int conv0_k5_forward(Ctx* ctx, const float* feat, const float* W, int cout, const float* scale,
-                     const float* shift, int relu, void* out, int out_bf16, hipStream_t stream);
+                     const float* shift, int relu, void* out, int out_bf16, hipStream_t stream, const void* wpk = nullptr);
+int conv0_pack_unit(const float* W, void* wpk, hipStream_t stream);   // 24 KB: the unit-feature kernel's W fragments
 
 // dense.hip ------------------------------------------------------------------------------------
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SOFTPLUS = 3, ACT_SIGMOID = 4 };

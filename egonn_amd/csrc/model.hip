@@ -71,6 +71,7 @@ struct egonn_model {
   // sparse-conv kernels repacked into MFMA fragment order (one buffer, carved in finalize)
   float* packed = nullptr;
   size_t packed_cap = 0;
+  void* conv0_unit = nullptr;   // conv0_pack_unit(conv0): 24 KB
   const float *p_convs[8] = {}, *p_c1[8] = {}, *p_c2[8] = {}, *p_gt[8] = {}, *p_lt[8] = {};
   // the same kernels packed as bf16 (EGONN_FLAG_BF16): [0] = fp32 set, [1] = bf16 set
   const float *q_convs[8] = {}, *q_c1[8] = {}, *q_c2[8] = {}, *q_gt[8] = {}, *q_lt[8] = {};
@@ -490,6 +491,7 @@ API void egonn_model_destroy(egonn_model* m) {
   if (!m) return;
   if (m->folded) (void)hipFree(m->folded);
   if (m->packed) (void)hipFree(m->packed);
+  if (m->conv0_unit) (void)hipFree(m->conv0_unit);
   delete m;
 }
 
@@ -649,6 +651,8 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
     EGONN_TRY(pack2(m->gt[7], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[7], &m->q_gt[7], &m->s_gt[7]));
     EGONN_TRY(pack2(m->lt[4], 8, LOCAL_CH, LOCAL_CH, &m->p_lt[4], &m->q_lt[4], &m->s_lt[4]));
   }
+  if (!m->conv0_unit) HIP_CHECK(hipMalloc(&m->conv0_unit, 2 * 4 * 3 * 64 * 16));
+  EGONN_TRY(conv0_pack_unit(m->conv0, m->conv0_unit, st));
   EGONN_TRY(fold(m->bn[0], st));
   for (int i = 1; i <= 7; ++i) {
     EGONN_TRY(fold(m->bn[i], st));
@@ -743,7 +747,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   FALLOC(x0, n0 * 32);
   {
     ProfScope ps(c, st, "conv0_k5_kernel/L0", PK_CONV0, 0, 125, 1, 32, (int)es);
-    EGONN_TRY(conv0_k5_forward(c, f0, m->conv0, 32, m->bn[0].scale, m->bn[0].shift, 1, x0, bf16, st));
+    EGONN_TRY(conv0_k5_forward(c, f0, m->conv0, 32, m->bn[0].scale, m->bn[0].shift, 1, x0, bf16, st, m->conv0_unit));
   }
   DBG_SYNC("conv0");
   const void* x[8] = {x0};
