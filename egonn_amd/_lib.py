@@ -121,9 +121,22 @@ def _err(lib) -> str:
     return msg.decode() if msg else "unknown error"
 
 
+class EgonnError(RuntimeError):
+    """non-zero status of a libegonn_hip entry point; `.code` is the C status (include/egonn_hip.h EGONN_STATUS_*)"""
+
+    def __init__(self, msg: str, code: int):
+        super().__init__(msg)
+        self.code = int(code)
+
+
+class CapacityError(EgonnError):
+    """status 5: the batch did not fit the capacities of egonn_ctx_reserve (the exact-size eager path still works)"""
+
+
 def check(rc: int):
     if rc != 0:
-        raise RuntimeError(f"libegonn_hip: {_err(load())} (code {rc})")
+        cls = CapacityError if rc == 5 else EgonnError
+        raise cls(f"libegonn_hip: {_err(load())} (code {rc})", rc)
 
 
 def _stream() -> int:

@@ -31,6 +31,7 @@ void set_error(const char* fmt, ...);
 #define EGONN_ERR_HIP 2
 #define EGONN_ERR_RANGE 3
 #define EGONN_ERR_STATE 4
+#define EGONN_ERR_CAPACITY 5   // a batch did not fit the capacities of egonn_ctx_reserve (the eager path still works)
 
 #define HIP_CHECK(expr)                                                                   \
   do {                                                                                    \

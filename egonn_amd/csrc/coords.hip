@@ -722,7 +722,7 @@ int plan_sync(Ctx* ctx, hipStream_t stream) {
               ctx->host_counts[3], ctx->host_counts[4], ctx->host_counts[5], ctx->host_counts[6], ctx->host_counts[7],
               (long long)P.cap[0], (long long)P.cap[1], (long long)P.cap[2], (long long)P.cap[3], (long long)P.cap[4],
               (long long)P.cap[5], (long long)P.cap[6], (long long)P.cap[7]);
-    return EGONN_ERR_RANGE;
+    return EGONN_ERR_CAPACITY;
   }
   for (int l = 0; l < NL; ++l) P.lv[l].n = ctx->host_counts[l];
   for (int l = 0; l < EGONN_NUM_LEVELS; ++l) {

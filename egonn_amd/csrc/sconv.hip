@@ -1140,7 +1140,8 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
   a.in_bytes = (uint32_t)ib;
   a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * (bf16 ? 2 : 4));
   a.K = rg.K; a.relu = relu ? 1 : 0; a.cap_groups = rg.cap_groups;
-  a.order4 = getenv("EGONN_NO_TASK_ORDER") ? nullptr : rg.order4;
+  static const bool no_order = getenv("EGONN_NO_TASK_ORDER") != nullptr;   // (measurement switch)
+  a.order4 = no_order ? nullptr : rg.order4;
   a.trace = variant == 9 ? g_sconv_trace : nullptr;
 
   // Measured (profiles/r02b_sconv.json, batch 16): in fp32 the per-wave kernel wins everywhere (the lock-step of the

@@ -438,8 +438,12 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
 template <int CIN, int COUT, int NW, int NSW, int TERMS, bool TRACE = false>
 static int launch_split(const SplitArgs& a, int64_t groups_hint, hipStream_t stream) {
   using GEO = SplitGeom<NSW, NW>;
-  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_split_kernel<CIN, COUT, NW, NSW, TERMS, TRACE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  static AttrOnce attr_done;
+  if (attr_done.need()) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_split_kernel<CIN, COUT, NW, NSW, TERMS, TRACE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done.mark();
+  }
   const int64_t ntask = cdiv(groups_hint, NW);
   int64_t gridx = std::min<int64_t>(std::max<int64_t>(ntask, 8), 1 << 20);
   gridx = (gridx + 7) / 8 * 8;
@@ -711,9 +715,13 @@ static int launch_wide(const SplitArgs& a, int64_t groups_hint, hipStream_t stre
   return EGONN_OK;
 }
 
+// exactly the channel plans EGONN_SP_PLAN instantiates below (the forward plans of the trunk and heads + the two
+// input-gradient plans); every other pair stays on the exact kernels of sconv.hip
 bool sconv_split_supported(int cin, int cout) {
-  auto ok = [](int c) { return c == 32 || c == 64 || c == 128; };
-  return ok(cin) && ok(cout);
+  static const int plans[][2] = {{32, 32}, {32, 64}, {64, 64}, {64, 128}, {128, 128}, {64, 32}, {128, 64}};
+  for (const auto& p : plans)
+    if (p[0] == cin && p[1] == cout) return true;
+  return false;
 }
 
 // cfg = terms_sel * 1000 + G * 100 + NW * 10 + DA (terms_sel 0: 6 terms, 1: 3, 2: 9); 0 = product choice
@@ -727,7 +735,8 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
   if (groups_hint <= 0) return EGONN_OK;
   SplitArgs a;
   a.in = in; a.snbr = rg.snbr; a.gmask = rg.gmask; a.perm = rg.perm; a.meta = rg.meta; a.Wsp = Wsp;
-  a.order = getenv("EGONN_NO_TASK_ORDER") ? nullptr : rg.order4;       // (measurement switch)
+  static const bool no_order = getenv("EGONN_NO_TASK_ORDER") != nullptr;   // (measurement switch)
+  a.order = no_order ? nullptr : rg.order4;
   a.scale = scale; a.shift = shift; a.out = out; a.psum = psum;
   a.in_rows = (uint32_t)n_in_cap;
   a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * 6);

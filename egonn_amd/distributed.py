@@ -136,9 +136,10 @@ def build_database_streaming(streamer, sources: Sequence, keep_local: bool = Fal
     n_scans = len(sources)
     lo, hi = shard_bounds(n_scans, rank, world)
     B = streamer.batch_size
-    old_keep = streamer.keep_local
-    if streamer.slots and old_keep != keep_local:
-        raise ValueError("build_database_streaming: the streamer was built with a different keep_local")
+    # keep_local is part of what a slot's captured graph copies back: it is fixed by the FIRST run of a streamer (the slots
+    # are built then) and a later call with another value is refused rather than silently changing the streamer
+    if streamer.slots and streamer.keep_local != keep_local:
+        raise ValueError("build_database_streaming: the streamer's slots were built with a different keep_local")
     streamer.keep_local = keep_local
     batches = ([sources[i] for i in range(s0, min(s0 + B, hi))] for s0 in range(lo, hi, B))
     globals_, kps, descs, counts = [], [], [], []

@@ -80,9 +80,9 @@ class _Slot(GraphExtractor):
                 self.stream.synchronize()
                 try:
                     self.ctx.plan_status()
-                except RuntimeError as e:                  # the slot's first batch already overflows the reservation: the
-                    if "reserve" not in str(e):            # capture below is still valid (fixed capacities), the replay is
-                        raise                              # flagged again and collect() takes the eager path
+                except _lib.CapacityError:                 # the slot's first batch already overflows the reservation: the
+                    pass                                   # capture below is still valid (fixed capacities), the replay is
+                                                           # flagged again and collect() takes the eager path
                 g = _lib._P()
                 _lib.check(self.ctx.lib.egonn_graph_begin(self.stream.cuda_stream))
                 try:
@@ -104,9 +104,7 @@ class _Slot(GraphExtractor):
         self.done.synchronize()
         try:
             self.status()
-        except RuntimeError as e:
-            if "reserve" not in str(e):
-                raise
+        except _lib.CapacityError:
             return self._fallback()
         n = self.n_real
         res = {"global": self.h_global[:n].clone(), "count": self.h_count[:n].clone()}
@@ -196,17 +194,23 @@ class StreamingExtractor:
             self.slots = [_Slot(self, i) for i in range(self.n_slots)]
         inflight: List[_Slot] = []
         i = 0
-        for batch in batches:
-            assert 1 <= len(batch) <= self.batch_size
-            if len(inflight) == self.n_slots:
+        try:
+            for batch in batches:
+                assert 1 <= len(batch) <= self.batch_size
+                if len(inflight) == self.n_slots:
+                    yield inflight.pop(0).collect()
+                slot = self.slots[i % self.n_slots]
+                i += 1
+                n_rows = self._stage(slot, batch)
+                slot.submit(n_rows, len(batch))
+                inflight.append(slot)
+            while inflight:
                 yield inflight.pop(0).collect()
-            slot = self.slots[i % self.n_slots]
-            i += 1
-            n_rows = self._stage(slot, batch)
-            slot.submit(n_rows, len(batch))
-            inflight.append(slot)
-        while inflight:
-            yield inflight.pop(0).collect()
+        finally:
+            # a consumer that abandons the generator early leaves batches in flight: wait for them, so that the next
+            # run() (which restarts at slot 0) never overwrites a pinned staging buffer a copy or graph still reads
+            for slot in inflight:
+                slot.done.synchronize()
 
     def close(self):
         self.pool.shutdown(wait=False)

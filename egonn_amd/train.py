@@ -462,20 +462,18 @@ class TrainStep:
 
     def __call__(self, batch: Dict[str, torch.Tensor], positives_mask: torch.Tensor, negatives_mask: torch.Tensor,
                  step_optimizer: bool = True, shard_sizes=None):
-        """shard_sizes: scans per rank (every rank knows them from the sampler); default: the contiguous balanced partition
-        `distributed.shard_bounds` of the B = positives_mask.shape[0] scans — the embedding exchange is then ONE all-gather."""
+        """shard_sizes: scans per rank when every rank knows them from the sampler (e.g. `distributed.shard_bounds` of the
+        B = positives_mask.shape[0] scans): the embedding exchange is then ONE all-gather with no host synchronisation.
+        Default (None): the sizes are exchanged first, so ANY sharding works and a mismatch can never leave some ranks
+        inside a collective the others did not enter."""
         import torch.distributed as dist
-        from .distributed import all_gather_embeddings, shard_bounds
+        from .distributed import all_gather_embeddings
         sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         model = self.model
         model.train()
         model.sync_bn_group = dist.group.WORLD if sharded else None
         self.optimizer.zero_grad(set_to_none=True)
         y = model(batch, disable_local_head=True)
-        if sharded and shard_sizes is None:
-            world = dist.get_world_size()
-            bounds = [shard_bounds(int(positives_mask.shape[0]), r, world) for r in range(world)]
-            shard_sizes = [hi - lo for lo, hi in bounds]
         emb = all_gather_embeddings(y['global'], shard_sizes if sharded else None)
         dev = emb.device
         loss, stats, _ = self.loss_fn(emb, positives_mask.to(dev), negatives_mask.to(dev))

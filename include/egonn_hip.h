@@ -30,6 +30,9 @@ typedef struct egonn_ctx egonn_ctx;       /* one per (device, stream user); owns
 typedef struct egonn_model egonn_model;   /* EgoNN weights registered by state_dict key */
 
 enum { EGONN_QUANT_CARTESIAN = 0, EGONN_QUANT_POLAR = 1 };
+/* status codes returned by every entry point (0 = ok; egonn_last_error() holds the text) */
+enum { EGONN_STATUS_OK = 0, EGONN_STATUS_INVALID = 1, EGONN_STATUS_HIP = 2, EGONN_STATUS_RANGE = 3, EGONN_STATUS_STATE = 4,
+       EGONN_STATUS_CAPACITY = 5 };
 enum { EGONN_FLAG_DISABLE_GLOBAL = 1, EGONN_FLAG_DISABLE_LOCAL = 2, EGONN_FLAG_IGNORE_KP_REGRESSOR = 4,
        /* BASELINE configs[2]: feature maps and sparse-conv weights are bf16 in HBM (2 bytes per element), products
         * accumulate in fp32 on v_mfma_f32_16x16x32_bf16; the dense heads, pooling and all outputs stay fp32 */
@@ -71,8 +74,10 @@ int egonn_voxelize(egonn_ctx* ctx, const float* points, const int64_t* scan_offs
  * so the sequence voxelize_device -> forward -> select_keypoints can be captured into a hipGraph once and replayed on
  * other batches.  Outputs of a reserved plan are sized by the capacities (out_descriptors: level_capacity[3] rows).
  * egonn_plan_status [SYNC] copies the sizes and the error state of the latest (replayed) plan to the host: non-zero if a
- * coordinate left the +-2^(coord_bits-1) range or the batch did not fit the reservation (the outputs are then invalid);
- * afterwards egonn_level_count / egonn_level_batch_offsets return that batch's true sizes. */
+ * coordinate left the +-2^(coord_bits-1) range (status 3) or the batch did not fit the reservation (status 5 =
+ * EGONN_STATUS_CAPACITY; the outputs are then invalid — checking the status is MANDATORY for reserved plans: out-of-range /
+ * non-finite points are clamped into their sample and overflowing rows are clipped, so an unchecked batch yields
+ * plausible-looking but wrong descriptors); afterwards egonn_level_count / egonn_level_batch_offsets return that batch's true sizes. */
 int egonn_ctx_reserve(egonn_ctx* ctx, int64_t max_points, int batch_size, const int64_t* level_capacity);
 int egonn_voxelize_device(egonn_ctx* ctx, const float* points, int64_t n_rows, const int64_t* scan_offsets_dev,
                           int batch_size, int quant_mode, const float* step, void* stream);
@@ -120,7 +125,8 @@ int egonn_conv_transpose(egonn_ctx* ctx, int level_in, const float* in, int cin,
  * unrounded activations: closer to the fp32 path than a mean of the stored bf16 numbers; within the configs[2] tolerance).
  * fp32 maps of levels <= 4 run on the bf16 matrix pipe with exactly split operands (six bf16 products per fp32 product, fp32
  * accumulate: max deviation from the exact fp32 kernel 1.6e-6 of the largest output); egonn_debug_set_naive_conv selects
- * the exact kernels. */
+ * the exact kernels.  Non-finite inputs: the three-way split of +-Inf yields NaN (Inf - Inf), so an Inf activation comes out
+ * of these kernels as NaN where the exact fp32 kernels propagate Inf; NaN stays NaN on both. */
 int egonn_sparse_conv(egonn_ctx* ctx, int map_kind, int level_out, const void* in, int cin, const float* kernel, int cout,
                       int bf16, const float* scale, const float* shift, int relu, void* out, float* group_sums,
                       void* stream);

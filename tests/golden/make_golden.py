@@ -13,6 +13,7 @@ No reference source text is stored — only arrays the reference code computed.
 
     python tests/golden/make_golden.py            # rewrite the inference fixtures
     python tests/golden/make_golden.py train      # rewrite the train-step fixtures
+    python tests/golden/make_golden.py only NAME  # rewrite one inference fixture
 """
 from __future__ import annotations
 
@@ -83,6 +84,8 @@ CASES = [
     ("egonn_cart01_b2", "cartesian", "0.1",          [(5, 8000), (6, 6000)],    12, False),
     ("egonn_cart03_b1", "cartesian", "0.3",          [(1, 40000)],              13, True),
     ("egonn_polar_b1",  "polar",     "1., 0.3, 0.2", [(1, 40000)],              14, True),
+    # BASELINE configs[1] cloud size (50 000 points, 0.1 m): the benchmark shape through the reference's own graph code
+    ("egonn_cart01_50k_b2", "cartesian", "0.1",      [(100, 50000), (101, 50000)], 15, False),
 ]
 
 
@@ -96,13 +99,16 @@ def main():
 
     torch.manual_seed(0)
     shapes_written = False
+    only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "only" else None
     for name, coordinates, step, scans, wseed, filt in CASES:
+        if only and name != only:
+            continue
         mp = model_params(coordinates, step)
         model = model_factory(mp)
         model.eval()
         sd = model.state_dict()
         shapes = {k: [int(s) for s in v.shape] for k, v in sd.items()}
-        if not shapes_written:
+        if not shapes_written and not only:
             with open(os.path.join(HERE, "egonn_state_dict_shapes.json"), "w") as f:
                 json.dump(shapes, f, indent=0, sort_keys=True)
             shapes_written = True
@@ -157,6 +163,8 @@ def main():
 
     # ---- MinkLoc3D / MinkLoc (MinkFPN backbone + GeM): reference models/minkfpn.py, models/minkloc.py,
     #      third_party/minkloc3d/minkloc.py executed on the stand-in
+    if only:
+        return
     for name, mname, block, step, scans, wseed in MINKLOC_CASES:
         mp = minkloc_params(mname, step, block)
         model = model_factory(mp)

@@ -231,6 +231,30 @@ def test_conv_primitives_vs_oracle(gpu, naive):
         ctx.set_naive_conv(False)
 
 
+def test_conv_every_channel_pair_at_split_levels(gpu):
+    """generic operator API: every Cin, Cout in {32, 64, 128} at a level where the product choice is the split-bf16 /
+    window kernel family — pairs without a split instantiation (32->128, 128->32) must fall through to the exact
+    kernels (they failed with 'no instantiation')."""
+    from oracle import me_ops as ops
+    case = H.load_case("egonn_cart01_b2")
+    c4 = case["coords"]
+    lv = _oracle_levels(c4)
+    ctx = gpu._lib.Context()
+    ctx.coords_set(torch.from_numpy(c4).cuda(), 2)
+    rng = np.random.default_rng(5)
+    for level in (2, 4):
+        perm_in = H.join_perm(lv.coords[level], _np(ctx.level_coords(level)))
+        perm_out = H.join_perm(_np(ctx.level_coords(level)), lv.coords[level])
+        for cin in (32, 64, 128):
+            for cout in (32, 64, 128):
+                f = rng.standard_normal((lv.n(level), cin)).astype(np.float32)
+                w = (rng.standard_normal((27, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+                want = ops.conv_forward(f, w, lv.kmap(level, level, 3), lv.n(level))
+                got = _np(ctx.conv(level, level, 3, torch.from_numpy(f[perm_in]), torch.from_numpy(w)))[perm_out]
+                err = np.abs(got - want).max() / (np.abs(want).max() + 1e-6)
+                assert err < 2e-5, (level, cin, cout, err)
+
+
 def test_conv_known_answer_line(gpu):
     """hand-derivable case: three voxels on a line (same as tests/test_oracle.py)."""
     ctx = gpu._lib.Context()
