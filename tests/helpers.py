@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["egonn_cart01_b1", "egonn_cart01_b2", "egonn_cart03_b1", "egonn_polar_b1"]
+CASES = ["egonn_cart01_b1", "egonn_cart01_b2", "egonn_cart03_b1", "egonn_polar_b1",
+         "egonn_cart01_50k_b2"]      # the last one: BASELINE configs[1] cloud size (2 x 50 000 points, 0.1 m)
 
 
 def load_case(name):
