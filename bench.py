@@ -49,7 +49,7 @@ def mfma_peak(layer: str, dtype: str) -> float:
     (sconv_split.hip) -> 2500 / 6; the first layer's unit-feature kernel three (conv.hip) -> 2500 / 3."""
     if dtype == "bf16":
         return MFMA_PEAK_TFLOPS["bf16"]
-    if layer.startswith(("sconv_split", "sconv_wide")):
+    if layer.startswith(("sconv_split", "sconv_wide", "sconv_win")):
         return MFMA_PEAK_TFLOPS["bf16"] / 6.0
     if layer.startswith("conv0_k5"):
         return MFMA_PEAK_TFLOPS["bf16"] / 3.0
@@ -100,6 +100,8 @@ def parse():
                    help="A/B measurements only: egonn_debug_set_naive_conv code (2 register-ring kernel, 16 LDS-DMA kernel with "
                         "split-phase fetch, 32 LDS-DMA kernel with 3 ring slots; all bitwise identical); 0 = product choice")
     p.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median one is reported")
+    p.add_argument("--distinct-batches", type=int, default=4,
+                   help="the timed loop rotates over this many distinct resident batches (1 = replay one batch: A/B with round <= 3)")
     p.add_argument("--no-extras", action="store_true",
                    help="skip the bounded side measurements of the other BASELINE configs (extra.configs[2], configs[3]_1gpu, db)")
     return p.parse_args()
@@ -161,11 +163,18 @@ def main():
     model.precision = "bf16" if args.dtype == "bf16" else "fp32"
     ex = DescriptorExtractor(model, n_k=128)
 
-    scans = make_scans(rank, args.batch, args.points)
-    offsets = [0]
-    for s in scans:
-        offsets.append(offsets[-1] + len(s))
-    points = torch.from_numpy(np.concatenate(scans, axis=0)).to(dev).contiguous()   # resident in HBM
+    # NB distinct batches resident in HBM: the timed loop rotates over them (a stream never re-reads the same 9.6 MB)
+    NB = max(1, args.distinct_batches)
+    batches = []
+    for b in range(NB):
+        from egonn_amd.synth import lidar_scan
+        sc = [lidar_scan(1000 * rank + 100 * b + i, n_points=args.points) for i in range(args.batch)]
+        off_b = [0]
+        for s in sc:
+            off_b.append(off_b[-1] + len(s))
+        batches.append((torch.from_numpy(np.concatenate(sc, axis=0)).to(dev).contiguous(), off_b))
+    points, offsets = batches[0]
+    scans = [points[offsets[i]:offsets[i + 1]].cpu().numpy() for i in range(args.batch)]     # (cpu_baseline sample)
     S = max(1, args.streams)
     ctx = model.context()
 
@@ -226,13 +235,13 @@ def main():
         host.update({"graph_launch_ms": round((g1 - g0) * 1e3, 3), "graph_latency_ms": round((g2 - g0) * 1e3, 3)})
 
         def run_steps(k):                                  # every step loads its batch (9.6 MB device copy + the scan
-            for i in range(k):                             # offsets) into the graph's input buffers, then ONE graph launch
-                graphs[i % S].run(points, offsets)
+            for i in range(k):                             # offsets) into the graph's input buffers, then ONE graph launch;
+                graphs[i % S].run(*batches[(i // S + i) % NB])   # the batches rotate over NB distinct ones
     else:
         ctx.profile_enable(2, dominant + "/")              # HIP events attached to the dominant kernel's dispatches
 
         def run_steps(k):
-            for _ in ex.extract_stream(((points, offsets) for _ in range(k)), n_streams=S):
+            for _ in ex.extract_stream((batches[i % NB] for i in range(k)), n_streams=S):
                 pass
         run_steps(2 * S)                                   # every in-flight slot grows its arenas before timing
     torch.cuda.synchronize()
@@ -331,6 +340,27 @@ def main():
         "layers_note": "every tagged layer of one step, one batch in flight (exclusive durations, HIP events around the launch); "
                        "frac = time at the binding roof (max of algorithmic bytes / 8 TB/s and flops / dense MFMA peak) / measured",
     }
+    # per channel plan: total exclusive us per step over every sparse-conv layer of the plan, and its fraction of the binding roof
+    by_plan = {}
+    for r in layers:
+        if not r["layer"].startswith("sconv"):
+            continue
+        nm = r["layer"].split("/")[0]
+        plan = nm[nm.index("<"):]
+        e = by_plan.setdefault(plan, {"us_per_step": 0.0, "t_hbm": 0.0, "t_mfma": 0.0, "launches_per_step": 0, "kernels": []})
+        e["us_per_step"] += r["us"]
+        e["t_hbm"] += r["alg_bytes"] / (HBM_PEAK_GBS * 1e9) * 1e6
+        e["t_mfma"] += r["flops"] / (mfma_peak(nm, args.dtype) * 1e12) * 1e6
+        e["launches_per_step"] += 1
+        if nm[:nm.index("<")] not in e["kernels"]:
+            e["kernels"].append(nm[:nm.index("<")])
+    roofline["by_plan"] = {k: {"us_per_step": round(v["us_per_step"], 1), "launches_per_step": v["launches_per_step"],
+                               "hbm_frac": round(v["t_hbm"] / v["us_per_step"], 4), "mfma_frac": round(v["t_mfma"] / v["us_per_step"], 4),
+                               "frac": round(max(v["t_hbm"], v["t_mfma"]) / v["us_per_step"], 4), "kernels": v["kernels"]}
+                           for k, v in sorted(by_plan.items(), key=lambda kv: -kv[1]["us_per_step"])}
+    roofline["by_plan_note"] = ("all sparse-conv launches of one step grouped by channel plan <Cin,Cout> (exclusive durations, one batch in flight); "
+                                "the kernel choice is a function of (map kind, level, channel plan) only, so the eager pass that fills this table "
+                                "runs the same kernels as the captured graph of the timed region")
     if excl:
         eus, eby, efl, eh, em = summarise(excl)
         roofline["exclusive"] = {"avg_launch_us": round(eus, 2), "frac": round(max(eh, em) / eus, 4),
@@ -431,6 +461,7 @@ def main():
                        "batch_per_gpu": args.batch, "points_per_scan": args.points, "voxel_m": args.voxel,
                        "voxels_per_level": n_levels, "parallelism": f"scan-sharded x{world} (no collective)",
                        "batches_in_flight": S, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "distinct_batches": NB,
                        "launch": "per step: the batch (already in HBM) is copied into the graph's input buffers, then one hipGraphLaunch "
                                  "(captured voxelise + forward + select; level sizes stay on the device; capacities calibrated on other scans)"
                                  if args.mode == "graph" else "eager: ~150 launches + one size query per step",

@@ -927,7 +927,10 @@ int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, h
     const int32_t* nbr = kind == 0 ? V.nbr27 : (kind == 1 ? V.nbr8 : V.nbrT);
     EGONN_REQUIRE(nbr, EGONN_ERR_STATE, "rowgroups: the plan has no kernel map of kind %d at level %d", kind, l);
     rg.K = kind == 0 ? 27 : 8;
-    rg.win = rg_window(l);
+    // k=3 maps of the big levels: WIN_ROWS-row windows + the window-resident tables (sconv_win.hip stages every distinct input
+    // row of a window ONCE in LDS instead of gathering it once per output neighbour)
+    const bool winmode = kind == 0 && l <= ctx->win_max_level;
+    rg.win = winmode ? WIN_ROWS : rg_window(l);
     const int gpw = rg.win / 16;
     rg.cap_groups = (int)((cdiv(P.cap[l], rg.win) + P.batch) * gpw);
     Arena& A = ctx->plan_arena;
@@ -936,6 +939,13 @@ int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, h
     rg.gmask = A.alloc<uint32_t>((size_t)rg.cap_groups);
     rg.meta = A.alloc<int32_t>((size_t)P.batch + 2);
     rg.order4 = A.alloc<int32_t>((size_t)rg.cap_groups / 4 + 16);
+    rg.wslot = nullptr; rg.urow = nullptr; rg.wmeta = nullptr;
+    if (winmode) {
+      rg.wslot = A.alloc<uint16_t>((size_t)rg.cap_groups * rg.K * 16);
+      rg.urow = A.alloc<int32_t>((size_t)(rg.cap_groups / gpw) * WIN_HALO);
+      rg.wmeta = A.alloc<int32_t>((size_t)(rg.cap_groups / gpw) * 4);
+      EGONN_REQUIRE(rg.wslot && rg.urow && rg.wmeta, EGONN_ERR_STATE, "plan arena too small (window tables)");
+    }
     EGONN_REQUIRE(rg.perm && rg.snbr && rg.gmask && rg.meta && rg.order4, EGONN_ERR_STATE, "plan arena too small (row groups)");
     EGONN_REQUIRE(nj < RG_MAX_JOBS, EGONN_ERR_INVALID, "rowgroups: too many maps in one request");
     jobs[nj].rg = &rg;
@@ -943,6 +953,7 @@ int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, h
     jobs[nj].n_dev = ctx->dev_counts + l;
     jobs[nj].boff = V.boff;
     jobs[nj].cap_rows = (int32_t)P.cap[l];
+    jobs[nj].halo_cap = ctx->win_halo_cap;
     ++nj;
   }
   if (nj == 0) return EGONN_OK;
@@ -956,7 +967,8 @@ static size_t plan_arena_bytes(int64_t n, int B) {
   size_t per_row = 2 * (8 + 4) + NL * (8 + 4 + 4 + 8 + 4) + 4 + 9 * 27 * 4 + 7 * (8 + 8) * 4 + 4 + 27 * 12 + 8 * 4;
   // row-group tables: k=3 (27+1 ints + mask) and the two 8-slot maps, <= 2n rows over all levels + window rounding
   per_row += 2 * ((27 + 1) * 4 + 2 + 2 * ((8 + 1) * 4 + 2));
-  const size_t rg_round = (size_t)(B + 8) * 1024 * (28 + 2 * 9) * 4 * EGONN_NUM_LEVELS;
+  per_row += 2 * (27 * 2 + (WIN_HALO + 4) * 4 / WIN_ROWS + 1);   // window-resident tables (u16 slots, halo lists, headers)
+  const size_t rg_round = (size_t)(B + 8) * 1024 * (28 + 14 + 2 * 9) * 4 * EGONN_NUM_LEVELS;
   return (size_t)(n + 8) * per_row + (size_t)(B + 1) * 4 * EGONN_NUM_LEVELS + (size_t)cdiv(n, PYR_TILE) * NL * 4 + rg_round +
          (1 << 20);
 }

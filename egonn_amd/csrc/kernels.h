@@ -14,10 +14,12 @@ bool sconv_rg_supported(int cin, int cout);
 int pack_rg_weights(const float* W, int K, int cin, int cout, int bf16, int flip, int transpose, void* out,
                     hipStream_t stream);
 extern unsigned long long* g_sconv_trace;
-const char* sconv_kernel_name(int cin, int cout, int bf16, int64_t groups_hint, int variant, int level, int split_max_level);
+// name of the kernel sconv_map dispatches for (map kind, output level, channel plan) under this context's settings
+const char* sconv_kernel_name(const Ctx* ctx, int kind, int level, int cin, int cout, int bf16);
+// level: output level of the map (selects the prefetch depth / kernel family: a function of the LAYER, never of a capacity)
 int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wp, int cin,
                      int cout, int bf16, const float* scale, const float* shift, int relu, void* out, float* psum,
-                     hipStream_t stream, int variant = 0);
+                     hipStream_t stream, int variant = 0, int level = 0);
 // Convolution over a map of the plan.  kind 0: k=3 on `level`; 1: k=2,s=2 from level-1 into `level`; 2: transposed from
 // level+1 onto `level`.  Wp: kernel already packed for this precision (or null: W is packed into `scratch` first).
 // bf16: feature maps in/out and weights are bf16.  psum (nullable): [groups][cout] per-group column sums of the output.
@@ -33,6 +35,12 @@ int sconv_split_default_cfg(int cin, int cout, int64_t groups_hint);
 int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
                         int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
                         int cfg = 0);
+// sconv_win.hip: window-resident kernel (k=3 maps with the window tables of rowgroup.hip; weights in the split packing)
+bool sconv_win_supported(int cin, int cout);
+bool sconv_uses_win(const Ctx* ctx, int kind, int level, int cin, int cout, int bf16);
+int sconv_win_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
+                      int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
+                      int cfg = 0);
 static constexpr size_t SCONV_SCRATCH_FLOATS = (size_t)2 << 20;   // 8 MB: one packed kernel (27 x 256 x 256 fp32 = 7 MB)
 // conv.hip -------------------------------------------------------------------------------------
 int sconv_naive(const float* in, const int32_t* nbr, const float* W, const float* scale, const float* shift, int relu,

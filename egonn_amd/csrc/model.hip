@@ -84,7 +84,9 @@ API const char* egonn_last_error(void) { return last_error(); }
 
 API int egonn_debug_set_naive_conv(egonn_ctx* c, int on) {
   EGONN_REQUIRE(c, EGONN_ERR_INVALID, "debug_set_naive_conv: null context");
-  if (on >= 1000) { c->conv_variant = on; return EGONN_OK; }     // split-bf16 kernel with an explicit configuration
+  if (on >= 7000 && on < 7008) { c->win_max_level = on - 7000; return EGONN_OK; }  // window-resident kernel up to this level (plans built next)
+  if (on >= 6000 && on < 7000) { c->win_halo_cap = on - 6000; return EGONN_OK; }   // tests: halo capacity of the window tables built next
+  if (on >= 1000) { c->conv_variant = on; return EGONN_OK; }     // 1000 + cfg: split-bf16 kernel, 5000 + G: window-resident kernel
   c->conv_variant = (on == 1) ? 3 : (on == 2 ? 1 : (on == 4 ? 2 : (on == 8 ? 4 : (on == 16 ? 5 : (on == 32 ? 6 : (on == 128 ? 9 : 0))))));
   return EGONN_OK;
 }
@@ -710,6 +712,9 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
 
   // ---- row-group tables of every map the graph uses: one launch per plan
   {
+    const int win_keep = c->win_max_level;
+    if (bf16) c->win_max_level = 0;       // bf16 maps run on the gather kernels: 512-row windows, no window-resident tables
+    struct Restore { egonn_ctx* c; int v; ~Restore() { c->win_max_level = v; } } restore{c, win_keep};
     int kinds[RG_MAX_JOBS], levels[RG_MAX_JOBS], nreq = 0;
     for (int l = 1; l <= 7; ++l) { kinds[nreq] = 0; levels[nreq++] = l; }
     for (int l = 1; l <= 7; ++l) { kinds[nreq] = 1; levels[nreq++] = l; }
@@ -763,7 +768,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     FALLOC(u3, n3 * LOCAL_CH);
     {
       char tag[64];
-      snprintf(tag, sizeof(tag), "%s<%d,%d>/L3/tconv", sconv_kernel_name(LOCAL_CH, LOCAL_CH, bf16, P.lv[3].rgT.cap_groups, c->conv_variant, 3, c->split_max_level),
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L3/tconv", sconv_kernel_name(c, 2, 3, LOCAL_CH, LOCAL_CH, bf16),
                LOCAL_CH, LOCAL_CH);
       ProfScope ps(c, st, tag, PK_TCONV, 3, 8, LOCAL_CH, LOCAL_CH, (int)es);
       EGONN_TRY(sconv_map(c, 2, 3, l4, nullptr, bf16 ? m->q_lt[4] : m->p_lt[4], m->s_lt[4], LOCAL_CH, LOCAL_CH, bf16, nullptr, nullptr, 0, u3,
@@ -786,7 +791,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     FALLOC(y, n * b.cin);
     char tag[64];
     {
-      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k2s2", sconv_kernel_name(b.cin, b.cin, bf16, L.rg8.cap_groups, c->conv_variant, i, c->split_max_level), b.cin,
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k2s2", sconv_kernel_name(c, 1, i, b.cin, b.cin, bf16), b.cin,
                b.cin, i);
       ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, (int)es);
       EGONN_TRY(sconv_map(c, 1, i, x[i - 1], nullptr, bf16 ? m->q_convs[i] : m->p_convs[i], m->s_convs[i], b.cin, b.cin, bf16, m->bn[i].scale,
@@ -796,7 +801,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     // ECABasicBlock (layers/eca_block.py:56-73)
     FALLOC(t1, n * b.cout);
     {
-      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv1", sconv_kernel_name(b.cin, b.cout, bf16, L.rg27.cap_groups, c->conv_variant, i, c->split_max_level),
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv1", sconv_kernel_name(c, 0, i, b.cin, b.cout, bf16),
                b.cin, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cin, b.cout, (int)es);
       EGONN_TRY(sconv_map(c, 0, i, y, nullptr, bf16 ? m->q_c1[i] : m->p_c1[i], m->s_c1[i], b.cin, b.cout, bf16, b.n1.scale, b.n1.shift, 1, t1,
@@ -805,7 +810,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     FALLOC(t2, n * b.cout);
     WALLOC(psum, (size_t)L.rg27.cap_groups * b.cout);
     {
-      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv2", sconv_kernel_name(b.cout, b.cout, bf16, L.rg27.cap_groups, c->conv_variant, i, c->split_max_level),
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv2", sconv_kernel_name(c, 0, i, b.cout, b.cout, bf16),
                b.cout, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cout, b.cout, (int)es);
       EGONN_TRY(sconv_map(c, 0, i, t1, nullptr, bf16 ? m->q_c2[i] : m->p_c2[i], m->s_c2[i], b.cout, b.cout, bf16, b.n2.scale, b.n2.shift, 0, t2,
@@ -843,7 +848,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     FALLOC(u6, P.cap[6] * GLOBAL_CH);
     {
       char tag[64];
-      snprintf(tag, sizeof(tag), "%s<%d,%d>/L6/tconv", sconv_kernel_name(GLOBAL_CH, GLOBAL_CH, bf16, P.lv[6].rgT.cap_groups, c->conv_variant, 6, c->split_max_level),
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L6/tconv", sconv_kernel_name(c, 2, 6, GLOBAL_CH, GLOBAL_CH, bf16),
                GLOBAL_CH, GLOBAL_CH);
       ProfScope ps(c, st, tag, PK_TCONV, 6, 8, GLOBAL_CH, GLOBAL_CH, (int)es);
       EGONN_TRY(sconv_map(c, 2, 6, g7, nullptr, bf16 ? m->q_gt[7] : m->p_gt[7], m->s_gt[7], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u6,
@@ -855,7 +860,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     FALLOC(u5, P.cap[5] * GLOBAL_CH);
     {
       char tag[64];
-      snprintf(tag, sizeof(tag), "%s<%d,%d>/L5/tconv", sconv_kernel_name(GLOBAL_CH, GLOBAL_CH, bf16, P.lv[5].rgT.cap_groups, c->conv_variant, 5, c->split_max_level),
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L5/tconv", sconv_kernel_name(c, 2, 5, GLOBAL_CH, GLOBAL_CH, bf16),
                GLOBAL_CH, GLOBAL_CH);
       ProfScope ps(c, st, tag, PK_TCONV, 5, 8, GLOBAL_CH, GLOBAL_CH, (int)es);
       EGONN_TRY(sconv_map(c, 2, 5, g6, nullptr, bf16 ? m->q_gt[6] : m->p_gt[6], m->s_gt[6], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u5,

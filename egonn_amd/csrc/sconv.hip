@@ -1088,7 +1088,7 @@ static int launch_rg_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stre
 // sel (tests / A-B measurements; every choice gives bitwise-identical results): 0 = product choice, 1 = register-ring
 // kernel, 2 = register-ring kernel with two groups per wave, 3 = LDS-DMA kernel (fp32 maps; split-phase LDS fetch, 4 ring slots), 4 = LDS-DMA kernel with the fetch inside the item (3 slots), 9 = traced build
 template <int CIN, int COUT, bool BF16>
-static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream, int sel) {
+static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream, int sel, int level) {
   constexpr int NS = COUT / 32, NCB = CIN / 32;
   // the input-channel blocks are always split over the waves of a workgroup (a function of the shape only, so results
   // never depend on launch sizes): measured faster at every level, 12 % on the 84 k-row 64->64 layer, 40 % on level 4.
@@ -1096,7 +1096,9 @@ static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
   constexpr int KSP = NCB >= 4 ? 4 : NCB;
   // prefetch depth (does not touch the arithmetic): few waves per SIMD => nothing else hides the gather latency, keep
   // 5 items in flight; a full chip prefers the smaller register footprint
-  const bool small = groups_hint * NS * KSP < 6144;     // fewer waves than 6 per SIMD
+  // levels >= 5 never fill the chip (batch 16: <= 240 groups): few waves per SIMD.  A function of the LAYER, not of a
+  // capacity: eager plans, reserved (graph) plans, the per-layer table and rocprof all see the same kernel
+  const bool small = level >= 5;
   if constexpr (!BF16) {
     {
       if (sel == 3 || (sel == 0 && !small)) return launch_dma_d<CIN, COUT, KSP, 4, false, true>(a, groups_hint, stream);
@@ -1127,7 +1129,7 @@ bool sconv_rg_supported(int cin, int cout) {
 // the groups in use (sizes the persistent grid only; the kernel reads the true count from rg.meta[0]).
 int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wp, int cin,
                      int cout, int bf16, const float* scale, const float* shift, int relu, void* out, float* psum,
-                     hipStream_t stream, int variant) {
+                     hipStream_t stream, int variant, int level) {
   EGONN_REQUIRE(rg.built, EGONN_ERR_STATE, "sconv: row-group tables not built");
   EGONN_REQUIRE(sconv_rg_supported(cin, cout), EGONN_ERR_INVALID, "sconv: channel plan %d->%d not supported (32/64/128/256)", cin, cout);
   const uint64_t ib = (uint64_t)n_in_cap * cin * (bf16 ? 2 : 4);
@@ -1148,11 +1150,11 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
   // cooperative kernel costs more than its saved W traffic when an item is 16-64 MFMAs of 32 cycles); with bf16 maps the
   // items are load-bound and the cooperative kernel wins on the big layers with >= 64 input or output channels.
   const int gsel = variant == 1 ? 1 : (variant == 4 ? 2 : (variant == 5 ? 3 : (variant == 6 ? 4 : (variant == 9 ? 9 : 0))));
-  const bool coop = variant == 2 || (variant == 0 && bf16 && groups_hint >= 2048 && cin * cout >= 32 * 64);
+  const bool coop = variant == 2 || (variant == 0 && bf16 && level <= 3 && cin * cout >= 32 * 64);   // (a function of the layer)
 #define EGONN_RG_CASE(CI, CO)                                                                      \
   if (cin == CI && cout == CO) {                                                                   \
     if (coop) return bf16 ? launch_wg<CI, CO, true>(a, groups_hint, stream) : launch_wg<CI, CO, false>(a, groups_hint, stream); \
-    return bf16 ? launch_rg<CI, CO, true>(a, groups_hint, stream, gsel) : launch_rg<CI, CO, false>(a, groups_hint, stream, gsel); \
+    return bf16 ? launch_rg<CI, CO, true>(a, groups_hint, stream, gsel, level) : launch_rg<CI, CO, false>(a, groups_hint, stream, gsel, level); \
   }
   EGONN_RG_CASE(32, 32)
   EGONN_RG_CASE(32, 64)
@@ -1175,14 +1177,14 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
   return EGONN_ERR_INVALID;
 }
 
-// Name of the kernel sconv_rg_forward dispatches for this launch (the profiler tags carry it, so that bench.py's dominant
-// kernel is the kernel rocprofv3 names).  Mirrors the choice in sconv_rg_forward / launch_rg.
-const char* sconv_kernel_name(int cin, int cout, int bf16, int64_t groups_hint, int variant, int level, int split_max_level) {
-  if (sconv_uses_split(cin, cout, bf16, level, variant, split_max_level)) return "sconv_split_kernel";
-  const int ns = cout / 32, ncb = cin / 32;
-  const int ksp = ncb >= 4 ? 4 : ncb;
-  const bool small = groups_hint * ns * ksp < 6144;
-  const bool coop = variant == 2 || (variant == 0 && bf16 && groups_hint >= 2048 && cin * cout >= 32 * 64);
+// Name of the kernel sconv_map dispatches for this layer (the profiler tags carry it, so that bench.py's dominant kernel is
+// the kernel rocprofv3 names).  Mirrors the choices in sconv_map / sconv_rg_forward / launch_rg.
+const char* sconv_kernel_name(const Ctx* ctx, int kind, int level, int cin, int cout, int bf16) {
+  const int variant = ctx->conv_variant;
+  if (sconv_uses_win(ctx, kind, level, cin, cout, bf16)) return "sconv_win_kernel";
+  if (sconv_uses_split(cin, cout, bf16, level, variant, ctx->split_max_level)) return "sconv_split_kernel";
+  const bool small = level >= 5;
+  const bool coop = variant == 2 || (variant == 0 && bf16 && level <= 3 && cin * cout >= 32 * 64);
   if (coop) return "sconv_wg_kernel";
   if (!bf16 && (variant == 5 || variant == 6 || variant == 9 || (variant == 0 && !small))) return "sconv_dma_kernel";
   return "sconv_rg_kernel";
@@ -1201,13 +1203,24 @@ const char* sconv_kernel_name(int cin, int cout, int bf16, int64_t groups_hint, 
 // >= inf / 4096 / 2000 / 700 / 200 groups = 21.8 k / 23.3 k / 24.3 k / 24.8 k / 23.6 k, i.e. levels <= 0 / 2 / 3 / 4 / 6.
 bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int split_max_level) {
   if (bf16 || !sconv_split_supported(cin, cout)) return false;
-  if (variant >= 1000) return true;
-  if (variant != 0) return false;
+  if (variant >= 1000 && variant < 5000) return true;
+  if (variant != 0 && variant < 5000) return false;    // (5000 + G: the window kernel's configuration; everything else as 0)
   static const int env_level = [] {                       // EGONN_SPLIT_MAX_LEVEL: measurement override
     const char* e = getenv("EGONN_SPLIT_MAX_LEVEL");
     return e ? atoi(e) : -1;
   }();
   return level <= (env_level >= 0 ? env_level : split_max_level);
+}
+
+// The window-resident kernel (sconv_win.hip) takes the k=3 maps whose row groups carry its tables (levels <= ctx->win_max_level,
+// fp32 maps, an instantiated channel plan).  conv_variant 5000 + G selects it with G groups per wave; 1..9 / 1000 + cfg (the
+// exact and lock-step kernels) bypass it.
+bool sconv_uses_win(const Ctx* ctx, int kind, int level, int cin, int cout, int bf16) {
+  if (bf16 || kind != 0 || level < 1 || level > ctx->win_max_level || !sconv_win_supported(cin, cout)) return false;
+  const int v = ctx->conv_variant;
+  if (v != 0 && !(v >= 5000 && v < 6000)) return false;
+  static const bool off = getenv("EGONN_NO_WIN") != nullptr;     // measurement switch
+  return !off;
 }
 
 int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, const void* Wsp, int cin, int cout,
@@ -1232,16 +1245,20 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
   }
   EGONN_TRY(ensure_rowgroups(ctx, &kind, &level, 1, stream));
   const RowGroups& rg = kind == 0 ? V.rg27 : (kind == 1 ? V.rg8 : V.rgT);
-  if (sconv_uses_split(cin, cout, bf16, level, ctx->conv_variant, ctx->split_max_level)) {
+  const bool use_win = sconv_uses_win(ctx, kind, level, cin, cout, bf16) && rg.wslot;
+  if (use_win || sconv_uses_split(cin, cout, bf16, level, ctx->conv_variant, ctx->split_max_level)) {
     if (!Wsp) {   // stand-alone operator call: pack into the caller's scratch
       const size_t wn = ((size_t)K * cin * cout * 3 + 1) / 2;
       EGONN_REQUIRE(W && scratch && scratch_floats >= wn, EGONN_ERR_STATE, "sconv: no scratch to pack the kernel into");
       EGONN_TRY(pack_split_weights(W, K, cin, cout, 0, 0, scratch, stream));
       Wsp = scratch;
     }
+    if (use_win)
+      return sconv_win_forward(reinterpret_cast<const float*>(in), P.cap[lin], rg, rg.cap_groups, Wsp, cin, cout, scale, shift, relu,
+                               reinterpret_cast<float*>(out), psum, stream, ctx->conv_variant >= 5000 ? ctx->conv_variant - 5000 : 0);
     return sconv_split_forward(reinterpret_cast<const float*>(in), P.cap[lin], rg, rg.cap_groups, Wsp, cin, cout, scale, shift,
                                relu, reinterpret_cast<float*>(out), psum, stream,
-                               ctx->conv_variant >= 1000 ? ctx->conv_variant - 1000 : 0);
+                               (ctx->conv_variant >= 1000 && ctx->conv_variant < 5000) ? ctx->conv_variant - 1000 : 0);
   }
   if (!Wp) {      // stand-alone operator call: pack into the caller's scratch
     const size_t wn = (size_t)K * cin * cout;
@@ -1250,7 +1267,7 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
     Wp = scratch;
   }
   return sconv_rg_forward(in, P.cap[lin], rg, rg.cap_groups, Wp, cin, cout, bf16, scale, shift, relu, out, psum, stream,
-                          ctx->conv_variant);
+                          ctx->conv_variant, level);
 }
 
 }  // namespace egonn

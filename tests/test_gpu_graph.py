@@ -422,6 +422,60 @@ def test_split_bf16_conv_matches_exact_fp32(gpu):
     print(f"split-bf16 worst relative deviation from the plain fp32 kernel: {worst:.2e}")
 
 
+@pytest.mark.gpu
+def test_window_resident_conv_matches_split_and_exact(gpu):
+    """The window-resident kernel (sconv_win.hip: every distinct input row of a 256-row window staged once in LDS, waves
+    free-running over their own groups) on every channel plan it is built for, levels 1-3: with 32 input channels its
+    summation order is the lock-step split kernel's -> bitwise equal; with 64 input channels the order is channel-block
+    major -> within the split tolerance of the plain fp32 kernel (3e-6 of the largest output); reruns are bitwise identical;
+    the per-group column sums match; and a plan whose windows overflow their halo capacity (forced: 8 halo slots, every
+    further halo row is gathered from global memory and split in registers) gives bitwise the same results."""
+    B = 3
+    from egonn_amd.synth import lidar_scan
+    scans = [lidar_scan(400 + i, 30000) for i in range(B)]
+    off = [0]
+    for s_ in scans:
+        off.append(off[-1] + len(s_))
+    pts = torch.from_numpy(np.concatenate(scans)).cuda()
+    ctx = gpu._lib.Context(coord_bits=12)
+    ctx.lib.egonn_debug_set_naive_conv(ctx.h, 7003)               # window-resident kernel on levels <= 3 (off in the product)
+    ctx.voxelize(pts, off, 0, [0.1])
+    ovf = gpu._lib.Context(coord_bits=12)
+    ovf.lib.egonn_debug_set_naive_conv(ovf.h, 7003)
+    ovf.lib.egonn_debug_set_naive_conv(ovf.h, 6008)               # halo capacity 8: (nearly) every window overflows
+    ovf.voxelize(pts, off, 0, [0.1])
+    ref = gpu._lib.Context(coord_bits=12)
+    ref.voxelize(pts, off, 0, [0.1])
+    ref.set_naive_conv(True)
+    torch.manual_seed(12)
+    for lvl, ci, co in [(1, 32, 32), (2, 32, 64), (2, 64, 64), (3, 64, 64), (3, 64, 32), (1, 64, 64)]:
+        n = ctx.level_count(lvl)
+        x = torch.randn(n, ci, device="cuda") * torch.exp(torch.randn(ci, device="cuda"))
+        w = torch.randn(27, ci, co, device="cuda") / np.sqrt(ci * 9)
+        sc, sh = torch.rand(co, device="cuda") + 0.5, torch.randn(co, device="cuda") * 0.1
+        want = ref.sparse_conv(0, lvl, x, w, sc, sh, relu=True)
+        scale = float(want.abs().max())
+        ctx.lib.egonn_debug_set_naive_conv(ctx.h, 0)                # default dispatch = the window kernel on these tables
+        got, sums = ctx.sparse_conv(0, lvl, x, w, sc, sh, relu=True, group_sums=True)
+        again, _ = ctx.sparse_conv(0, lvl, x, w, sc, sh, relu=True, group_sums=True)
+        assert torch.equal(got, again), (lvl, ci, co)
+        err = float((got - want).abs().max()) / scale
+        assert err < 3e-6, (lvl, ci, co, err)
+        assert torch.allclose(sums.double().sum(0), got.double().sum(0), rtol=1e-5, atol=1e-2 * max(scale, 1.0))
+        ctx.lib.egonn_debug_set_naive_conv(ctx.h, 1142)             # lock-step split kernel on the same tables
+        lock, lsums = ctx.sparse_conv(0, lvl, x, w, sc, sh, relu=True, group_sums=True)
+        if ci == 32:
+            assert torch.equal(lock, got) and torch.equal(lsums, sums), (lvl, ci, co)
+        else:
+            assert float((lock - got).abs().max()) / scale < 3e-6, (lvl, ci, co)
+        ctx.lib.egonn_debug_set_naive_conv(ctx.h, 5004)             # explicit configuration: 4 groups per wave
+        v, s2 = ctx.sparse_conv(0, lvl, x, w, sc, sh, relu=True, group_sums=True)
+        assert torch.equal(v, got) and torch.equal(s2, sums), (lvl, ci, co)
+        o, os_ = ovf.sparse_conv(0, lvl, x, w, sc, sh, relu=True, group_sums=True)
+        assert torch.equal(o, got) and torch.equal(os_, sums), ("overflow path", lvl, ci, co)
+    ctx.lib.egonn_debug_set_naive_conv(ctx.h, 0)
+
+
 def _db_worker(rank, world, port, out_path, n_scans):
     import os
     import torch.distributed as dist
