@@ -26,6 +26,7 @@ _SIGS = [
     ("egonn_last_error", C.c_char_p, []),
     ("egonn_debug_set_naive_conv", C.c_int, [_P, C.c_int]),
     ("egonn_debug_set_trace", C.c_int, [_P]),
+    ("egonn_prepare_maps", C.c_int, [_P, C.c_int, _P]),
     ("egonn_debug_rowgroup_tables", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int64), _P]),
     ("egonn_voxelize", C.c_int, [_P, _P, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     ("egonn_ctx_reserve", C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
@@ -301,6 +302,11 @@ class Context:
                                              int(x.dtype == torch.bfloat16), _ptr(sc), _ptr(sh), int(relu), out.data_ptr(),
                                              _ptr(sums), _stream()))
         return (out, sums) if group_sums else out
+
+    def prepare_maps(self, with_level0_transpose: bool = False):
+        """row-group tables of every kernel map of the plan in ONE launch (training steps, operator sequences)"""
+        with torch.cuda.device(self.device):
+            check(self.lib.egonn_prepare_maps(self.h, int(with_level0_transpose), _stream()))
 
     def map_groups(self, map_kind: int, level_out: int):
         n = C.c_int64()

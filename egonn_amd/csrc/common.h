@@ -255,6 +255,11 @@ int radix_sort_pairs(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* k
                      int64_t n, int nbits, hipStream_t stream, const int64_t* n_dev = nullptr, uint64_t** keys_res = nullptr,
                      uint32_t** vals_res = nullptr);
 size_t radix_sort_scratch_bytes(int64_t n);
+// Per-scan variant: every segment [off[b], off[b+1]) (DEVICE int64 offsets, B+1) is sorted on its own on bits [0, nbits), 9 bits
+// per pass — no pass is spent on the batch index of contiguous scans.  The result lands in whichever pair the last pass wrote.
+int radix_sort_segments(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, int64_t n,
+                        const int64_t* off_dev, int B, int nbits, hipStream_t stream, uint64_t** keys_res, uint32_t** vals_res);
+size_t radix_sort_segments_scratch_bytes(int64_t n, int B);
 
 // ------------------------------------------------------------------ coords.hip
 int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets, int64_t n_cap, int offsets_on_device,

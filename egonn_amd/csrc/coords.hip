@@ -743,8 +743,15 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
   const int cb = ctx->coord_bits;
   Arena& A = ctx->plan_arena;
   // (the sorted pairs land in whichever pair the last pass wrote: batches of 17-64 scans need six passes, an even number)
-  EGONN_TRY(radix_sort_pairs(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, 3 * cb + batch_bits(B), stream, n_dev, &keys_sorted,
-                             &vals_sorted));
+  static const bool flat_sort = getenv("EGONN_FLAT_SORT") != nullptr;      // measurement switch: the round-3 flat sort
+  if (n_dev && !flat_sort) {
+    // plans built from points: the scans are contiguous (offsets on the device at n_dev - B), each is sorted on its Morton bits
+    EGONN_TRY(radix_sort_segments(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, n_dev - B, B, 3 * cb, stream, &keys_sorted,
+                                  &vals_sorted));
+  } else {
+    EGONN_TRY(radix_sort_pairs(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, 3 * cb + batch_bits(B), stream, n_dev, &keys_sorted,
+                               &vals_sorted));
+  }
 
   const int ntiles = (int)cdiv(n, PYR_TILE);
   int32_t* tilecnt = A.alloc<int32_t>((size_t)ntiles * NL);
@@ -1049,7 +1056,7 @@ int plan_reserve(Ctx* ctx, int64_t max_points, int B, const int64_t* level_caps)
   ctx->reserve_points = max_points;
   ctx->reserve_batch = B;
   EGONN_TRY(ctx->plan_arena.ensure(plan_arena_bytes(max_points, B)));
-  EGONN_TRY(ctx->sort_arena.ensure(radix_sort_scratch_bytes(max_points)));
+  EGONN_TRY(ctx->sort_arena.ensure(std::max(radix_sort_scratch_bytes(max_points), radix_sort_segments_scratch_bytes(max_points, B))));
   ctx->reserved = true;
   return EGONN_OK;
 }

@@ -346,6 +346,20 @@ API int egonn_sparse_conv(egonn_ctx* c, int map_kind, int level_out, const void*
   return sconv_map(c, map_kind, level_out, in, kernel, nullptr, nullptr, cin, cout, bf16, scale, shift, relu, out, group_sums,
                    op_scratch(c), SCONV_SCRATCH_FLOATS, (hipStream_t)stream);
 }
+// Row-group tables of every kernel map of the plan a training step (or a sequence of stand-alone operator calls) uses, in ONE
+// launch: k=3 and k=2,s=2 maps of levels 1..7, transposed maps onto levels 0..6 (with_level0_transpose: the input gradient of the
+// first strided convolution; builds the level-0 parent table).  Without it every operator builds its map's tables on first
+// use — 21 launches of 12 us per training step.
+API int egonn_prepare_maps(egonn_ctx* c, int with_level0_transpose, void* stream) {
+  REQUIRE_PLAN(c);
+  HIP_CHECK(hipSetDevice(c->device));
+  int kinds[RG_MAX_JOBS], levels[RG_MAX_JOBS], n = 0;
+  for (int l = 1; l < EGONN_NUM_LEVELS; ++l) { kinds[n] = 0; levels[n++] = l; }
+  for (int l = 1; l < EGONN_NUM_LEVELS; ++l) { kinds[n] = 1; levels[n++] = l; }
+  for (int l = with_level0_transpose ? 0 : 1; l < EGONN_NUM_LEVELS - 1; ++l) { kinds[n] = 2; levels[n++] = l; }
+  return ensure_rowgroups(c, kinds, levels, n, (hipStream_t)stream);
+}
+
 // Measurement hook (tools/sconv_trace.py): device buffer the traced conv build (debug variant 128) writes its per-task
 // timestamps into (8 u64 per wave task); null switches it off.
 API int egonn_debug_set_trace(void* buf) {

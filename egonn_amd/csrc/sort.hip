@@ -270,4 +270,269 @@ int radix_sort_pairs(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* k
   return EGONN_OK;
 }
 
+
+// ------------------------------------------------------------------ segmented variant (plans built from points)
+// The points of a batch arrive scan by scan (offsets known on the device), so the batch index needs no sorting: every scan
+// is sorted on its own Morton bits only, 9 bits per pass — 36 bits = 4 passes for coord_bits = 12 where the flat sort of
+// (batch | Morton) = 40 bits needed 5 (48 -> 6 instead of 7 for coord_bits = 16).  Same two launches per pass; a tile never
+// straddles two scans, the global base of digit d in a tile is
+//   scan start + (keys of the scan with a smaller digit) + (keys with digit d in earlier tiles of the SAME scan),
+// i.e. one row of per-scan totals and at most cdiv(n_scan, TILE) - 1 tile rows instead of the supertile pyramid.
+static constexpr int SEG_BITS = 9;
+static constexpr int SEG_DIGITS = 1 << SEG_BITS;          // 512: two digits per thread
+static constexpr int SEG_DPT = SEG_DIGITS / SORT_BLOCK;
+
+// tile -> (scan, first key, keys in the tile, first tile of the scan); false: the tile is beyond the last scan
+__device__ static inline bool seg_locate(const int64_t* __restrict__ off, int B, int64_t n_cap, int tile, int& scan, int64_t& k0,
+                                         int32_t& nk, int& tile0) {
+  int t = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t lo = min(off[b], n_cap), hi = min(off[b + 1], n_cap);
+    const int nt = (int)((hi - lo + SORT_TILE - 1) / SORT_TILE);
+    if (tile < t + nt) {
+      scan = b; tile0 = t;
+      k0 = lo + (int64_t)(tile - t) * SORT_TILE;
+      nk = (int32_t)min((int64_t)SORT_TILE, hi - k0);
+      return true;
+    }
+    t += nt;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(SORT_BLOCK) void sort_seg_hist_kernel(const uint64_t* __restrict__ keys, int64_t n_cap,
+                                                                   const int64_t* __restrict__ off, int B, int shift,
+                                                                   int32_t* __restrict__ tilehist, int32_t* __restrict__ scanhist) {
+  __shared__ int32_t hist[SEG_DIGITS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  int scan, tile0;
+  int64_t k0;
+  int32_t nk;
+  if (!seg_locate(off, B, n_cap, blockIdx.x, scan, k0, nk, tile0)) return;       // workgroup-uniform
+#pragma unroll
+  for (int q = 0; q < SEG_DPT; ++q) hist[q * SORT_BLOCK + tid] = 0;
+  __syncthreads();
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint64_t kreg[SORT_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int32_t i = r * SORT_BLOCK + tid;
+    kreg[r] = (i < nk) ? keys[k0 + i] : 0ull;
+  }
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const bool valid = r * SORT_BLOCK + tid < nk;
+    const uint32_t d = (uint32_t)(kreg[r] >> shift) & (SEG_DIGITS - 1);
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < SEG_BITS; ++b) {
+      const bool bit = (d >> b) & 1;
+      const uint64_t bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    if (valid && (m & lt) == 0) atomicAdd(&hist[d], (int32_t)__popcll(m));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < SEG_DPT; ++q) {
+    const int d = q * SORT_BLOCK + tid;
+    const int32_t c = hist[d];
+    tilehist[(int64_t)blockIdx.x * SEG_DIGITS + d] = c;
+    if (c) atomicAdd(&scanhist[scan * SEG_DIGITS + d], c);          // <= cdiv(n_scan, TILE) adders per word
+  }
+}
+
+__global__ __launch_bounds__(SORT_BLOCK) void sort_seg_scatter_kernel(
+    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, int64_t n_cap, const int64_t* __restrict__ off, int B, int shift,
+    const int32_t* __restrict__ tilehist, const int32_t* __restrict__ scanhist) {
+  __shared__ int32_t whist[SORT_WAVES][SEG_DIGITS];   // running per-wave digit counts
+  __shared__ int32_t dbase[SEG_DIGITS];               // global base of every digit for this tile
+  __shared__ int32_t delta[SEG_DIGITS];               // global position - local position, per digit
+  __shared__ int32_t wsum[SORT_WAVES];
+  __shared__ uint64_t lkey[SORT_TILE];                // the tile, locally sorted by digit (stable)
+  __shared__ uint32_t lval[SORT_TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int scan, tile0;
+  int64_t k0;
+  int32_t nk;
+  if (!seg_locate(off, B, n_cap, blockIdx.x, scan, k0, nk, tile0)) return;       // workgroup-uniform
+  const int tile = blockIdx.x;
+  // the tile's keys are requested first: they do not depend on the histogram sums below, whose L2 round trips they overlap
+  const int32_t wbase = wave * (64 * SORT_ROUNDS);
+  uint64_t k[SORT_ROUNDS];
+  uint32_t v[SORT_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int32_t i = wbase + r * 64 + lane;
+    const bool valid = i < nk;
+    k[r] = valid ? keys_in[k0 + i] : ~0ull;
+    v[r] = valid ? vals_in[k0 + i] : 0u;
+  }
+  // ---- global base of digit d (thread tid owns digits 2 tid, 2 tid + 1: a wave covers 128 consecutive digits)
+  {
+    int32_t tot[SEG_DPT], before[SEG_DPT];
+#pragma unroll
+    for (int q = 0; q < SEG_DPT; ++q) {
+      tot[q] = scanhist[scan * SEG_DIGITS + SEG_DPT * tid + q];
+      before[q] = 0;
+    }
+    for (int t0 = tile0; t0 < tile; t0 += 8) {           // earlier tiles of the same scan, eight rows in flight
+      int32_t c[8][SEG_DPT];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int q = 0; q < SEG_DPT; ++q) c[u][q] = (t0 + u < tile) ? tilehist[(int64_t)(t0 + u) * SEG_DIGITS + SEG_DPT * tid + q] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int q = 0; q < SEG_DPT; ++q) before[q] += c[u][q];
+    }
+    // exclusive scan of the scan's digit totals over the 512 digits
+    int32_t mine = 0;
+#pragma unroll
+    for (int q = 0; q < SEG_DPT; ++q) mine += tot[q];
+    int32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wsum[wave] = incl;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w)
+#pragma unroll
+      for (int q = 0; q < SEG_DPT; ++q) whist[w][q * SORT_BLOCK + tid] = 0;
+    __syncthreads();
+    int32_t run = incl - mine;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    const int32_t scan_start = (int32_t)min(off[scan], n_cap);
+#pragma unroll
+    for (int q = 0; q < SEG_DPT; ++q) {
+      dbase[SEG_DPT * tid + q] = scan_start + run + before[q];
+      run += tot[q];
+    }
+  }
+  __syncthreads();
+  // ---- stable ranking: wave `wave` owns keys [wave*64*ROUNDS, +64*ROUNDS) of the tile
+  int32_t rank[SORT_ROUNDS];
+  volatile int32_t* my = whist[wave];
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const bool valid = wbase + r * 64 + lane < nk;
+    const uint32_t d = (uint32_t)(k[r] >> shift) & (SEG_DIGITS - 1);
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < SEG_BITS; ++b) {
+      const bool bit = (d >> b) & 1;
+      const uint64_t bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    const int32_t prior = my[d];
+    __builtin_amdgcn_wave_barrier();
+    rank[r] = prior + __popcll(m & lt);
+    if (valid && (m & lt) == 0) my[d] = prior + __popcll(m);   // group leader publishes the new count
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // ---- per digit: the tile's count, the start of the digit's run INSIDE the tile, per wave the local position of its first key
+  {
+    int32_t cnt[SEG_DPT], mine = 0;
+#pragma unroll
+    for (int q = 0; q < SEG_DPT; ++q) {
+      cnt[q] = 0;
+#pragma unroll
+      for (int w = 0; w < SORT_WAVES; ++w) cnt[q] += whist[w][SEG_DPT * tid + q];
+      mine += cnt[q];
+    }
+    int32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    __syncthreads();                             // wsum was last read in the digit-base scan above
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int32_t lstart = incl - mine;
+    for (int w = 0; w < wave; ++w) lstart += wsum[w];
+#pragma unroll
+    for (int q = 0; q < SEG_DPT; ++q) {
+      const int d = SEG_DPT * tid + q;
+      delta[d] = dbase[d] - lstart;
+      int32_t acc = lstart;
+#pragma unroll
+      for (int w = 0; w < SORT_WAVES; ++w) {
+        const int32_t c = whist[w][d];
+        whist[w][d] = acc;
+        acc += c;
+      }
+      lstart += cnt[q];
+    }
+  }
+  __syncthreads();
+  // ---- local reorder, then leave in runs (consecutive threads = consecutive keys of one digit = consecutive addresses)
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    if (wbase + r * 64 + lane < nk) {
+      const uint32_t d = (uint32_t)(k[r] >> shift) & (SEG_DIGITS - 1);
+      const int32_t pos = whist[wave][d] + rank[r];
+      lkey[pos] = k[r];
+      lval[pos] = v[r];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int32_t p = r * SORT_BLOCK + tid;
+    if (p < nk) {
+      const uint64_t kk = lkey[p];
+      const int64_t dst = (int64_t)delta[(uint32_t)(kk >> shift) & (SEG_DIGITS - 1)] + p;
+      keys_out[dst] = kk;
+      vals_out[dst] = lval[p];
+    }
+  }
+}
+
+size_t radix_sort_segments_scratch_bytes(int64_t n, int B) {
+  const int64_t tiles = cdiv(n > 0 ? n : 1, SORT_TILE) + B;
+  return (size_t)(tiles * SEG_DIGITS + 8 * (int64_t)B * SEG_DIGITS) * sizeof(int32_t) + 1024;
+}
+
+// Sorts every scan [off[b], off[b+1]) of (keys, vals) on bits [0, nbits) of the key (stable).  off: DEVICE int64 (B+1), clipped
+// to n (the capacity the buffers and the grid are sized for).  Result: as radix_sort_pairs (keys_res / vals_res).
+int radix_sort_segments(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, int64_t n,
+                        const int64_t* off_dev, int B, int nbits, hipStream_t stream, uint64_t** keys_res, uint32_t** vals_res) {
+  EGONN_REQUIRE(n >= 0 && n < (int64_t(1) << 31), EGONN_ERR_INVALID, "radix_sort: n=%lld out of range", (long long)n);
+  EGONN_REQUIRE(nbits >= 1 && nbits <= 64 && off_dev && B >= 1, EGONN_ERR_INVALID, "radix_sort_segments: bad arguments");
+  const int passes = (nbits + SEG_BITS - 1) / SEG_BITS;
+  EGONN_REQUIRE(passes <= 8, EGONN_ERR_INVALID, "radix_sort_segments: %d passes", passes);
+  *keys_res = keys_out;
+  *vals_res = vals_out;
+  if (n == 0) return EGONN_OK;
+  const int64_t tiles = cdiv(n, SORT_TILE) + B;
+  EGONN_TRY(ctx->sort_arena.ensure(radix_sort_segments_scratch_bytes(n, B)));
+  ctx->sort_arena.reset();
+  int32_t* tilehist = ctx->sort_arena.alloc<int32_t>(tiles * SEG_DIGITS);
+  int32_t* scanhist = ctx->sort_arena.alloc<int32_t>((size_t)8 * B * SEG_DIGITS);
+  EGONN_REQUIRE(tilehist && scanhist, EGONN_ERR_STATE, "radix_sort: scratch arena too small");
+  HIP_CHECK(hipMemsetAsync(scanhist, 0, sizeof(int32_t) * passes * B * SEG_DIGITS, stream));
+  uint64_t* kb[2] = {keys_in, keys_out};
+  uint32_t* vb[2] = {vals_in, vals_out};
+  int src = 0;
+  for (int p = 0; p < passes; ++p) {
+    int32_t* sh = scanhist + (int64_t)p * B * SEG_DIGITS;
+    const int shift = SEG_BITS * p;
+    hipLaunchKernelGGL(sort_seg_hist_kernel, dim3((unsigned)tiles), dim3(SORT_BLOCK), 0, stream, kb[src], n, off_dev, B, shift, tilehist, sh);
+    hipLaunchKernelGGL(sort_seg_scatter_kernel, dim3((unsigned)tiles), dim3(SORT_BLOCK), 0, stream, kb[src], vb[src], kb[src ^ 1],
+                       vb[src ^ 1], n, off_dev, B, shift, tilehist, sh);
+    src ^= 1;
+  }
+  *keys_res = kb[src];                                    // whichever pair the last pass wrote
+  *vals_res = vb[src];
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
 }  // namespace egonn

@@ -304,6 +304,7 @@ class MinkGL(nn.Module):
         if not bool((feats == 1).all()):
             raise NotImplementedError("train mode supports the reference's all-ones input features only")
         y = {}
+        ctx.prepare_maps(with_level0_transpose=True)          # the tables of all 21 maps of the step in one launch
         levels = train.trunk_forward(self, ctx, self.sync_bn_group)
         if not disable_global_head:
             g = train.global_branch(self, ctx, self.sync_bn_group, levels)

@@ -130,6 +130,10 @@ int egonn_conv_transpose(egonn_ctx* ctx, int level_in, const float* in, int cin,
 int egonn_sparse_conv(egonn_ctx* ctx, int map_kind, int level_out, const void* in, int cin, const float* kernel, int cout,
                       int bf16, const float* scale, const float* shift, int relu, void* out, float* group_sums,
                       void* stream);
+/* Builds the row-group tables of every kernel map of the current plan in one launch (otherwise each operator builds the tables
+ * of its map on first use): k=3 and k=2,s=2 maps of levels 1..7, transposed maps onto levels 1..6 and, with
+ * with_level0_transpose, onto level 0 (input gradient of the first strided convolution, training/trainer.py:168).  No sync. */
+int egonn_prepare_maps(egonn_ctx* ctx, int with_level0_transpose, void* stream);
 /* n_groups / first_group (HOST, B+1 entries, nullable) of a map's row groups.  [SYNC] */
 int egonn_map_groups(egonn_ctx* ctx, int map_kind, int level_out, int64_t* n_groups, int64_t* first_group, void* stream);
 /* MinkowskiGlobalAvgPooling: layers/eca_block.py:16, layers/pooling.py:80.  out (B,C) */

@@ -175,7 +175,7 @@ def test_config2_bf16_batch64_graph(gpu):
         assert np.abs(out["keypoints"][b].cpu().numpy()[i16] - ref["keypoints"][b].cpu().numpy()[i32]).max() <= 5e-2
     assert np.mean(common) >= 0.85 * 128, np.mean(common)
     # three of the 64 scans against the CPU restatement (oracle/egonn_cpu.c, fp32) — the stated bf16 tolerance of this
-    # configuration: global descriptor 1-cos <= 3e-4; >= 80 % of the 128 selected keypoints are the oracle's (the others
+    # configuration: global descriptor 1-cos <= 3e-4; >= 94 % of the 128 selected keypoints are the oracle's (the others
     # are saliency near-ties decided differently by bf16 maps); on those, local descriptors 1-cos <= 3e-3 and keypoint
     # positions within 0.05 m (1/16 of the 0.8 m super-voxel)
     from oracle import egonn_cpu
@@ -189,7 +189,15 @@ def test_config2_bf16_batch64_graph(gpu):
         key16 = H.rowkey(np.c_[np.zeros(len(rows), np.int64), c3[rows][:, 1:]])
         keyref = H.rowkey(np.c_[np.zeros(len(kc_ref), np.int64), kc_ref])
         both, i16, iref = np.intersect1d(key16, keyref, return_indices=True)
-        assert len(both) >= 0.80 * 128, (b, len(both))
+        assert len(both) >= 0.94 * 128, (b, len(both))                # measured: 128 / 126 / 127
+        # the sigma-gap rule with a bf16-sized gap (the fp32 tests use 2e-4): an oracle keypoint may be missing from the bf16
+        # selection only if its saliency is within BF16_GAP (relative) of the selection threshold = the oracle's 128th sigma
+        BF16_GAP = 5e-3                                               # measured: 0 / 1.0e-3 / 0 on the three scans
+        sref = np.asarray(sig_ref, dtype=np.float64).reshape(-1)
+        missing = np.setdiff1d(np.arange(len(keyref)), iref)
+        slack = (sref[-1] - sref[missing]) / np.maximum(1.0, np.abs(sref[missing])) if len(missing) else np.zeros(1)
+        print(f"bf16 batch-64 scan {b}: {len(both)} of 128 keypoints shared, largest saliency margin of a missing one {slack.max():.2e}")
+        assert slack.max() <= BF16_GAP, (b, slack.max())
         assert H.cosine_err(out["descriptors"][b].cpu().numpy()[i16], desc_ref[iref]).max() <= 3e-3, b
         assert np.abs(out["keypoints"][b].cpu().numpy()[i16] - kp_ref[iref]).max() <= 5e-2, b
 

@@ -87,8 +87,10 @@ def test_input_layer_weight_gradient(plan):
     assert rel(lhs, rhs) < 2e-5
     # explicit features: same kernel through the general (feature-gathering) path
     ones = torch.ones((n0, 1), device=dev)
+    # (unit features run on the bf16 matrix pipe with dout split exactly into three bf16 parts, explicit features on the plain
+    #  fp32 kernel: the same sums in another order)
     dk = ctx.conv_backward_weight(0, 0, 5, False, ones, G, (125, 1, 32))
-    assert torch.allclose(dk, W.grad, rtol=1e-5, atol=1e-5)
+    assert float((dk - W.grad).abs().max()) <= 2e-6 * float(dk.abs().max()) * np.sqrt(n0), float((dk - W.grad).abs().max())
 
 
 @pytest.mark.parametrize("relu", [True, False])
