@@ -1097,8 +1097,9 @@ static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
   // prefetch depth (does not touch the arithmetic): few waves per SIMD => nothing else hides the gather latency, keep
   // 5 items in flight; a full chip prefers the smaller register footprint
   // levels >= 5 never fill the chip (batch 16: <= 240 groups): few waves per SIMD.  A function of the LAYER, not of a
-  // capacity: eager plans, reserved (graph) plans, the per-layer table and rocprof all see the same kernel
-  const bool small = level >= 5;
+  // capacity: eager plans, reserved (graph) plans, the per-layer table and rocprof all see the same kernel.  bf16 maps are the
+  // batch-64 configuration (BASELINE configs[2]): level 5 still fills the chip there
+  const bool small = level >= (BF16 ? 6 : 5);
   if constexpr (!BF16) {
     {
       if (sel == 3 || (sel == 0 && !small)) return launch_dma_d<CIN, COUT, KSP, 4, false, true>(a, groups_hint, stream);
@@ -1150,7 +1151,7 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
   // cooperative kernel costs more than its saved W traffic when an item is 16-64 MFMAs of 32 cycles); with bf16 maps the
   // items are load-bound and the cooperative kernel wins on the big layers with >= 64 input or output channels.
   const int gsel = variant == 1 ? 1 : (variant == 4 ? 2 : (variant == 5 ? 3 : (variant == 6 ? 4 : (variant == 9 ? 9 : 0))));
-  const bool coop = variant == 2 || (variant == 0 && bf16 && level <= 3 && cin * cout >= 32 * 64);   // (a function of the layer)
+  const bool coop = variant == 2 || (variant == 0 && bf16 && level <= 4 && cin * cout >= 32 * 64);   // (a function of the layer)
 #define EGONN_RG_CASE(CI, CO)                                                                      \
   if (cin == CI && cout == CO) {                                                                   \
     if (coop) return bf16 ? launch_wg<CI, CO, true>(a, groups_hint, stream) : launch_wg<CI, CO, false>(a, groups_hint, stream); \
@@ -1183,8 +1184,8 @@ const char* sconv_kernel_name(const Ctx* ctx, int kind, int level, int cin, int 
   const int variant = ctx->conv_variant;
   if (sconv_uses_win(ctx, kind, level, cin, cout, bf16)) return "sconv_win_kernel";
   if (sconv_uses_split(cin, cout, bf16, level, variant, ctx->split_max_level)) return "sconv_split_kernel";
-  const bool small = level >= 5;
-  const bool coop = variant == 2 || (variant == 0 && bf16 && level <= 3 && cin * cout >= 32 * 64);
+  const bool small = level >= (bf16 ? 6 : 5);
+  const bool coop = variant == 2 || (variant == 0 && bf16 && level <= 4 && cin * cout >= 32 * 64);
   if (coop) return "sconv_wg_kernel";
   if (!bf16 && (variant == 5 || variant == 6 || variant == 9 || (variant == 0 && !small))) return "sconv_dma_kernel";
   return "sconv_rg_kernel";
