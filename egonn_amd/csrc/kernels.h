@@ -115,8 +115,9 @@ int softmax_ce(const float* logits, int64_t n, int64_t m, const int32_t* target,
 
 // train.hip --------------------------------------------------------------------------------------
 // dW[k][ci][co] = sum_o in[nbr[o][k]][ci] * dout[o][co]; nbr == nullptr: identity map (K = 1, dense layer)
+// rg (nullable): the row-group form of the same map when it is built (the pair source of the MFMA kernel)
 int conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int64_t n_out, int K, int cin, int cout,
-               float* dW, float* scratch, size_t scratch_floats, hipStream_t stream);
+               float* dW, float* scratch, size_t scratch_floats, hipStream_t stream, const RowGroups* rg = nullptr);
 int conv0_wgrad(Ctx* ctx, const float* feat, const float* dout, float* dW, float* scratch, size_t scratch_floats,
                 hipStream_t stream);
 int col_stats(int mode, const float* a, const float* b, const float* mask, const float* m, int64_t n, int c, float* out2c,

@@ -1072,18 +1072,18 @@ API int egonn_conv_backward_weight(egonn_ctx* c, int level_in, int level_out, in
     EGONN_REQUIRE(level_in == level_out && level_in >= 1 && !transposed, EGONN_ERR_INVALID,
                   "k=3 convolution: levels 1..7, same in/out level");
     return conv_wgrad(in, grad_out, P.lv[level_in].nbr27, P.lv[level_in].n, 27, cin, cout, grad_kernel, scratch,
-                      (size_t)scratch_floats, st);
+                      (size_t)scratch_floats, st, &P.lv[level_in].rg27);
   }
   if (ks == 2 && !transposed) {
     EGONN_REQUIRE(level_out == level_in + 1, EGONN_ERR_INVALID, "k=2,s=2 convolution maps level l to l+1");
     return conv_wgrad(in, grad_out, P.lv[level_out].nbr8, P.lv[level_out].n, 8, cin, cout, grad_kernel, scratch,
-                      (size_t)scratch_floats, st);
+                      (size_t)scratch_floats, st, &P.lv[level_out].rg8);
   }
   if (ks == 2 && transposed) {
     EGONN_REQUIRE(level_out == level_in - 1 && level_out >= 0, EGONN_ERR_INVALID, "transposed conv maps level l to l-1");
     if (level_out == 0) EGONN_TRY(ensure_level0_parent_table(c, st));
     return conv_wgrad(in, grad_out, P.lv[level_out].nbrT, P.lv[level_out].n, 8, cin, cout, grad_kernel, scratch,
-                      (size_t)scratch_floats, st);
+                      (size_t)scratch_floats, st, &P.lv[level_out].rgT);
   }
   set_error("conv_backward_weight: kernel_size %d not supported", ks);
   return EGONN_ERR_INVALID;

@@ -112,7 +112,9 @@ typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const float* __restrict__ in, const float* __restrict__ dout,
                                                         const int32_t* __restrict__ nbr, int32_t n_out, int K,
-                                                        int32_t rows_per_chunk, float* __restrict__ partial) {
+                                                        int32_t rows_per_chunk, float* __restrict__ partial,
+                                                        const int32_t* __restrict__ rg_perm, const int32_t* __restrict__ rg_snbr,
+                                                        const int32_t* __restrict__ rg_meta) {
   constexpr int TM = CIN / 16, TN = COUT / 16;
   constexpr int WN = 2, WM = 2;
   constexpr int TMW = TM / WM, TNW = TN / WN;
@@ -130,12 +132,24 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const float* __restrict
   for (int i = 0; i < TMW; ++i)
 #pragma unroll
     for (int j = 0; j < TNW; ++j) acc[i][j] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+  // rg_perm != null: the pairs come from the row-group form of the map (rowgroup.hip) — slot e = 16 g + s holds output row
+  // perm[e] and input row snbr[(g K + k) 16 + s]: one 64-byte line per (group, offset) where the plain table costs every
+  // (chunk, offset) workgroup a 108-byte-strided column (each line of the table fetched 27 times); n_out counts slots then
+  if (rg_perm) n_out = min(n_out, rg_meta[0] * 16);
   const int32_t r0 = chunk * rows_per_chunk;
   const int32_t r1 = (int32_t)min((int64_t)n_out, (int64_t)r0 + rows_per_chunk);
   for (int32_t base = r0; base < r1; base += 256) {
-    const int32_t o = base + t;
+    int32_t o = base + t;
     int32_t j = -1;
-    if (o < r1) j = nbr ? nbr[(int64_t)o * K + k] : o;
+    if (o < r1) {
+      if (rg_perm) {
+        const int32_t e = o;
+        o = rg_perm[e];
+        if (o >= 0) j = rg_snbr[((int64_t)(e >> 4) * K + k) * 16 + (e & 15)];
+      } else {
+        j = nbr ? nbr[(int64_t)o * K + k] : o;
+      }
+    }
     const bool v = j >= 0;
     const uint64_t bal = __ballot(v);
     if (lane == 0) s_wcnt[w] = __popcll(bal);
@@ -251,7 +265,7 @@ static void launch_sum_partials(const float* partial, int chunks, int64_t size, 
 }
 
 int conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int64_t n_out, int K, int cin, int cout,
-               float* dW, float* scratch, size_t scratch_floats, hipStream_t stream) {
+               float* dW, float* scratch, size_t scratch_floats, hipStream_t stream, const RowGroups* rg) {
   const int64_t size = (int64_t)K * cin * cout;
   if (n_out == 0) {
     HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)size * 4, stream));
@@ -262,6 +276,8 @@ int conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int64_t n
   const bool mfma = (cin == 32 && (cout == 32 || cout == 64)) || (cin == 64 && (cout == 64 || cout == 128)) ||
                     (cin == 128 && cout == 128);
   if (mfma) {
+    const bool use_rg = rg && rg->built && rg->K == K && K > 1;
+    if (use_rg) n_out = (int64_t)rg->cap_groups * 16;      // slots (the kernel clips to the groups in use)
     // (chunk, offset) workgroups: enough of them to fill the chip (a chunk is a chain of dependent 256-row slabs: the small
     // levels ran 3-17 workgroups for 72-79 us per call), never fewer than 256 rows per chunk
     int64_t chunks = std::max<int64_t>(1, 2048 / (int64_t)K);
@@ -273,7 +289,7 @@ int conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int64_t n
 #define EGONN_WGRAD_CASE(CI, CO)                                                                                 \
   if (cin == CI && cout == CO)                                                                                   \
     hipLaunchKernelGGL((wgrad_mfma_kernel<CI, CO>), grid, dim3(256), 0, stream, in, dout, nbr, (int32_t)n_out, K, rpc, \
-                       scratch);
+                       scratch, use_rg ? rg->perm : nullptr, use_rg ? rg->snbr : nullptr, use_rg ? rg->meta : nullptr);
     EGONN_WGRAD_CASE(32, 32)
     EGONN_WGRAD_CASE(32, 64)
     EGONN_WGRAD_CASE(64, 64)
@@ -735,9 +751,9 @@ int col_stats(int mode, const float* a, const float* b, const float* mask, const
   const bool aligned16 = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(mask) |
                            reinterpret_cast<uintptr_t>(m)) & 15u) == 0;
   if (c % 4 == 0 && c >= 32 && 256 % (c / 4) == 0 && aligned16) {      // 32 / 64 / 128 / 256 channels: 16-byte accesses
-    // >= ~1 000 blocks whenever the map has the rows for it (a function of n only: deterministic)
+    // >= ~500 blocks whenever the map has the rows for it (a function of n only: deterministic)
     int rpb = CS4_ROWS;
-    while (rpb > 32 && cdiv(n, rpb) < 1024) rpb >>= 1;
+    while (rpb > 32 && cdiv(n, rpb) < 512) rpb >>= 1;
     const int64_t blocks4 = cdiv(n, rpb);
     EGONN_REQUIRE(scratch && scratch_floats >= (size_t)blocks4 * 2 * c, EGONN_ERR_INVALID,
                   "col_stats: scratch too small (%zu < %lld floats)", scratch_floats, (long long)(blocks4 * 2 * c));
@@ -1023,23 +1039,44 @@ __global__ void eca_gate_fwd_kernel(const float* __restrict__ mean, const float*
   }
   gate[(int64_t)b * c + t] = 1.f / (1.f + expf(-z));
 }
+// One workgroup (the (B, C) gate is 4 096 values at batch 32).  dz = dgate * g (1 - g) and the pooled means are staged once in
+// LDS (the first version read gate / dgate / mean from global memory inside every one of its 6 passes: 38 us of dependent
+// loads per call); sums in the same order as before (thread-strided, then a binary tree): bitwise the same results.
+static constexpr int ECA_BWD_LDS = 8192;                  // (B * C) values the staged path holds
 __global__ __launch_bounds__(256) void eca_gate_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
                                                           const float* __restrict__ mean, const float* __restrict__ w,
                                                           int ks, int B, int c, float* __restrict__ dmean,
                                                           float* __restrict__ dw) {
   __shared__ float red[256];
+  __shared__ float s_dz[ECA_BWD_LDS];
+  __shared__ float s_mean[ECA_BWD_LDS];
+  __shared__ float s_w[16];
   const int t = threadIdx.x;
   const int pad = (ks - 1) / 2;
   const int total = B * c;
+  const bool staged = total <= ECA_BWD_LDS;
+  if (staged) {
+    for (int e = t; e < total; e += 256) {
+      const float g = gate[e];
+      s_dz[e] = dgate[e] * g * (1.f - g);
+      s_mean[e] = mean[e];
+    }
+    if (t < ks) s_w[t] = w[t];
+    __syncthreads();
+  }
+  auto dz_at = [&](int e) {
+    if (staged) return s_dz[e];
+    const float g = gate[e];
+    return dgate[e] * g * (1.f - g);
+  };
+  auto mean_at = [&](int e) { return staged ? s_mean[e] : mean[e]; };
+  auto w_at = [&](int j) { return staged ? s_w[j] : w[j]; };
   for (int e = t; e < total; e += 256) {                 // dmean[b][q] = sum_j w[j] * dz[b][q - j + pad]
     const int b = e / c, q = e - b * c;
     float s = 0.f;
     for (int j = 0; j < ks; ++j) {
       const int cc = q - j + pad;
-      if (cc >= 0 && cc < c) {
-        const float g = gate[(int64_t)b * c + cc];
-        s = fmaf(w[j], dgate[(int64_t)b * c + cc] * g * (1.f - g), s);
-      }
+      if (cc >= 0 && cc < c) s = fmaf(w_at(j), dz_at(b * c + cc), s);
     }
     dmean[e] = s;
   }
@@ -1048,10 +1085,7 @@ __global__ __launch_bounds__(256) void eca_gate_bwd_kernel(const float* __restri
     for (int e = t; e < total; e += 256) {
       const int b = e / c, cc = e - b * c;
       const int q = cc + j - pad;
-      if (q >= 0 && q < c) {
-        const float g = gate[e];
-        s = fmaf(dgate[e] * g * (1.f - g), mean[(int64_t)b * c + q], s);
-      }
+      if (q >= 0 && q < c) s = fmaf(dz_at(e), mean_at(b * c + q), s);
     }
     red[t] = s;
     __syncthreads();
