@@ -736,17 +736,18 @@ int plan_sync(Ctx* ctx, hipStream_t stream) {
 
 // n_cap: rows the key buffers hold; n_dev (nullable): device-resident row count.  reserved = false: the level capacities
 // are the exact row counts (one host sync right after the pyramid); true: ctx->reserve_cap[] (no host sync at all).
+// seg_off (nullable): DEVICE scan offsets (B+1) when the rows arrive scan by scan (plans built from points)
 static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* vals_raw, uint64_t* keys_sorted,
-                                        uint32_t* vals_sorted, int64_t n, const int64_t* n_dev, int B, bool reserved,
-                                        hipStream_t stream) {
+                                        uint32_t* vals_sorted, int64_t n, const int64_t* n_dev, const int64_t* seg_off, int B,
+                                        bool reserved, hipStream_t stream) {
   Plan& P = ctx->plan;
   const int cb = ctx->coord_bits;
   Arena& A = ctx->plan_arena;
   // (the sorted pairs land in whichever pair the last pass wrote: batches of 17-64 scans need six passes, an even number)
   static const bool flat_sort = getenv("EGONN_FLAT_SORT") != nullptr;      // measurement switch: the round-3 flat sort
-  if (n_dev && !flat_sort) {
-    // plans built from points: the scans are contiguous (offsets on the device at n_dev - B), each is sorted on its Morton bits
-    EGONN_TRY(radix_sort_segments(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, n_dev - B, B, 3 * cb, stream, &keys_sorted,
+  if (seg_off && !flat_sort) {
+    // plans built from points: the scans are contiguous, each is sorted on its Morton bits
+    EGONN_TRY(radix_sort_segments(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, seg_off, B, 3 * cb, stream, &keys_sorted,
                                   &vals_sorted));
   } else {
     EGONN_TRY(radix_sort_pairs(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, 3 * cb + batch_bits(B), stream, n_dev, &keys_sorted,
@@ -1021,7 +1022,7 @@ int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets,
   QuantParams qp{mode, step[0], mode ? step[1] : step[0], mode ? step[2] : step[0]};
   hipLaunchKernelGGL(points_to_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, points, n, doff, B, qp,
                      ctx->coord_bits, k0, v0, ctx->dev_flags);
-  return build_plan_from_sorted_input(ctx, k0, v0, k1, v1, n, doff + B, B, offsets_on_device != 0, stream);
+  return build_plan_from_sorted_input(ctx, k0, v0, k1, v1, n, doff + B, doff, B, offsets_on_device != 0, stream);
 }
 
 int plan_from_coords(Ctx* ctx, const int32_t* coords, int64_t n, int B, hipStream_t stream) {
@@ -1040,7 +1041,7 @@ int plan_from_coords(Ctx* ctx, const int32_t* coords, int64_t n, int B, hipStrea
   HIP_CHECK(hipMemsetAsync(ctx->dev_flags, 0, sizeof(int32_t), stream));
   hipLaunchKernelGGL(coords_to_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, coords, n,
                      ctx->coord_bits, B, k0, v0, ctx->dev_flags);
-  return build_plan_from_sorted_input(ctx, k0, v0, k1, v1, n, nullptr, B, false, stream);
+  return build_plan_from_sorted_input(ctx, k0, v0, k1, v1, n, nullptr, nullptr, B, false, stream);
 }
 
 // Fixes the sizes of everything a plan allocates, so that later plans neither allocate nor synchronise (capturable).

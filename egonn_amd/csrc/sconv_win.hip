@@ -126,7 +126,8 @@ __device__ static inline void win_split4(const f32x4& a, uint2& hi, uint2& mid, 
 // G: groups per wave (a workgroup has 16 / G waves).  The W fragments of a step are fetched once per wave: G = 4 moves a
 // quarter of the W bytes of G = 1 through the vector-memory path.
 template <int CIN, int COUT, int G, bool TRACE = false>
-__global__ __launch_bounds__((16 / G) * 64, 8 / G) void sconv_win_kernel(const WinArgs p) {
+__global__ __launch_bounds__((16 / G) * 64, (CIN * COUT >= 64 * 64) ? 1 : 8 / G) void sconv_win_kernel(const WinArgs p) {   // (64 x 64: more
+                                                                                      // than 256 registers rather than spills)
   auto now = [] { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
   unsigned long long tr[8] = {};
   if constexpr (TRACE) tr[0] = now();
@@ -188,23 +189,25 @@ __global__ __launch_bounds__((16 / G) * 64, 8 / G) void sconv_win_kernel(const W
   // chunk c lands in half (c >> 2) of the 16-byte operand (c & 3), XOR-swizzled by two slot bits against bank conflicts of
   // the random-row reads: byte (slot * 64) + (((c & 3) ^ ((slot >> 2) & 3)) * 16) + (c >> 2) * 8 of every plane.
   const int st_c = lane & 7;
-  auto stage = [&](int cb) {
-    f32x4 v[OPW + HPW];
+  auto stage_pieces = [&](auto HALO, int cb) {              // own rows, then halo rows: two batches of loads (registers)
+    constexpr bool halo = decltype(HALO)::value;
+    constexpr int NP = halo ? HPW : OPW;
+    f32x4 v[NP];
 #pragma unroll
-    for (int i = 0; i < OPW; ++i) {
-      const int slot = (wave + NW * i) * 8 + (lane >> 3);
-      const int32_t vi = slot < rows ? r0 + slot : -1;                     // -1: out of range -> zeros, no traffic
+    for (int i = 0; i < NP; ++i) {
+      int32_t vi;
+      if constexpr (halo) {
+        vi = hidx[i];
+      } else {
+        const int slot = (wave + NW * i) * 8 + (lane >> 3);
+        vi = slot < rows ? r0 + slot : -1;                                // -1: out of range -> zeros, no traffic
+      }
       v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, vi * (CIN * 4) + st_c * 16, cb * 128, 0));
     }
 #pragma unroll
-    for (int i = 0; i < HPW; ++i) {
-      const int32_t hv = hidx[i];
-      v[OPW + i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, hv * (CIN * 4) + st_c * 16, cb * 128, 0));
-    }
-#pragma unroll
-    for (int i = 0; i < OPW + HPW; ++i) {
-      const int pc = i < OPW ? wave + NW * i : NOWN + wave + NW * (i - OPW);
-      const bool live = i < OPW ? (wave + NW * i) * 8 < rows : (wave + NW * (i - OPW)) * 8 < nh;     // wave-uniform
+    for (int i = 0; i < NP; ++i) {
+      const int pc = halo ? NOWN + wave + NW * i : wave + NW * i;
+      const bool live = halo ? (wave + NW * i) * 8 < nh : (wave + NW * i) * 8 < rows;       // wave-uniform
       if (!live) continue;
       const int slot = pc * 8 + (lane >> 3);
       uint2 hi, mid, lo;
@@ -214,6 +217,10 @@ __global__ __launch_bounds__((16 / G) * 64, 8 / G) void sconv_win_kernel(const W
       *reinterpret_cast<uint2*>(dst + PLANE) = mid;
       *reinterpret_cast<uint2*>(dst + 2 * PLANE) = lo;
     }
+  };
+  auto stage = [&](int cb) {
+    stage_pieces(std::integral_constant<bool, false>{}, cb);
+    stage_pieces(std::integral_constant<bool, true>{}, cb);
   };
   if constexpr (TRACE) tr[1] = now();
 

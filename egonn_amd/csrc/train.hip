@@ -304,7 +304,7 @@ int conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int64_t n
   const int T = small ? 32 : 64, NT = small ? 64 : 256;
   const int tiles = (int)(cdiv(cin, T) * cdiv(cout, T));
   int64_t chunks = std::max<int64_t>(1, 4096 / ((int64_t)K * tiles));
-  chunks = std::min<int64_t>(chunks, cdiv(n_out, 2 * NT));
+  chunks = std::min<int64_t>(chunks, cdiv(n_out, NT));    // (one slab of NT rows per chunk at least: a chunk is a serial chain of slabs)
   chunks = std::min<int64_t>(chunks, (int64_t)(scratch_floats / (size_t)size));
   chunks = std::max<int64_t>(chunks, 1);
   const int32_t rpc = (int32_t)cdiv(n_out, chunks);
