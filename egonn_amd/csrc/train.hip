@@ -740,6 +740,25 @@ __global__ __launch_bounds__(64) void sum_partials_wave_kernel(const float* __re
   if (threadIdx.x == 0) out[i] = (float)s;
 }
 
+// the same with a whole workgroup per output value (the BatchNorm statistics: 64-512 outputs, 500-1 600 partial rows): thread t
+// adds rows t, t + 256, ... in ascending order, the 256 sums are added in a fixed binary tree
+__global__ __launch_bounds__(256) void sum_partials_block_kernel(const float* __restrict__ partial, int chunks, int64_t size,
+                                                                float* __restrict__ out) {
+  __shared__ double red[256];
+  const int64_t i = blockIdx.x;
+  const int t = threadIdx.x;
+  double s = 0.0;
+  for (int ch = t; ch < chunks; ch += 256) s += (double)partial[(int64_t)ch * size + i];
+  red[t] = s;
+  __syncthreads();
+#pragma unroll
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  if (t == 0) out[i] = (float)red[0];
+}
+
 int col_stats(int mode, const float* a, const float* b, const float* mask, const float* m, int64_t n, int c, float* out2c,
               float* scratch, size_t scratch_floats, hipStream_t stream) {
   EGONN_REQUIRE(c >= 1 && c <= 256, EGONN_ERR_INVALID, "col_stats: %d channels unsupported (1..256)", c);
@@ -758,8 +777,12 @@ int col_stats(int mode, const float* a, const float* b, const float* mask, const
     EGONN_REQUIRE(scratch && scratch_floats >= (size_t)blocks4 * 2 * c, EGONN_ERR_INVALID,
                   "col_stats: scratch too small (%zu < %lld floats)", scratch_floats, (long long)(blocks4 * 2 * c));
     hipLaunchKernelGGL(col_stats4_kernel, dim3((unsigned)blocks4), dim3(256), 0, stream, mode, a, b, mask, m, n, c, rpb, scratch);
-    hipLaunchKernelGGL(sum_partials_wave_kernel, dim3((unsigned)(2 * c)), dim3(64), 0, stream, scratch, (int)blocks4,
-                       (int64_t)2 * c, out2c);
+    if (blocks4 >= 256)
+      hipLaunchKernelGGL(sum_partials_block_kernel, dim3((unsigned)(2 * c)), dim3(256), 0, stream, scratch, (int)blocks4,
+                         (int64_t)2 * c, out2c);
+    else
+      hipLaunchKernelGGL(sum_partials_wave_kernel, dim3((unsigned)(2 * c)), dim3(64), 0, stream, scratch, (int)blocks4,
+                         (int64_t)2 * c, out2c);
     HIP_CHECK(hipGetLastError());
     return EGONN_OK;
   }
