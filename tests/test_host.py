@@ -120,3 +120,20 @@ def test_minkloc_state_dict_matches_reference(built, name, kind):
     assert list(sd.keys()) == list(ref.keys())
     for k, v in sd.items():
         assert tuple(v.shape) == ref[k], k
+
+
+def test_status_codes_map_to_exception_types(built):
+    """C status 5 (EGONN_STATUS_CAPACITY: a batch did not fit egonn_ctx_reserve) raises CapacityError — what the streaming
+    pipeline catches to fall back to the exact-size eager path; every other non-zero status raises EgonnError; both are
+    RuntimeErrors (callers written against round <= 3 keep working) and carry the C code.  The header documents the codes."""
+    from egonn_amd import _lib
+    assert issubclass(_lib.CapacityError, _lib.EgonnError) and issubclass(_lib.EgonnError, RuntimeError)
+    _lib.check(0)
+    with pytest.raises(_lib.CapacityError) as e:
+        _lib.check(5)
+    assert e.value.code == 5
+    with pytest.raises(_lib.EgonnError) as e:
+        _lib.check(3)
+    assert e.value.code == 3 and not isinstance(e.value, _lib.CapacityError)
+    header = open(os.path.join(REPO, "include", "egonn_hip.h")).read()
+    assert "EGONN_STATUS_CAPACITY = 5" in header and "EGONN_STATUS_RANGE = 3" in header
