@@ -57,6 +57,7 @@ struct RGJob {
 struct RGArgs {
   RGJob job[RG_MAX_JOBS];
   int njobs, B, nblocks;
+  int first_pass;              // 27-offset maps: radix passes first_pass .. 2 of the window sort (0 = all 27 mask bits)
   unsigned long long* trace;   // measurement hook (egonn_debug_set_trace): 8 s_memtime stamps per window; null = off
 };
 
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
     if (tid < rows) km = (K == 27) ? remap27(smask[tid]) : smask[tid];
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int npass = (K == 27) ? 3 : 1;
-    for (int pass = 0; pass < npass; ++pass) {
+    for (int pass = (K == 27 ? a.first_pass : 0); pass < npass; ++pass) {
       for (int e = tid; e < RG_WAVES * 512 / 2; e += RG_THREADS) reinterpret_cast<uint32_t*>(&s_cnt[0][0])[e] = 0u;
       __syncthreads();
       const uint32_t d = (km >> (9 * pass)) & 511u;
@@ -461,6 +462,8 @@ int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream) {
     nb += b.rg->cap_groups / (b.rg->win / 16);
   }
   a.nblocks = nb;
+  static const int env_first = [] { const char* e = getenv("EGONN_RG_FIRST_PASS"); return e ? atoi(e) : 0; }();   // measurement switch
+  a.first_pass = std::min(std::max(env_first, 0), 2);
   a.trace = g_sconv_trace;
   if (nb == 0) return EGONN_OK;
   static AttrOnce attr_done;
