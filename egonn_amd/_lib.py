@@ -25,6 +25,7 @@ _SIGS = [
     ("egonn_ctx_destroy", None, [_P]),
     ("egonn_last_error", C.c_char_p, []),
     ("egonn_debug_set_naive_conv", C.c_int, [_P, C.c_int]),
+    ("egonn_debug_set_tail", C.c_int, [_P, C.c_int]),
     ("egonn_debug_set_trace", C.c_int, [_P]),
     ("egonn_prepare_maps", C.c_int, [_P, C.c_int, _P]),
     ("egonn_debug_rowgroup_tables", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int64), _P]),
@@ -330,6 +331,10 @@ class Context:
     def set_naive_conv(self, on: bool):
         """tests only: route this context's sparse convolutions through the plain (non-MFMA) kernel."""
         check(self.lib.egonn_debug_set_naive_conv(self.h, int(on)))
+
+    def set_tail(self, mode: int):
+        """tests only: 1 = levels 5-7 + global head as per-layer launches, 0 = the resident tail kernel (product path)."""
+        check(self.lib.egonn_debug_set_tail(self.h, int(mode)))
 
     def global_avg_pool(self, level: int, x: torch.Tensor):
         x = _dev_f32(x, self.device)

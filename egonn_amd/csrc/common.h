@@ -181,7 +181,7 @@ struct Plan {
 };
 
 // ------------------------------------------------------------------ per-launch HIP-event timing (bench.py roofline leg)
-enum ProfKind { PK_CONV0 = 0, PK_K3 = 1, PK_K2S2 = 2, PK_TCONV = 3, PK_OTHER = 4 };
+enum ProfKind { PK_CONV0 = 0, PK_K3 = 1, PK_K2S2 = 2, PK_TCONV = 3, PK_OTHER = 4, PK_TAIL = 5 };
 struct ProfRec {
   char name[64];
   int kind, level, K, cin, cout;     // enough to evaluate the algorithmic-bytes formula of SURVEY.md §8(d)
@@ -218,6 +218,10 @@ struct Ctx {
   int32_t* host_counts = nullptr;    // pinned staging for the size query
   int32_t* dev_counts = nullptr;
   int32_t* dev_flags = nullptr;      // bit 0 = out-of-range coordinate seen, bit 1 = batch larger than the reserved capacities
+  uint32_t* tail_flags = nullptr;    // [EGONN_MAX_BATCH][8] stage counters of the resident tail kernel (tail.hip), zeroed once
+  float* tail_sums = nullptr;        // [EGONN_MAX_BATCH][128]
+  int tail_mode = 0;                 // 0 = levels 5-7 + global head in the resident tail kernel (fp32 maps), 1 = per-layer launches
+                                     // (egonn_debug_set_tail; the cross-check path of tests/test_gpu_tail.py)
   bool reserved = false;             // egonn_ctx_reserve: fixed capacities, plans neither allocate nor synchronise
   int64_t reserve_points = 0;
   int reserve_batch = 0;

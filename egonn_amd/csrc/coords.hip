@@ -714,6 +714,12 @@ int plan_sync(Ctx* ctx, hipStream_t stream) {
     set_error("batch index %d >= batch size %d", ctx->host_counts[NL] - 1, B);
     return EGONN_ERR_RANGE;
   }
+  if (flags & 4) {
+    P.valid = false;
+    set_error("resident tail kernel: a sample-cluster wait timed out (a workgroup of the cluster was never scheduled); the "
+              "outputs of this batch are invalid");
+    return EGONN_ERR_HIP;
+  }
   if (flags & 2) {
     P.valid = false;
     set_error("the batch does not fit the reserved plan (points %d / capacity %lld; level rows %d %d %d %d %d %d %d %d / "

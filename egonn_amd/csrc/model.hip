@@ -77,6 +77,10 @@ struct egonn_model {
   const float *q_convs[8] = {}, *q_c1[8] = {}, *q_c2[8] = {}, *q_gt[8] = {}, *q_lt[8] = {};
   // the same kernels as hi|mid|lo bf16 fragments for the split-bf16 fp32 path (sconv_split.hip)
   const float *s_convs[8] = {}, *s_c1[8] = {}, *s_c2[8] = {}, *s_gt[8] = {}, *s_lt[8] = {};
+  // levels 5-7 + global head packed per 16-column tile for the resident tail kernel (tail.hip)
+  uint16_t* tail_packed = nullptr;
+  size_t tail_cap = 0;
+  const uint16_t *t_k2[8] = {}, *t_c1[8] = {}, *t_c2[8] = {}, *t_1x1[8] = {}, *t_gt[8] = {}, *t_m0 = nullptr, *t_m1 = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------ lifecycle
@@ -88,6 +92,14 @@ API int egonn_debug_set_naive_conv(egonn_ctx* c, int on) {
   if (on >= 6000 && on < 7000) { c->win_halo_cap = on - 6000; return EGONN_OK; }   // tests: halo capacity of the window tables built next
   if (on >= 1000) { c->conv_variant = on; return EGONN_OK; }     // 1000 + cfg: split-bf16 kernel, 5000 + G: window-resident kernel
   c->conv_variant = (on == 1) ? 3 : (on == 2 ? 1 : (on == 4 ? 2 : (on == 8 ? 4 : (on == 16 ? 5 : (on == 32 ? 6 : (on == 128 ? 9 : 0))))));
+  return EGONN_OK;
+}
+
+// 0 = levels 5-7 + the global head run in the resident tail kernel (tail.hip; fp32 maps: the product path), 1 = the per-layer
+// launches (the cross-check path of tests/test_gpu_tail.py and of A/B measurements)
+API int egonn_debug_set_tail(egonn_ctx* c, int mode) {
+  EGONN_REQUIRE(c && (mode == 0 || mode == 1), EGONN_ERR_INVALID, "debug_set_tail: bad argument");
+  c->tail_mode = mode;
   return EGONN_OK;
 }
 
@@ -115,6 +127,18 @@ API int egonn_ctx_create(egonn_ctx** out, int device, int coord_bits) {
     return EGONN_ERR_HIP;
   }
   c->dev_flags = c->dev_counts + 16;   // counts[0..11], flags at [16]: fetched by one copy
+  // resident tail kernel (tail.hip): per-scan stage counters (monotonic over launches: zeroed once, here) and ECA column sums
+  if (hipMalloc(reinterpret_cast<void**>(&c->tail_flags), sizeof(uint32_t) * 8 * EGONN_MAX_BATCH) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->tail_sums), sizeof(float) * 128 * EGONN_MAX_BATCH) != hipSuccess ||
+      hipMemset(c->tail_flags, 0, sizeof(uint32_t) * 8 * EGONN_MAX_BATCH) != hipSuccess) {
+    set_error("ctx_create: allocation failed");
+    egonn_ctx_destroy(c);
+    return EGONN_ERR_HIP;
+  }
+  {
+    static const bool use_tail = getenv("EGONN_TAIL") != nullptr;       // (work in progress: the resident tail is opt-in until it wins)
+    c->tail_mode = use_tail ? 0 : 1;
+  }
   if (conv0_lut_init(c) != EGONN_OK) {
     egonn_ctx_destroy(c);
     return EGONN_ERR_HIP;
@@ -134,6 +158,8 @@ API void egonn_ctx_destroy(egonn_ctx* c) {
   if (c->dev_counts) (void)hipFree(c->dev_counts);
   if (c->dev_pairs) (void)hipFree(c->dev_pairs);
   if (c->conv0_lut) (void)hipFree(c->conv0_lut);
+  if (c->tail_flags) (void)hipFree(c->tail_flags);
+  if (c->tail_sums) (void)hipFree(c->tail_sums);
 
   for (auto& r : c->prof.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto& r : c->prof.graph_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -508,6 +534,7 @@ API void egonn_model_destroy(egonn_model* m) {
   if (m->folded) (void)hipFree(m->folded);
   if (m->packed) (void)hipFree(m->packed);
   if (m->conv0_unit) (void)hipFree(m->conv0_unit);
+  if (m->tail_packed) (void)hipFree(m->tail_packed);
   delete m;
 }
 
@@ -667,6 +694,35 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
     EGONN_TRY(pack2(m->gt[7], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[7], &m->q_gt[7], &m->s_gt[7]));
     EGONN_TRY(pack2(m->lt[4], 8, LOCAL_CH, LOCAL_CH, &m->p_lt[4], &m->q_lt[4], &m->s_lt[4]));
   }
+  // ---- levels 5-7 + global head + descriptor decoder per 16-column tile (tail.hip)
+  {
+    const size_t c2 = (size_t)GLOBAL_CH * GLOBAL_CH;
+    const size_t need_t = (3 * 8 + 6 * 27 + 3 + 2 * 8) * c2 + (size_t)m->gdec.mid * GLOBAL_CH + (size_t)GLOBAL_DIM * m->gdec.mid;
+    if (m->tail_cap < need_t) {
+      if (m->tail_packed) HIP_CHECK(hipFree(m->tail_packed));
+      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->tail_packed), need_t * 3 * sizeof(uint16_t)));
+      m->tail_cap = need_t;
+    }
+    uint16_t* tc = m->tail_packed;
+    auto packt = [&](const float* w, int K, int ci, int co, int out_in, const uint16_t** dst) -> int {
+      EGONN_TRY(pack_tail_weights(w, K, ci, co, out_in, tc, st));
+      *dst = tc;
+      tc += (size_t)K * ci * co * 3;
+      return EGONN_OK;
+    };
+    for (int i = 5; i <= 7; ++i) {
+      const BlockRef& b = m->blk[i];
+      EGONN_REQUIRE(b.cin == GLOBAL_CH && b.cout == GLOBAL_CH && !b.down, EGONN_ERR_STATE, "model: levels 5-7 are 128-channel blocks");
+      EGONN_TRY(packt(m->convs[i], 8, 128, 128, 0, &m->t_k2[i]));
+      EGONN_TRY(packt(b.conv1, 27, 128, 128, 0, &m->t_c1[i]));
+      EGONN_TRY(packt(b.conv2, 27, 128, 128, 0, &m->t_c2[i]));
+      EGONN_TRY(packt(m->g1x1[i], 1, 128, GLOBAL_CH, 0, &m->t_1x1[i]));
+    }
+    EGONN_TRY(packt(m->gt[6], 8, GLOBAL_CH, GLOBAL_CH, 0, &m->t_gt[6]));
+    EGONN_TRY(packt(m->gt[7], 8, GLOBAL_CH, GLOBAL_CH, 0, &m->t_gt[7]));
+    EGONN_TRY(packt(m->gdec.w0, 1, GLOBAL_CH, m->gdec.mid, 1, &m->t_m0));
+    EGONN_TRY(packt(m->gdec.w1, 1, m->gdec.mid, GLOBAL_DIM, 1, &m->t_m1));
+  }
   if (!m->conv0_unit) HIP_CHECK(hipMalloc(&m->conv0_unit, 2 * 4 * 3 * 64 * 16));
   EGONN_TRY(conv0_pack_unit(m->conv0, m->conv0_unit, st));
   EGONN_TRY(fold(m->bn[0], st));
@@ -798,10 +854,68 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
                                   (flags & EGONN_FLAG_IGNORE_KP_REGRESSOR) ? 1 : 0, out_desc, out_kp, out_sigma, st));
     return EGONN_OK;
   };
+  // levels 5-7 + global head + decoder + pooling: one resident launch for fp32 maps (tail.hip)
+  const bool use_tail = !bf16 && c->tail_mode == 0 && c->conv_variant == 0 && m->t_m1 != nullptr && B <= EGONN_MAX_BATCH;
+  bool tail_done = false;
   for (int i = 1; i <= 7; ++i) {
     const BlockRef& b = m->blk[i];
     const Level& L = P.lv[i];
     const int64_t n = P.cap[i];
+    if (use_tail && i == 5) {
+      TailArgs ta;
+      memset(&ta, 0, sizeof(ta));
+      ta.B = B;
+      ta.do_head = do_global ? 1 : 0;
+      ta.pool_mode = (flags & EGONN_FLAG_POOL_MAC) ? 2 : ((flags & EGONN_FLAG_POOL_SPOC) ? 0 : 1);
+      if (do_global && ta.pool_mode == 1)
+        EGONN_REQUIRE(m->gem_p, EGONN_ERR_STATE, "forward: GeM pooling needs the tensor 'global_pooling.pooling.p'");
+      ta.cnt = cnt;
+      for (int l = 0; l < EGONN_NUM_LEVELS; ++l) { ta.boff[l] = P.lv[l].boff; ta.cap[l] = (int)P.cap[l]; }
+      auto tmap = [](const RowGroups& rg) { return TailMap{rg.snbr, rg.gmask, rg.perm, rg.meta}; };
+      for (int li = 0; li < 3; ++li) {
+        const int lv = 5 + li;
+        const BlockRef& tb = m->blk[lv];
+        ta.rg27[li] = tmap(P.lv[lv].rg27);
+        ta.rg8[li] = tmap(P.lv[lv].rg8);
+        FALLOC(ty, P.cap[lv] * 128);
+        FALLOC(tt1, P.cap[lv] * 128);
+        FALLOC(tt2, P.cap[lv] * 128);
+        FALLOC(tx, P.cap[lv] * 128);
+        ta.y[li] = (float*)ty; ta.t1[li] = (float*)tt1; ta.t2[li] = (float*)tt2; ta.x[li] = (float*)tx;
+        ta.w_k2[li] = m->t_k2[lv]; ta.w_c1[li] = m->t_c1[lv]; ta.w_c2[li] = m->t_c2[lv]; ta.w_1x1[li] = m->t_1x1[lv];
+        ta.bn_s[li] = m->bn[lv].scale; ta.bn_h[li] = m->bn[lv].shift;
+        ta.n1_s[li] = tb.n1.scale; ta.n1_h[li] = tb.n1.shift;
+        ta.n2_s[li] = tb.n2.scale; ta.n2_h[li] = tb.n2.shift;
+        ta.eca_w[li] = tb.eca; ta.eca_k[li] = tb.eca_k;
+        x[lv] = tx;
+        c->level_feat[lv] = tx;
+        c->level_ch[lv] = 128;
+      }
+      ta.x4 = (const float*)x[4];
+      if (do_global) {
+        ta.rgT[0] = tmap(P.lv[6].rgT);
+        ta.rgT[1] = tmap(P.lv[5].rgT);
+        ta.w_t[0] = m->t_gt[7]; ta.w_t[1] = m->t_gt[6];
+        ta.w_m0 = m->t_m0; ta.w_m1 = m->t_m1;
+        ta.b0 = m->gdec.b0; ta.b1 = m->gdec.b1; ta.gem_p = m->gem_p;
+        EGONN_REQUIRE(m->gdec.cin == 128 && m->gdec.mid == 192 && m->gdec.cout == 256, EGONN_ERR_STATE, "global decoder: unexpected layer sizes");
+        WALLOC(tg7, P.cap[7] * GLOBAL_CH);
+        WALLOC(tg6, P.cap[6] * GLOBAL_CH);
+        WALLOC(tg5, P.cap[5] * GLOBAL_CH);
+        WALLOC(tgh, P.cap[5] * 192);
+        ta.g7 = tg7; ta.g6 = tg6; ta.g5 = tg5; ta.gh = tgh;
+        ta.out_global = out_global;
+      }
+      ta.sums = c->tail_sums; ta.flags = c->tail_flags; ta.err = c->dev_flags;
+      ta.trace = g_sconv_trace;
+      {
+        ProfScope ps(c, st, "tail_kernel<128,128>/L5-7+head", PK_TAIL, 5, 27, 128, 128, 4);
+        EGONN_TRY(tail_forward(ta, st));
+      }
+      DBG_SYNC("tail");
+      tail_done = true;
+      break;
+    }
     FALLOC(y, n * b.cin);
     char tag[64];
     {
@@ -855,7 +969,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   DBG_SYNC("local head");
 
   // ---- global head + decoder + GeM (models/minkgl.py:46-60, 207-225; layers/pooling.py:82-86)
-  if (do_global) {
+  if (do_global && !tail_done) {
     FALLOC(g7, P.cap[7] * GLOBAL_CH);
     EGONN_TRY(dense_forward_ex(x[7], bf16, P.cap[7], 128, m->g1x1[7], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0,
                                g7, bf16, st, cnt + 7));
@@ -990,6 +1104,29 @@ API int egonn_profile_fetch(egonn_ctx* c, int cap, int* n, char* names, float* m
       ms[w] = t;
       bytes[w] = Pn * r.cin * r.es + n_out * r.cout * r.es + (double)r.K * r.cin * r.cout * r.es + 8.0 * Pn;
       flops[w] = 2.0 * Pn * r.cin * r.cout;
+      if (r.kind == PK_TAIL) {
+        // the resident tail (tail.hip): the sum of the same formula over its 11 sparse convolutions (k=2,s=2 + 2 x k=3 of
+        // levels 5-7, the two transposed convolutions of the head) + the dense layers N * (Cin + Cout) * e (1x1 x 3, decoder)
+        double by = 0, fl = 0;
+        auto conv = [&](double pn, double no, int K) {
+          by += pn * 128 * 4 + no * 128 * 4 + (double)K * 128 * 128 * 4 + 8.0 * pn;
+          fl += 2.0 * pn * 128 * 128;
+        };
+        for (int l = 5; l <= 7; ++l) {
+          const double nl = (double)P.lv[l].n;
+          conv((double)P.lv[l - 1].n, nl, 8);
+          conv((double)pairs[l], nl, 27);
+          conv((double)pairs[l], nl, 27);
+          by += nl * 256 * 4; fl += 2.0 * nl * 128 * 128;                   // conv1x1
+        }
+        conv((double)P.lv[6].n, (double)P.lv[6].n, 8);
+        conv((double)P.lv[5].n, (double)P.lv[5].n, 8);
+        const double n5 = (double)P.lv[5].n;
+        by += n5 * (128 + 192) * 4 + n5 * (192 + 256) * 4;
+        fl += 2.0 * n5 * (128.0 * 192 + 192.0 * 256);
+        bytes[w] = by;
+        flops[w] = fl;
+      }
       ++w;
     }
     if (plain) { c->prof.pool.push_back(r.e0); c->prof.pool.push_back(r.e1); }
