@@ -123,27 +123,14 @@ struct RowGroups {
   int32_t* meta = nullptr;    // [0] groups in use, [1 + b] first group of sample b (b = 0..B)
   int32_t* order4 = nullptr;  // [cap_groups / 4] tasks of 4 consecutive groups in dispatch order: inside each contiguous eighth
                               // (= XCD) the tasks with the most offsets first (the tail of a launch is then made of short tasks)
-  // window-resident form (sconv_win.hip; k=3 maps with win == WIN_ROWS only, null otherwise): every window's DISTINCT input
-  // rows are staged once in LDS — its own rows in slots [0, rows), the rows it references outside itself ("halo") in slots
-  // WIN_ROWS + i — and the table entries are LDS slots instead of global rows
-  uint16_t* wslot = nullptr;  // [cap_groups][K][16] LDS slot of every table entry; WIN_ZERO_SLOT = absent
-  int32_t* urow = nullptr;    // [cap_groups / 16][WIN_HALO] global row of halo slot i, -1 = unused
-  int32_t* wmeta = nullptr;   // [cap_groups / 16][4]: first row, rows, halo rows staged, halo rows without a slot
   bool built = false;
 };
-static constexpr int WIN_ROWS = 256;             // rows (16 groups) of a window of the window-resident kernel
-static constexpr int WIN_HALO = 128;             // halo slots (benchmark clouds, levels 1-4: mean 62-86, p99 ~ 160, max ~ 200): the few
-                                                 // halo rows beyond it keep code WIN_OVF_SLOT and are gathered from global memory
-static constexpr int WIN_SLOTS = WIN_ROWS + WIN_HALO;
-static constexpr int WIN_ZERO_SLOT = WIN_SLOTS;  // an all-zero row: what an absent neighbour reads
-static constexpr int WIN_OVF_SLOT = 0xFFFE;      // table code of a halo row that got no slot
 struct RGBuild {
   RowGroups* rg;
   const int32_t* nbr;         // [n][K] kernel map
   const int32_t* n_dev;       // device: rows of the output level
   const int32_t* boff;        // device: [B+1] per-sample offsets of the output level
   int32_t cap_rows = 0;       // rows the level's arrays (and the map) can hold: rows beyond it are never touched
-  int32_t halo_cap = WIN_HALO;   // (tests: a smaller value forces the overflow path of the window-resident kernel)
 };
 int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream);
 
@@ -205,10 +192,6 @@ struct Ctx {
   int device = 0;
   int coord_bits = 16;
   int split_max_level = 4;    // fp32 sparse convs whose output level is <= this run on the split-bf16 kernels (sconv.hip)
-  int win_max_level = 0;      // k=3 maps of levels <= this get 256-row windows + the window-resident tables and run on
-                              // sconv_win.hip.  0 = off, the product setting: measured slower than the lock-step split kernel
-                              // (round 4, profiles/r04_window_kernel.txt); egonn_debug_set_naive_conv(7000 + level) switches it on
-  int win_halo_cap = WIN_HALO;   // tests only (egonn_debug_set_naive_conv 6000 + n)
   int conv_variant = 0;       // tests / A-B measurements only (egonn_debug_set_naive_conv): 0 = product choice, 1 = per-wave
                               // MFMA kernel, 2 = workgroup-cooperative MFMA kernel, 3 = plain one-thread-per-output kernel
   Arena plan_arena;           // keys, maps (lives until the next plan)

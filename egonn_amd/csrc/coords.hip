@@ -941,10 +941,7 @@ int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, h
     const int32_t* nbr = kind == 0 ? V.nbr27 : (kind == 1 ? V.nbr8 : V.nbrT);
     EGONN_REQUIRE(nbr, EGONN_ERR_STATE, "rowgroups: the plan has no kernel map of kind %d at level %d", kind, l);
     rg.K = kind == 0 ? 27 : 8;
-    // k=3 maps of the big levels: WIN_ROWS-row windows + the window-resident tables (sconv_win.hip stages every distinct input
-    // row of a window ONCE in LDS instead of gathering it once per output neighbour)
-    const bool winmode = kind == 0 && l <= ctx->win_max_level;
-    rg.win = winmode ? WIN_ROWS : rg_window(l);
+    rg.win = rg_window(l);
     const int gpw = rg.win / 16;
     rg.cap_groups = (int)((cdiv(P.cap[l], rg.win) + P.batch) * gpw);
     Arena& A = ctx->plan_arena;
@@ -953,13 +950,6 @@ int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, h
     rg.gmask = A.alloc<uint32_t>((size_t)rg.cap_groups);
     rg.meta = A.alloc<int32_t>((size_t)P.batch + 2);
     rg.order4 = A.alloc<int32_t>((size_t)rg.cap_groups / 4 + 16);
-    rg.wslot = nullptr; rg.urow = nullptr; rg.wmeta = nullptr;
-    if (winmode) {
-      rg.wslot = A.alloc<uint16_t>((size_t)rg.cap_groups * rg.K * 16);
-      rg.urow = A.alloc<int32_t>((size_t)(rg.cap_groups / gpw) * WIN_HALO);
-      rg.wmeta = A.alloc<int32_t>((size_t)(rg.cap_groups / gpw) * 4);
-      EGONN_REQUIRE(rg.wslot && rg.urow && rg.wmeta, EGONN_ERR_STATE, "plan arena too small (window tables)");
-    }
     EGONN_REQUIRE(rg.perm && rg.snbr && rg.gmask && rg.meta && rg.order4, EGONN_ERR_STATE, "plan arena too small (row groups)");
     EGONN_REQUIRE(nj < RG_MAX_JOBS, EGONN_ERR_INVALID, "rowgroups: too many maps in one request");
     jobs[nj].rg = &rg;
@@ -967,7 +957,6 @@ int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, h
     jobs[nj].n_dev = ctx->dev_counts + l;
     jobs[nj].boff = V.boff;
     jobs[nj].cap_rows = (int32_t)P.cap[l];
-    jobs[nj].halo_cap = ctx->win_halo_cap;
     ++nj;
   }
   if (nj == 0) return EGONN_OK;
@@ -976,12 +965,11 @@ int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, h
   return EGONN_OK;
 }
 
-static size_t plan_arena_bytes(int64_t n, int B, bool window_tables) {
+static size_t plan_arena_bytes(int64_t n, int B) {
   // raw+sorted keys/vals, 10 levels x (keys, parent, cstart, mask, bstart), perm, maps of levels 1..7 (<= n rows each)
   size_t per_row = 2 * (8 + 4) + NL * (8 + 4 + 4 + 8 + 4) + 4 + 9 * 27 * 4 + 7 * (8 + 8) * 4 + 4 + 27 * 12 + 8 * 4;
   // row-group tables: k=3 (27+1 ints + mask) and the two 8-slot maps, <= 2n rows over all levels + window rounding
   per_row += 2 * ((27 + 1) * 4 + 2 + 2 * ((8 + 1) * 4 + 2));
-  if (window_tables) per_row += 2 * (27 * 2 + (WIN_HALO + 4) * 4 / WIN_ROWS + 1);   // window-resident tables (u16 slots, halo lists, headers)
   const size_t rg_round = (size_t)(B + 8) * 1024 * (28 + 14 + 2 * 9) * 4 * EGONN_NUM_LEVELS;
   return (size_t)(n + 8) * per_row + (size_t)(B + 1) * 4 * EGONN_NUM_LEVELS + (size_t)cdiv(n, PYR_TILE) * NL * 4 + rg_round +
          (1 << 20);
@@ -1000,7 +988,7 @@ int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets,
     EGONN_REQUIRE(scan_offsets[0] == 0 && n >= 1, EGONN_ERR_INVALID, "empty input (n=%lld points)", (long long)n);
     for (int b = 0; b < B; ++b)
       EGONN_REQUIRE(scan_offsets[b] <= scan_offsets[b + 1], EGONN_ERR_INVALID, "scan offsets not monotone");
-    EGONN_TRY(ctx->plan_arena.ensure(plan_arena_bytes(n, B, ctx->win_max_level > 0)));
+    EGONN_TRY(ctx->plan_arena.ensure(plan_arena_bytes(n, B)));
   } else {
     n = n_cap;
     EGONN_REQUIRE(ctx->reserved && n >= 1 && n <= ctx->reserve_points && B == ctx->reserve_batch, EGONN_ERR_STATE,
@@ -1035,7 +1023,7 @@ int plan_from_coords(Ctx* ctx, const int32_t* coords, int64_t n, int B, hipStrea
   ctx->plan.valid = false;
   EGONN_REQUIRE(n >= 1, EGONN_ERR_INVALID, "empty coordinate list");
   EGONN_REQUIRE(B >= 1 && B <= EGONN_MAX_BATCH, EGONN_ERR_INVALID, "batch size %d outside [1,%d]", B, EGONN_MAX_BATCH);
-  EGONN_TRY(ctx->plan_arena.ensure(plan_arena_bytes(n, B, ctx->win_max_level > 0)));
+  EGONN_TRY(ctx->plan_arena.ensure(plan_arena_bytes(n, B)));
   Arena& A = ctx->plan_arena;
   A.reset();
   uint64_t* k0 = A.alloc<uint64_t>(n);
@@ -1062,7 +1050,7 @@ int plan_reserve(Ctx* ctx, int64_t max_points, int B, const int64_t* level_caps)
   }
   ctx->reserve_points = max_points;
   ctx->reserve_batch = B;
-  EGONN_TRY(ctx->plan_arena.ensure(plan_arena_bytes(max_points, B, ctx->win_max_level > 0)));
+  EGONN_TRY(ctx->plan_arena.ensure(plan_arena_bytes(max_points, B)));
   EGONN_TRY(ctx->sort_arena.ensure(std::max(radix_sort_scratch_bytes(max_points), radix_sort_segments_scratch_bytes(max_points, B))));
   ctx->reserved = true;
   return EGONN_OK;

@@ -28,19 +28,14 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
               int bf16, const float* scale, const float* shift, int relu, void* out, float* psum, float* scratch,
               size_t scratch_floats, hipStream_t stream);
 bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int split_max_level);
-// sconv_split.hip: fp32 maps on the bf16 matrix pipe (three-way split operands, fp32 accumulate)
+// sconv_split.hip: fp32 maps on the fp16 matrix pipe (two-way split operands, three products, fp32 accumulate)
 bool sconv_split_supported(int cin, int cout);
 int pack_split_weights(const float* W, int K, int cin, int cout, int flip, int transpose, void* out, hipStream_t stream);
+size_t split_weights_bytes(int K, int cin, int cout);   // fragments + 16 bytes (inverse of the pack scale)
 int sconv_split_default_cfg(int cin, int cout, int64_t groups_hint);
 int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
                         int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
                         int cfg = 0);
-// sconv_win.hip: window-resident kernel (k=3 maps with the window tables of rowgroup.hip; weights in the split packing)
-bool sconv_win_supported(int cin, int cout);
-bool sconv_uses_win(const Ctx* ctx, int kind, int level, int cin, int cout, int bf16);
-int sconv_win_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
-                      int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
-                      int cfg = 0);
 // tail.hip: levels 5-7 + global head + descriptor decoder + pooling of the EgoNN graph as ONE resident launch (fp32 maps)
 struct TailMap { const int32_t* snbr; const uint32_t* gmask; const int32_t* perm; const int32_t* meta; };
 struct TailArgs {

@@ -88,9 +88,7 @@ API const char* egonn_last_error(void) { return last_error(); }
 
 API int egonn_debug_set_naive_conv(egonn_ctx* c, int on) {
   EGONN_REQUIRE(c, EGONN_ERR_INVALID, "debug_set_naive_conv: null context");
-  if (on >= 7000 && on < 7008) { c->win_max_level = on - 7000; return EGONN_OK; }  // window-resident kernel up to this level (plans built next)
-  if (on >= 6000 && on < 7000) { c->win_halo_cap = on - 6000; return EGONN_OK; }   // tests: halo capacity of the window tables built next
-  if (on >= 1000) { c->conv_variant = on; return EGONN_OK; }     // 1000 + cfg: split-bf16 kernel, 5000 + G: window-resident kernel
+  if (on >= 1000) { c->conv_variant = on; return EGONN_OK; }     // 1000 + cfg: the split kernel with an explicit configuration
   c->conv_variant = (on == 1) ? 3 : (on == 2 ? 1 : (on == 4 ? 2 : (on == 8 ? 4 : (on == 16 ? 5 : (on == 32 ? 6 : (on == 128 ? 9 : 0))))));
   return EGONN_OK;
 }
@@ -663,7 +661,7 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
     need_p += (size_t)2 * 8 * GLOBAL_CH * GLOBAL_CH + (size_t)8 * LOCAL_CH * LOCAL_CH;
     if (m->packed_cap < need_p) {
       if (m->packed) HIP_CHECK(hipFree(m->packed));
-      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->packed), (3 * need_p + 64) * sizeof(float)));
+      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->packed), (3 * need_p + 512) * sizeof(float)));
       m->packed_cap = need_p;
     }
     float* pc = m->packed;
@@ -678,7 +676,7 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
       if (sconv_split_supported(ci, co)) {
         EGONN_TRY(pack_split_weights(w, K, ci, co, 0, 0, sc, st));
         *dsts = reinterpret_cast<const float*>(sc);
-        sc += (size_t)K * ci * co * 3;
+        sc += split_weights_bytes(K, ci, co) / 2;
       }
       pc += (size_t)K * ci * co;
       qc += (size_t)K * ci * co;
@@ -782,9 +780,6 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
 
   // ---- row-group tables of every map the graph uses: one launch per plan
   {
-    const int win_keep = c->win_max_level;
-    if (bf16) c->win_max_level = 0;       // bf16 maps run on the gather kernels: 512-row windows, no window-resident tables
-    struct Restore { egonn_ctx* c; int v; ~Restore() { c->win_max_level = v; } } restore{c, win_keep};
     int kinds[RG_MAX_JOBS], levels[RG_MAX_JOBS], nreq = 0;
     for (int l = 1; l <= 7; ++l) { kinds[nreq] = 0; levels[nreq++] = l; }
     for (int l = 1; l <= 7; ++l) { kinds[nreq] = 1; levels[nreq++] = l; }

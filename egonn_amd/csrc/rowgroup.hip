@@ -49,10 +49,6 @@ struct RGJob {
   int K, win, wbase;        // wbase: first block of this job in the launch
   int cap_rows, cap_groups; // capacity of the level / of the tables: a batch that exceeds a reservation is clipped, never
                             // written out of bounds (egonn_plan_status reports it)
-  uint16_t* wslot;          // window-resident form (common.h RowGroups; null = not wanted): requires win == WIN_ROWS
-  int32_t* urow;
-  int32_t* wmeta;
-  int halo_cap;
 };
 struct RGArgs {
   RGJob job[RG_MAX_JOBS];
@@ -78,7 +74,6 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
   __shared__ uint32_t s_k[RG_MAX_WIN];
   __shared__ uint16_t s_i[RG_MAX_WIN];
   __shared__ int32_t s_info[4];
-  __shared__ int32_t s_hw[20];                           // window-resident form: per-(round, wave) halo counts, [18] = table full
   const int tid = threadIdx.x, lane = tid & 63;
   unsigned long long* const tr = (TRACE && a.trace) ? a.trace + (size_t)blockIdx.x * 8 : nullptr;
   auto stamp = [&](int i) {
@@ -233,79 +228,6 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
   }
   __syncthreads();
   stamp(4);
-  // ---- window-resident form (sconv_win.hip): the DISTINCT rows this window references outside itself get LDS slots
-  // WIN_ROWS + i.  Dedup by an open-addressing hash set in LDS (the sort's counters are free now), slots = rank of the entry
-  // in table order (ballot prefix).  Which slot a halo row gets may differ from run to run (insertion races decide the probe
-  // position); the convolution's arithmetic does not depend on it.
-  int32_t* const hkey = reinterpret_cast<int32_t*>(&s_cnt[0][0]);          // [1024]
-  uint16_t* const hslot = reinterpret_cast<uint16_t*>(hkey + 1024);         // [1024]
-  static_assert(sizeof(s_cnt) >= 1024 * 4 + 1024 * 2, "hash set aliases the sort counters");
-  const bool winmode = J.wslot != nullptr;
-  auto hash_of = [](int32_t j) { return (int)(((uint32_t)j * 2654435761u) >> 22); };
-  if (winmode) {
-    for (int e = tid; e < 1024; e += RG_THREADS) hkey[e] = -1;
-    if (tid == 0) s_hw[18] = 0;
-    __syncthreads();
-    for (int e = tid; e < nint; e += RG_THREADS) {
-      const int32_t jrow = stbl[e];
-      if (jrow >= 0 && (jrow < r0 || jrow >= r0 + rows)) {
-        int h = hash_of(jrow);
-        for (int probes = 0;; ++probes) {
-          const int32_t old = atomicCAS(&hkey[h], -1, jrow);
-          if (old == -1 || old == jrow) break;
-          h = (h + 1) & 1023;
-          if (probes >= 1023) { s_hw[18] = 1; break; }
-        }
-      }
-    }
-    __syncthreads();
-    const int wave = tid >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    unsigned long long bal[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      bal[r] = __ballot(hkey[r * RG_THREADS + tid] >= 0);
-      if (lane == 0) s_hw[r * RG_WAVES + wave] = __popcll(bal[r]);
-    }
-    __syncthreads();
-    int total = 0, base[2] = {0, 0};
-#pragma unroll
-    for (int q = 0; q < 2 * RG_WAVES; ++q) {
-      const int c = s_hw[q];
-      if (q < wave) base[0] += c;
-      if (q < RG_WAVES + wave) base[1] += c;
-      total += c;
-    }
-    const int hcap = min(J.halo_cap, WIN_HALO);
-    int32_t* const urow = J.urow + (int64_t)w * WIN_HALO;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int e = r * RG_THREADS + tid;
-      const int32_t key = hkey[e];
-      if (key >= 0) {
-        const int rank = base[r] + __popcll(bal[r] & lt);
-        hslot[e] = (uint16_t)(rank < hcap ? WIN_ROWS + rank : WIN_OVF_SLOT);
-        if (rank < hcap) urow[rank] = key;
-      }
-    }
-    const int nh = min(total, hcap);
-    for (int i = nh + tid; i < WIN_HALO; i += RG_THREADS) urow[i] = -1;
-    if (tid == 0) {
-      int32_t* m = J.wmeta + (int64_t)w * 4;
-      m[0] = r0; m[1] = rows; m[2] = nh; m[3] = s_hw[18] ? -1 : total - nh;
-    }
-    __syncthreads();
-  }
-  auto slot_of = [&](int32_t jrow) -> uint16_t {           // LDS slot of a table entry
-    if (jrow < 0) return (uint16_t)WIN_ZERO_SLOT;
-    if (jrow >= r0 && jrow < r0 + rows) return (uint16_t)(jrow - r0);
-    int h = hash_of(jrow);
-    for (int probes = 0; probes < 1024; ++probes) {
-      if (hkey[h] == jrow) return hslot[h];
-      h = (h + 1) & 1023;
-    }
-    return (uint16_t)WIN_OVF_SLOT;                         // (hash set full — > 1023 distinct halo rows: gathered from global memory)
-  };
   // ---- perm + group masks
   const int64_t gbase = (int64_t)w * GPW;
   for (int i = tid; i < WIN; i += RG_THREADS) {         // WIN is a multiple of 64: whole waves stay in the loop
@@ -334,11 +256,6 @@ __global__ __launch_bounds__(RG_THREADS) void rowgroup_build_kernel(RGArgs a) {
       v[j2] = (key != ~0ull) ? stbl[(int)(key & 0xFFFFu) * K + k] : -1;
     }
     reinterpret_cast<int4*>(J.snbr + (gbase + gl) * K * 16)[pc] = make_int4(v[0], v[1], v[2], v[3]);
-    if (winmode) {
-      const uint32_t lo = (uint32_t)slot_of(v[0]) | ((uint32_t)slot_of(v[1]) << 16);
-      const uint32_t hi = (uint32_t)slot_of(v[2]) | ((uint32_t)slot_of(v[3]) << 16);
-      reinterpret_cast<uint2*>(J.wslot + (gbase + gl) * K * 16)[pc] = make_uint2(lo, hi);
-    }
   }
   stamp(6);
   if constexpr (TRACE) {
@@ -456,9 +373,6 @@ int rowgroup_build(const RGBuild* jobs, int njobs, int B, hipStream_t stream) {
     J.K = b.rg->K; J.win = b.rg->win; J.wbase = nb;
     J.cap_rows = b.cap_rows > 0 ? b.cap_rows : INT32_MAX;
     J.cap_groups = b.rg->cap_groups;
-    J.wslot = b.rg->wslot; J.urow = b.rg->urow; J.wmeta = b.rg->wmeta; J.halo_cap = b.halo_cap;
-    EGONN_REQUIRE(!J.wslot || (b.rg->win == WIN_ROWS && b.rg->K == 27 && J.urow && J.wmeta), EGONN_ERR_INVALID,
-                  "rowgroup_build: the window-resident form needs %d-row windows of a k=3 map", WIN_ROWS);
     nb += b.rg->cap_groups / (b.rg->win / 16);
   }
   a.nblocks = nb;

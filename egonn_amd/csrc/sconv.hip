@@ -1182,7 +1182,6 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
 // the kernel rocprofv3 names).  Mirrors the choices in sconv_map / sconv_rg_forward / launch_rg.
 const char* sconv_kernel_name(const Ctx* ctx, int kind, int level, int cin, int cout, int bf16) {
   const int variant = ctx->conv_variant;
-  if (sconv_uses_win(ctx, kind, level, cin, cout, bf16)) return "sconv_win_kernel";
   if (sconv_uses_split(cin, cout, bf16, level, variant, ctx->split_max_level)) return "sconv_split_kernel";
   const bool small = level >= (bf16 ? 6 : 5);
   const bool coop = variant == 2 || (variant == 0 && bf16 && level <= 4 && cin * cout >= 32 * 64);
@@ -1204,24 +1203,13 @@ const char* sconv_kernel_name(const Ctx* ctx, int kind, int level, int cin, int 
 // >= inf / 4096 / 2000 / 700 / 200 groups = 21.8 k / 23.3 k / 24.3 k / 24.8 k / 23.6 k, i.e. levels <= 0 / 2 / 3 / 4 / 6.
 bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int split_max_level) {
   if (bf16 || !sconv_split_supported(cin, cout)) return false;
-  if (variant >= 1000 && variant < 5000) return true;
-  if (variant != 0 && variant < 5000) return false;    // (5000 + G: the window kernel's configuration; everything else as 0)
+  if (variant >= 1000) return true;
+  if (variant != 0) return false;
   static const int env_level = [] {                       // EGONN_SPLIT_MAX_LEVEL: measurement override
     const char* e = getenv("EGONN_SPLIT_MAX_LEVEL");
     return e ? atoi(e) : -1;
   }();
   return level <= (env_level >= 0 ? env_level : split_max_level);
-}
-
-// The window-resident kernel (sconv_win.hip) takes the k=3 maps whose row groups carry its tables (levels <= ctx->win_max_level,
-// fp32 maps, an instantiated channel plan).  conv_variant 5000 + G selects it with G groups per wave; 1..9 / 1000 + cfg (the
-// exact and lock-step kernels) bypass it.
-bool sconv_uses_win(const Ctx* ctx, int kind, int level, int cin, int cout, int bf16) {
-  if (bf16 || kind != 0 || level < 1 || level > ctx->win_max_level || !sconv_win_supported(cin, cout)) return false;
-  const int v = ctx->conv_variant;
-  if (v != 0 && !(v >= 5000 && v < 6000)) return false;
-  static const bool off = getenv("EGONN_NO_WIN") != nullptr;     // measurement switch
-  return !off;
 }
 
 int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, const void* Wsp, int cin, int cout,
@@ -1246,20 +1234,16 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
   }
   EGONN_TRY(ensure_rowgroups(ctx, &kind, &level, 1, stream));
   const RowGroups& rg = kind == 0 ? V.rg27 : (kind == 1 ? V.rg8 : V.rgT);
-  const bool use_win = sconv_uses_win(ctx, kind, level, cin, cout, bf16) && rg.wslot;
-  if (use_win || sconv_uses_split(cin, cout, bf16, level, ctx->conv_variant, ctx->split_max_level)) {
+  if (sconv_uses_split(cin, cout, bf16, level, ctx->conv_variant, ctx->split_max_level)) {
     if (!Wsp) {   // stand-alone operator call: pack into the caller's scratch
-      const size_t wn = ((size_t)K * cin * cout * 3 + 1) / 2;
+      const size_t wn = (split_weights_bytes(K, cin, cout) + 3) / 4;
       EGONN_REQUIRE(W && scratch && scratch_floats >= wn, EGONN_ERR_STATE, "sconv: no scratch to pack the kernel into");
       EGONN_TRY(pack_split_weights(W, K, cin, cout, 0, 0, scratch, stream));
       Wsp = scratch;
     }
-    if (use_win)
-      return sconv_win_forward(reinterpret_cast<const float*>(in), P.cap[lin], rg, rg.cap_groups, Wsp, cin, cout, scale, shift, relu,
-                               reinterpret_cast<float*>(out), psum, stream, ctx->conv_variant >= 5000 ? ctx->conv_variant - 5000 : 0);
     return sconv_split_forward(reinterpret_cast<const float*>(in), P.cap[lin], rg, rg.cap_groups, Wsp, cin, cout, scale, shift,
                                relu, reinterpret_cast<float*>(out), psum, stream,
-                               (ctx->conv_variant >= 1000 && ctx->conv_variant < 5000) ? ctx->conv_variant - 1000 : 0);
+                               ctx->conv_variant >= 1000 ? ctx->conv_variant - 1000 : 0);
   }
   if (!Wp) {      // stand-alone operator call: pack into the caller's scratch
     const size_t wn = (size_t)K * cin * cout;

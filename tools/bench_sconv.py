@@ -19,8 +19,6 @@ off = [0]
 for s in scans: off.append(off[-1] + len(s))
 pts = torch.from_numpy(np.concatenate(scans)).cuda()
 ctx = _lib.Context(coord_bits=12)
-if os.environ.get("WIN"):                            # WIN=3: window-resident kernel (sconv_win.hip) on levels <= 3
-    ctx.lib.egonn_debug_set_naive_conv(ctx.h, 7000 + int(os.environ["WIN"]))
 ctx.voxelize(pts, off, 0, [0.1])
 ref = _lib.Context(coord_bits=12)
 ref.voxelize(pts, off, 0, [0.1])

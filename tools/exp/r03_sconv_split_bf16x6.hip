@@ -1,0 +1,823 @@
+// fp32 sparse convolution on the bf16 matrix pipe: three-way split operands, fp32 accumulate (gfx950).
+//
+// Replaces the same reference operators as sconv.hip (MinkowskiConvolution k=3 / k=2,s=2 and
+// MinkowskiConvolutionTranspose forward: models/minkgl.py:39,100,105 and :46-60; ME BasicBlock conv1/conv2 via
+// layers/eca_block.py:58-63) for fp32 feature maps:
+//
+//   out[o] = act( (sum_k in[nbr[o][k]] @ W[k]) * scale + shift )
+//
+// Why.  v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (157 TFLOP/s, 1/16 of the bf16 matrix rate) and was the binding
+// roof of every fp32 layer with >= 64 channels (0.29-0.34 of it on 1.4x-padded tiles).  An fp32 number is
+// EXACTLY the sum of three bf16 numbers (24 = 8 + 8 + 8 significand bits: hi = rn(x), mid = rn(x - hi), lo = x - hi - mid),
+// and a bf16 x bf16 product is exact in fp32.  So  a*w = sum over the nine (part of a, part of w) products; the six with
+// weight >= 2^-16 relative (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) are issued on v_mfma_f32_16x16x32_bf16 with fp32
+// accumulation; the three dropped ones are <= 2^-25 |a w| each (round-to-nearest parts: |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|),
+// i.e. below the rounding of an fp32 FMA chain.  6 bf16 MFMAs of 16 cycles replace 16 fp32 MFMAs of 32: 0.1875 x the matrix
+// time per product.  TERMS = 3 / 9 are measurement variants (tools/bench_sconv.py).
+//
+// Once the matrix pipe is out of the way the per-wave kernel of sconv.hip is bound by its W fragments (every wave re-reads
+// W[k][cb] for every 16 rows: 3 x more bytes than the rows it gathers), so the decomposition changes as well:
+//   * a WORKGROUP of NW waves owns NW*G consecutive row groups (rowgroup.hip: 16 output rows each, sorted by neighbour mask
+//     inside a window, so consecutive groups have nearly the same offsets present) and ALL output columns;
+//   * the workgroup walks the UNION of its groups' offsets k and the 32-channel blocks cb in lock-step.  Per step the slab
+//     W[k][cb][all columns] (hi|mid|lo fragments, 192*COUT bytes) is copied ONCE per workgroup global -> LDS by LDS-DMA
+//     (buffer_load_dwordx4 ... lds, lane-linear = fragment order) and every wave reads its B fragments from there;
+//   * every wave gathers the rows of its own G groups by LDS-DMA in full 128-byte lines (structured buffer: vindex = the
+//     neighbour row from the table, -1 = absent = out of range = zeros without traffic; XOR-swizzled source chunk so that
+//     the lane-linear LDS image is conflict-free for the ds_read_b128 fragment reads), splits them ONCE in registers
+//     (44 VALU per group and step) and feeds the MFMAs of all COUT/32 column slices;
+//   * DMA of step i+LA is issued at the start of step i (LA = DA-1 ring slots of look-ahead); a wave waits for its own
+//     pieces of step i+1 at the end of step i and one s_barrier per step publishes the slab (and retires the slab that is
+//     overwritten next);
+//   * a group that lacks the offset skips the step's split and MFMAs (wave-uniform branch).
+// Every output row is produced by one wave, summed in ascending k, ascending channel block, fixed term order: results do not
+// depend on the batch, the grouping of other rows or eager vs graph execution (bitwise reproducible, batch-invariant).
+// The compiler does not know that an LDS-DMA write feeds a later ds_read (it would drain vmcnt(0) in front of any LDS read
+// it can see), so every LDS read of the step loop is issued from asm with its own counted waits.
+#include <stdlib.h>
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include <hip/hip_ext.h>
+#include "kernels.h"
+
+namespace egonn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// channel of the 32-channel block that lane group g (= lane >> 4) holds in element e of its 8-element MFMA operand: the two
+// 16-byte chunks g and 4+g of the gathered 128-byte row (the conflict-free ds_read_b128 pattern of the swizzled image)
+__host__ __device__ static inline int sp_chan(int g, int e) { return e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4); }
+
+__device__ static inline uint32_t bf16_rn_bits(float a) {
+  uint32_t u = __float_as_uint(a);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// ------------------------------------------------------------------ weight packing
+// W[k][ci][co] -> Wsp[k][cb][ns][f][lane][e] (bf16), f = 2*part + nt, part: 0 hi, 1 mid, 2 lo
+//   = part( W[k][32cb + sp_chan(lane>>4, e)][32ns + 16nt + (lane&15)] )
+// so that the slab of a step (k, cb) is one contiguous block of COUT/32 * 6 KB and every 1 KB piece is one lane-linear
+// MFMA A-operand fragment.  flip / transpose: as pack_rg_weights (input-gradient kernels, k=2 <-> transposed pairs).
+__global__ void pack_split_weights_kernel(const float* __restrict__ W, int K, int cin, int cout, int flip, int transpose,
+                                          uint16_t* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per_k = (int64_t)cin * cout;
+  if (t >= K * per_k * 3) return;
+  const int ncb = cin / 32, ns_n = cout / 32;
+  int64_t r = t;
+  const int e = (int)(r & 7); r >>= 3;
+  const int lane = (int)(r & 63); r >>= 6;
+  const int f = (int)(r % 6); r /= 6;
+  const int ns = (int)(r % ns_n); r /= ns_n;
+  const int cb = (int)(r % ncb); r /= ncb;
+  const int k = (int)r;
+  const int part = f >> 1, nt = f & 1;
+  const int ci = 32 * cb + sp_chan(lane >> 4, e);
+  const int co = 32 * ns + 16 * nt + (lane & 15);
+  const int ks = flip ? K - 1 - k : k;
+  const float v = transpose ? W[(int64_t)ks * per_k + (int64_t)co * cin + ci] : W[(int64_t)ks * per_k + (int64_t)ci * cout + co];
+  const uint32_t hi = bf16_rn_bits(v);
+  const float r1 = v - __uint_as_float(hi << 16);
+  const uint32_t mid = bf16_rn_bits(r1);
+  const float r2 = r1 - __uint_as_float(mid << 16);
+  const uint32_t lo = bf16_rn_bits(r2);                  // exact: r2 has <= 8 significant bits
+  out[t] = (uint16_t)(part == 0 ? hi : (part == 1 ? mid : lo));
+}
+
+int pack_split_weights(const float* W, int K, int cin, int cout, int flip, int transpose, void* out, hipStream_t stream) {
+  EGONN_REQUIRE(cin % 32 == 0 && cout % 32 == 0, EGONN_ERR_INVALID, "sconv: channel counts must be multiples of 32 (%d->%d)", cin, cout);
+  const int64_t n = (int64_t)K * cin * cout * 3;
+  hipLaunchKernelGGL(pack_split_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, W, K, cin, cout, flip,
+                     transpose, reinterpret_cast<uint16_t*>(out));
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ the kernel
+struct SplitArgs {
+  const float* in;           // [n_in][CIN] fp32
+  const int32_t* snbr;       // row-group tables
+  const uint32_t* gmask;
+  const int32_t* perm;
+  const int32_t* meta;       // [0] = groups in use
+  const int32_t* order;      // dispatch order of the 4-group tasks (rowgroup.hip; nullable = table order)
+  const void* Wsp;           // pack_split_weights
+  const float* scale;        // folded BatchNorm (nullable)
+  const float* shift;
+  float* out;                // [n_out][COUT]
+  float* psum;               // [groups][COUT] column sums of the stored values (nullable)
+  uint32_t in_rows, w_bytes;
+  int K, relu, cap_groups;
+  unsigned long long* trace = nullptr;   // measurement builds only (tools/split_trace.py): 12 u64 per wave task
+};
+
+__device__ static inline float sp_row16_sum(float v) {   // sum over the 16 lanes of a DPP row (= the 16 rows of a tile)
+  int x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));   // row_half_mirror
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
+// fp32 x 8 -> (hi, mid, lo) bf16 x 8, round to nearest even at every level (v_cvt_pk_bf16_f32): 44 VALU
+__device__ static inline void split8(const f32x4& a0, const f32x4& a1, bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
+  uint32_t h[4], m[4], l[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float x0 = p < 2 ? a0[2 * p] : a1[2 * p - 4], x1 = p < 2 ? a0[2 * p + 1] : a1[2 * p - 3];
+    const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){x0, x1}, bf16x2_t));
+    const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xFFFF0000u);
+    const uint32_t mp = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){r0, r1}, bf16x2_t));
+    const float s0 = r0 - __uint_as_float(mp << 16), s1 = r1 - __uint_as_float(mp & 0xFFFF0000u);
+    h[p] = hp;
+    m[p] = mp;
+    l[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){s0, s1}, bf16x2_t));
+  }
+  hi = __builtin_bit_cast(bf16x8_t, (uint4){h[0], h[1], h[2], h[3]});
+  mid = __builtin_bit_cast(bf16x8_t, (uint4){m[0], m[1], m[2], m[3]});
+  lo = __builtin_bit_cast(bf16x8_t, (uint4){l[0], l[1], l[2], l[3]});
+}
+
+template <int NSW, int NW>
+struct SplitGeom {
+  static constexpr int NS = NSW;                         // 32-column slices a workgroup owns
+  static constexpr int SLAB = NS * 6144;                 // bytes of W[k][cb][all columns], three parts
+  static constexpr int NPIECE = NS * 6;                  // 1 KB DMA pieces per slab
+  static constexpr int WPP = (NPIECE + NW - 1) / NW;     // pieces a wave issues per step (at most)
+  static constexpr int TBL_BYTES = 27 * 64;              // one group's table: 27 offsets x 16 slots
+  static constexpr int WAVE_LDS = 2048 + 2 * 2048;       // table (padded) + two ring slots of 16 x 128 B
+  static constexpr int WAVES_AT = 2 * SLAB;
+  static constexpr int LDS_BYTES = WAVES_AT + NW * WAVE_LDS;
+};
+
+// NSW: 32-column slices per workgroup (grid.y = COUT/32/NSW column parts).  Small maps (levels 3-4: a few hundred tasks, less
+// than one round of the chip) are a chain of K*CIN/32 dependent steps per task; giving every column part its own workgroup
+// shortens the step (fewer MFMAs, a smaller slab) and multiplies the workgroups in flight; the rows are then gathered once
+// per part, which small maps can afford.  Columns are independent: the results are bitwise the same for every NSW.
+template <int CIN, int COUT, int NW, int NSW, int TERMS, bool TRACE = false>
+__global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p) {
+  using GEO = SplitGeom<NSW, NW>;
+  constexpr int NS = NSW, NSTOT = COUT / 32, NCB = CIN / 32;
+  static_assert(NSTOT % NSW == 0, "column parts");
+  const int ns0 = blockIdx.y * NSW;                      // first column slice of this workgroup
+  constexpr int SLAB = GEO::SLAB, NPIECE = GEO::NPIECE, WPP = GEO::WPP;
+  static_assert(GEO::LDS_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(TERMS == 3 || TERMS == 6 || TERMS == 9, "terms");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  typedef __attribute__((address_space(3))) char lds_char;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int K = p.K;
+  char* const wl = smem + GEO::WAVES_AT + wave * GEO::WAVE_LDS;
+  int32_t* const tbl = reinterpret_cast<int32_t*>(wl);
+  char* const ring = wl + 2048;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)(lds_char*)smem;
+  const uint32_t wl_addr = (uint32_t)(uintptr_t)(lds_char*)wl;
+  // operand read addresses inside a gathered group image: chunks g4 and 4+g4 of row l15 (XOR swizzle on the chunk index)
+  const uint32_t rd0 = wl_addr + 2048 + (uint32_t)(l15 * 128 + ((g4 ^ (l15 & 7)) * 16));
+  const uint32_t rd1 = wl_addr + 2048 + (uint32_t)(l15 * 128 + (((4 + g4) ^ (l15 & 7)) * 16));
+  const uint32_t tb0 = wl_addr + (uint32_t)((lane >> 3) * 4);          // table entry of this lane's DMA rows (L>>3, 8+(L>>3))
+  const uint32_t wrd = smem_addr + (uint32_t)(lane * 16);              // fragment read address inside a slab piece
+  const int dma_chunk = ((lane & 7) ^ (lane >> 3)) * 16;
+  const int w_lane = lane * 16;
+
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), (short)(CIN * 4), (int)p.in_rows, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wsp), 0, (int)p.w_bytes, 0x00020000);
+
+  const int ngroups = __builtin_amdgcn_readfirstlane(min(p.meta[0], p.cap_groups));
+  const int ntask = (ngroups + NW - 1) / NW;
+  // contiguous eighth of the tasks per XCD (block b runs on XCD b % 8): a Z-order slice of the map per L2
+  const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3;
+  const int cpx = (ntask + 7) >> 3;
+
+  for (int lt = blockIdx.x >> 3; lt < cpx; lt += nper) {
+    const int tslot = xcd * cpx + lt;
+    if (tslot >= ntask) continue;                        // workgroup-uniform
+    const int task = (NW == 4 && p.order) ? __builtin_amdgcn_readfirstlane(p.order[tslot]) : tslot;   // longest tasks first
+    const int g0 = task * NW;
+    const int gw = g0 + wave;                            // this wave's group
+    unsigned long long tr[12] = {};
+    auto now = [] { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
+    if constexpr (TRACE) tr[0] = now();
+    // ---- masks: union over the workgroup (identical in every wave), own group
+    uint32_t mload = 0;
+    if (lane < NW && g0 + lane < ngroups) mload = p.gmask[g0 + lane];
+    uint32_t U = mload;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) U |= (uint32_t)__shfl_xor((int)U, o, 64);
+    U = __builtin_amdgcn_readfirstlane(U);
+    if (!(U >> 31)) continue;                            // nothing but padding groups
+    const uint32_t gm = (uint32_t)__builtin_amdgcn_readlane((int)mload, wave);
+    const bool live = (gm >> 31) != 0;
+
+    // ---- the group's neighbour table -> wave-private LDS (two 16-byte pieces per lane); output rows of the epilogue
+    int32_t orow = -1;
+    if (live) {
+      const int n16 = K * 4;
+      const int4* src = reinterpret_cast<const int4*>(p.snbr + (int64_t)gw * K * 16);
+      int4 v0 = make_int4(-1, -1, -1, -1), v1 = make_int4(-1, -1, -1, -1);
+      if (lane < n16) v0 = src[lane];
+      if (lane + 64 < n16) v1 = src[lane + 64];
+      orow = p.perm[(int64_t)gw * 16 + l15];
+      int4* dst = reinterpret_cast<int4*>(tbl);
+      dst[lane] = v0;
+      if (lane + 64 < 27 * 4) dst[lane + 64] = v1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    if constexpr (TRACE) tr[1] = now();
+    // ---- step generator (scalar, identical in every wave): set bits of the union x channel blocks
+    uint32_t mk = U & 0x07FFFFFFu;
+    const int n_steps = __popc(mk) * NCB;
+    int gen_k = 0, gen_cb = 0;
+    auto gen = [&](int& k, int& cb) {                      // k = 27: past the end
+      const bool need = (gen_cb == 0);
+      const bool take = need && (mk != 0);
+      const bool valid = !need || take;
+      gen_k = take ? __builtin_ctz(mk | 0x80000000u) : gen_k;
+      mk = take ? (mk & (mk - 1)) : mk;
+      k = valid ? gen_k : 27;
+      cb = gen_cb;
+      gen_cb = (valid && gen_cb + 1 < NCB) ? gen_cb + 1 : 0;
+    };
+    // this wave's share of the step's requests: its pieces of the slab, the rows of its group if it has the offset.
+    // Requests that would move nothing are NOT issued (a step costs a wave 0..WPP+2 vector-memory instructions): the
+    // texture path is the busiest unit of these kernels (profiles/r03c_pmc_wide.txt) and an out-of-range piece costs it
+    // as much as a real one.  Nothing is counted: the wave drains its queue (vmcnt(0)) before the step's barrier.
+    auto issue = [&](int slot, int k, int cb, int32_t i0, int32_t i1) {
+      if (k >= 27) return;
+      const int woff = ((k * NCB + cb) * NSTOT + ns0) * 6144;
+#pragma unroll
+      for (int q = 0; q < WPP; ++q) {
+        const int pc = wave + NW * q;
+        if (NPIECE % NW == 0 || pc < NPIECE)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_char*)(smem + slot * SLAB + pc * 1024), 16, w_lane, woff + pc * 1024, 0, 0);
+      }
+      if ((gm >> k) & 1u) {
+        __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(ring + slot * 2048), 16, i0, dma_chunk, cb * 128, 0, 0);
+        __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(ring + slot * 2048 + 1024), 16, i1, dma_chunk, cb * 128, 0, 0);
+      }
+    };
+    auto idx_read = [&](int k, int32_t& i0, int32_t& i1) {   // issued; awaited by the lgkmcnt(0) in front of the barrier
+      if (k < 27 && ((gm >> k) & 1u)) {
+        const uint32_t tb = tb0 + (uint32_t)(k * 64);
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:32" : "=&v"(i0), "=&v"(i1) : "v"(tb) : "memory");
+      }
+    };
+
+    f32x4 acc[NS][2];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) acc[ns][0] = acc[ns][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto wread = [&](uint32_t a, auto NSI, f32x4 (&w)[6]) {      // the six fragments of column slice NSI (issued)
+      constexpr int off = decltype(NSI)::value * 6144;
+      asm volatile(
+          "ds_read_b128 %0, %6 offset:%7\n\t"
+          "ds_read_b128 %1, %6 offset:%7+1024\n\t"
+          "ds_read_b128 %2, %6 offset:%7+2048\n\t"
+          "ds_read_b128 %3, %6 offset:%7+3072\n\t"
+          "ds_read_b128 %4, %6 offset:%7+4096\n\t"
+          "ds_read_b128 %5, %6 offset:%7+5120"
+          : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5])
+          : "v"(a), "n"(off)
+          : "memory");
+    };
+    auto wwait = [&](f32x4 (&w)[6]) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5])::"memory");
+    };
+    auto mfma = [](const f32x4& wf, const bf16x8_t& af, f32x4& c) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), af, c, 0, 0, 0);
+    };
+    // ---- one step of this wave's group: rows of ring slot x slab of the same slot
+    auto compute = [&](int slot) {
+      f32x4 ra0, ra1, w[6];
+      {
+        const uint32_t r0 = rd0 + (uint32_t)(slot * 2048), r1 = rd1 + (uint32_t)(slot * 2048);
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(ra0), "=&v"(ra1) : "v"(r0), "v"(r1) : "memory");
+      }
+      const uint32_t wa = wrd + (uint32_t)(slot * SLAB);
+      wread(wa, std::integral_constant<int, 0>{}, w);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1)::"memory");
+      wwait(w);
+      bf16x8_t ah, am, al;
+      split8(ra0, ra1, ah, am, al);
+      [&]<int... NSI>(std::integer_sequence<int, NSI...>) {
+        (([&] {
+           f32x4 wn[6];
+           if constexpr (NSI + 1 < NS) wread(wa, std::integral_constant<int, NSI + 1>{}, wn);
+           __builtin_amdgcn_sched_barrier(0);
+           // small terms first; w[2*part + nt]
+           if constexpr (TERMS >= 9) {
+             mfma(w[4], al, acc[NSI][0]); mfma(w[5], al, acc[NSI][1]);      // lo * lo
+             mfma(w[4], am, acc[NSI][0]); mfma(w[5], am, acc[NSI][1]);      // lo * mid
+             mfma(w[2], al, acc[NSI][0]); mfma(w[3], al, acc[NSI][1]);      // mid * lo
+           }
+           if constexpr (TERMS >= 6) {
+             mfma(w[4], ah, acc[NSI][0]); mfma(w[5], ah, acc[NSI][1]);      // w lo * a hi
+             mfma(w[0], al, acc[NSI][0]); mfma(w[1], al, acc[NSI][1]);      // w hi * a lo
+             mfma(w[2], am, acc[NSI][0]); mfma(w[3], am, acc[NSI][1]);      // mid * mid
+           }
+           mfma(w[2], ah, acc[NSI][0]); mfma(w[3], ah, acc[NSI][1]);        // w mid * a hi
+           mfma(w[0], am, acc[NSI][0]); mfma(w[1], am, acc[NSI][1]);        // w hi * a mid
+           mfma(w[0], ah, acc[NSI][0]); mfma(w[1], ah, acc[NSI][1]);        // hi * hi
+           __builtin_amdgcn_sched_barrier(0);
+           if constexpr (NSI + 1 < NS) {
+             wwait(wn);
+#pragma unroll
+             for (int i = 0; i < 6; ++i) w[i] = wn[i];
+           }
+         }()), ...);
+      }(std::make_integer_sequence<int, NS>{});
+    };
+
+    // ---- prologue: step 0 in flight, rows of step 1 looked up
+    int k0, cb0, k1, cb1;
+    int32_t i0 = -1, i1 = -1;
+    gen(k0, cb0);
+    idx_read(k0, i0, i1);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(i0), "+v"(i1)::"memory");
+    issue(0, k0, cb0, i0, i1);
+    gen(k1, cb1);
+    idx_read(k1, i0, i1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(i0), "+v"(i1)::"memory");
+    if constexpr (TRACE) tr[2] = now();
+    __builtin_amdgcn_s_barrier();
+    if constexpr (TRACE) tr[3] = now();
+    // ---- main loop: requests of step i+1, arithmetic of step i, drain, barrier
+    for (int i = 0; i < n_steps; ++i) {
+      const int slot = i & 1;
+      unsigned long long ta, tb, tc, td;
+      if constexpr (TRACE) ta = now();
+      issue(slot ^ 1, k1, cb1, i0, i1);
+      int k2, cb2;
+      gen(k2, cb2);
+      idx_read(k2, i0, i1);                              // (the DMA above has read its index registers at issue)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (TRACE) tb = now();
+      const bool has = ((gm >> k0) & 1u) != 0;
+      if (has) compute(slot);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (TRACE) tc = now();
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(i0), "+v"(i1)::"memory");
+      if constexpr (TRACE) td = now();
+      __builtin_amdgcn_s_barrier();
+      if constexpr (TRACE) {
+        tr[4] += tb - ta; tr[5] += tc - tb; tr[6] += td - tc; tr[7] += now() - td; tr[8] += has ? 1 : 0;
+      }
+      k0 = k1; k1 = k2; cb1 = cb2;
+    }
+    if constexpr (TRACE) tr[9] = now();
+
+    // ---- epilogue: BN scale/shift (+ReLU), one 16-byte store per tile; optional per-group column sums
+    if (live) {
+      const int32_t row = orow;
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        float sums[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int c0 = (ns0 + ns) * 32 + nt * 16 + 4 * g4;
+          f32x4 v = acc[ns][nt];
+          if (p.scale) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c0);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + c0);
+            v = v * sc + sh;
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+          }
+          if (row >= 0) *reinterpret_cast<f32x4*>(p.out + (int64_t)row * COUT + c0) = v;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sums[nt][u] = row >= 0 ? v[u] : 0.f;
+        }
+        if (p.psum) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sums[nt][u] = sp_row16_sum(sums[nt][u]);
+          if (l15 == 0) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              *reinterpret_cast<f32x4*>(p.psum + (int64_t)gw * COUT + (ns0 + ns) * 32 + nt * 16 + 4 * g4) =
+                  (f32x4){sums[nt][0], sums[nt][1], sums[nt][2], sums[nt][3]};
+          }
+        }
+      }
+    }
+    if constexpr (TRACE) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tr[10] = now();
+      tr[11] = (unsigned long long)n_steps;
+      if (lane == 0 && p.trace) {
+        unsigned long long* o = p.trace + (int64_t)gw * 12;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) o[q] = tr[q];
+      }
+    }
+    __builtin_amdgcn_s_barrier();                        // the next task rewrites tables and slabs
+  }
+}
+
+template <int CIN, int COUT, int NW, int NSW, int TERMS, bool TRACE = false>
+static int launch_split(const SplitArgs& a, int64_t groups_hint, hipStream_t stream) {
+  using GEO = SplitGeom<NSW, NW>;
+  static AttrOnce attr_done;
+  if (attr_done.need()) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_split_kernel<CIN, COUT, NW, NSW, TERMS, TRACE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done.mark();
+  }
+  const int64_t ntask = cdiv(groups_hint, NW);
+  int64_t gridx = std::min<int64_t>(std::max<int64_t>(ntask, 8), 1 << 20);
+  gridx = (gridx + 7) / 8 * 8;
+  const dim3 grid((unsigned)gridx, (unsigned)(COUT / 32 / NSW));
+  hipEvent_t* pev = prof_kernel_events();
+  if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
+    hipExtLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, NSW, TERMS, TRACE>), grid, dim3(NW * 64), GEO::LDS_BYTES, stream,
+                          pev[0], pev[1], 0, a);
+    pev[0] = pev[1] = nullptr;
+  } else {
+    hipLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, NSW, TERMS, TRACE>), grid, dim3(NW * 64), GEO::LDS_BYTES, stream, a);
+  }
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// ------------------------------------------------------------------ wave-wide variant (big launches)
+// What the lock-step kernel above measured (profiles/r03a_split_ab.json): it is slower than the exact fp32 kernel although
+// its matrix time is 0.19 x — the launches are latency chains, not throughput problems.  A task pays a fixed 5-7 us (mask ->
+// tables -> first gathers -> ... -> store drain), the barriers keep the waves of a workgroup in one phase, and the LDS rings
+// that grow with G leave 4-12 waves per CU.  Here, for launches with thousands of groups:
+//   * a WAVE is a workgroup: it owns G consecutive row groups and all output columns, no barrier anywhere;
+//   * the W fragments of a step (k, cb, 32-column slice) are loaded ONCE per wave into registers (six 1 KB lane-linear
+//     buffer loads, double buffered across slices and steps) and feed the MFMAs of all G groups: 6 KB per G group-steps
+//     instead of per group-step (the vector-memory path moves 64 B per clock and CU: at G = 1 the W fragments alone would
+//     take longer than the MFMAs);
+//   * the rows of step s+1 are gathered (LDS-DMA, full lines) while step s computes: a two-slot ring of G groups; the
+//     neighbour rows of step s+2 are fetched from the row-group table with plain loads, so the wave-private LDS is only the
+//     ring (G x 4 KB) and 8-13 waves fit a CU;
+//   * all counters are in-order: one counted s_waitcnt per step covers the ring slot, the compiler's own waits cover the
+//     W registers and the table entries.
+// Same arithmetic, same order per output row as the lock-step kernel => bitwise identical results.
+template <int CIN, int COUT, int G, int TERMS_>
+__global__ __launch_bounds__(64) void sconv_wide_kernel(const SplitArgs p) {
+  constexpr int NS = COUT / 32, NCB = CIN / 32;
+  constexpr int TERMS = TERMS_ % 100, ABL = TERMS_ / 100;   // ABL: measurement builds (1 no MFMA, 2 no gathers, 4 no W loads, 8 no split)
+  constexpr int WSLICE = 6144;                           // bytes of one (k, cb, 32-column slice): six fragments
+  static_assert(TERMS == 3 || TERMS == 6 || TERMS == 9, "terms");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];          // [2 slots][G][2048]
+  typedef __attribute__((address_space(3))) char lds_char;
+  const int lane = threadIdx.x & 63;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int K = p.K;
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)(lds_char*)smem;
+  const uint32_t rd0 = smem_addr + (uint32_t)(l15 * 128 + ((g4 ^ (l15 & 7)) * 16));
+  const uint32_t rd1 = smem_addr + (uint32_t)(l15 * 128 + (((4 + g4) ^ (l15 & 7)) * 16));
+  const int dma_chunk = ((lane & 7) ^ (lane >> 3)) * 16;
+  const int w_lane = lane * 16;
+
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), (short)(CIN * 4), (int)p.in_rows, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wsp), 0, (int)p.w_bytes, 0x00020000);
+
+  const int ngroups = __builtin_amdgcn_readfirstlane(min(p.meta[0], p.cap_groups));
+  const int ntask = (ngroups + G - 1) / G;
+  const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3;
+  const int cpx = (ntask + 7) >> 3;                      // contiguous eighth of the tasks per XCD
+
+  for (int lt = blockIdx.x >> 3; lt < cpx; lt += nper) {
+    const int task = xcd * cpx + lt;
+    if (task >= ntask) continue;
+    const int g0 = task * G;
+    uint32_t gm[G];
+    uint32_t U = 0;
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      gm[j] = (g0 + j < ngroups) ? p.gmask[g0 + j] : 0u;
+      gm[j] = __builtin_amdgcn_readfirstlane(gm[j]);
+      U |= gm[j];
+    }
+    if (!(U >> 31)) continue;
+    int32_t orow[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) orow[j] = (gm[j] >> 31) ? p.perm[(int64_t)(g0 + j) * 16 + l15] : -1;
+    // table rows of this lane's two DMA pieces: entry (L >> 3) and 8 + (L >> 3) of the 16 slots of (group, offset)
+    const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int32_t*>(p.snbr) + (int64_t)g0 * K * 16, 0, G * K * 64, 0x00020000);
+    const int t_lane = (lane >> 3) * 4;
+
+    // ---- step generator (scalar)
+    uint32_t mk = U & 0x07FFFFFFu;
+    const int n_steps = __popc(mk) * NCB;
+    int gen_k = 0, gen_cb = 0;
+    auto gen = [&](int& k, int& cb) {                     // k = 27: past the end
+      const bool need = (gen_cb == 0);
+      const bool take = need && (mk != 0);
+      const bool valid = !need || take;
+      gen_k = take ? __builtin_ctz(mk | 0x80000000u) : gen_k;
+      mk = take ? (mk & (mk - 1)) : mk;
+      k = valid ? gen_k : 27;
+      cb = gen_cb;
+      gen_cb = (valid && gen_cb + 1 < NCB) ? gen_cb + 1 : 0;
+    };
+    auto idx_load = [&](int k, int32_t (&i0)[G], int32_t (&i1)[G]) {       // table entries of a step (-1 for a step past the end)
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const bool live = k < 27 && ((gm[j] >> k) & 1u);                 // scalar; a group without the offset gathers nothing
+        const int so = live ? (j * K + k) * 64 : 0;
+        const int vo = live ? t_lane : (int)0x80000000u;                 // out of range: returns 0
+        const int32_t a = __builtin_amdgcn_raw_buffer_load_b32(t_rsrc, vo, so, 0);
+        const int32_t b = __builtin_amdgcn_raw_buffer_load_b32(t_rsrc, vo + 32, so, 0);
+        i0[j] = live ? a : -1;
+        i1[j] = live ? b : -1;
+      }
+    };
+    auto dma = [&](auto S, int cb, const int32_t (&i0)[G], const int32_t (&i1)[G]) {   // rows of a step -> ring slot S
+      constexpr int s = decltype(S)::value;
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int32_t r0 = (ABL & 2) ? -1 : i0[j], r1 = (ABL & 2) ? -1 : i1[j];
+        __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(smem + (s * G + j) * 2048), 16, r0, dma_chunk, cb * 128, 0, 0);
+        __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(smem + (s * G + j) * 2048 + 1024), 16, r1, dma_chunk, cb * 128, 0, 0);
+      }
+    };
+    auto wload = [&](int k, int cb, int ns, f32x4 (&w)[6]) {              // six fragments of slice ns of step (k, cb)
+      const bool valid = k < 27 && !(ABL & 4);
+      const int so = valid ? ((k * NCB + cb) * NS + ns) * WSLICE : 0;
+      const int vo = valid ? w_lane : (int)(0x80000000u | (uint32_t)w_lane);
+#pragma unroll
+      for (int f = 0; f < 6; ++f) w[f] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, vo + f * 1024, so, 0));
+    };
+    auto mfma = [](const f32x4& wf, const bf16x8_t& af, f32x4& c) {
+      if constexpr (ABL & 1) c += wf * __builtin_bit_cast(f32x4, af);
+      else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), af, c, 0, 0, 0);
+    };
+
+    f32x4 acc[G][NS][2];
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[j][ns][0] = acc[j][ns][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // step descriptors: 0 = computed now, 1 = rows in flight, 2 = table entries in flight.  Table entries and W fragments
+    // ping-pong between two register sets with static indices (a copy of a register that is still being loaded would wait
+    // for it): idx[q] holds the entries of a step of parity q, wb[b] the fragments of the block of parity b.
+    int k0, cb0, k1, cb1, k2, cb2;
+    int32_t ia[2][G], ib[2][G];
+    f32x4 wb[2][6];
+    // ---- prologue
+    gen(k0, cb0);
+    idx_load(k0, ia[0], ib[0]);
+    gen(k1, cb1);
+    idx_load(k1, ia[1], ib[1]);
+    dma(std::integral_constant<int, 0>{}, cb0, ia[0], ib[0]);
+    wload(k0, cb0, 0, wb[0]);
+
+    // one step: S = ring slot (= parity) of the rows computed now; for NS = 1 the W parity follows it, for even NS every
+    // step starts at parity 0
+    auto step = [&](auto S) {
+      constexpr int s = decltype(S)::value;
+      constexpr int pb0 = (NS % 2) ? s : 0;
+      // I1: table entries of the step after next; I2: rows of the next step into the other slot
+      gen(k2, cb2);
+      idx_load(k2, ia[s], ib[s]);
+      __builtin_amdgcn_sched_barrier(0);
+      dma(std::integral_constant<int, s ^ 1>{}, cb1, ia[s ^ 1], ib[s ^ 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      // rows of this step: everything older than the 2G + 2G requests just issued has landed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * G) : "memory");
+      bool has[G];
+      f32x4 ra0[G], ra1[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        has[j] = k0 < 27 && ((gm[j] >> k0) & 1u) != 0;
+        const uint32_t r0 = rd0 + (uint32_t)((s * G + j) * 2048), r1 = rd1 + (uint32_t)((s * G + j) * 2048);
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(ra0[j]), "=&v"(ra1[j]) : "v"(r0), "v"(r1) : "memory");
+      }
+      bf16x8_t ah[G], am[G], al[G];
+      [&]<int... NSI>(std::integer_sequence<int, NSI...>) {
+        (([&] {
+           constexpr int pb = (pb0 + NSI) & 1;
+           f32x4(&w)[6] = wb[pb];
+           if constexpr (NSI + 1 < NS) wload(k0, cb0, NSI + 1, wb[pb ^ 1]);
+           else wload(k1, cb1, 0, wb[pb ^ 1]);
+           __builtin_amdgcn_sched_barrier(0);
+           if constexpr (NSI == 0) {
+#pragma unroll
+             for (int j = 0; j < G; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0[j]), "+v"(ra1[j])::"memory");
+           }
+#pragma unroll
+           for (int j = 0; j < G; ++j) {
+             if (!has[j]) continue;                      // wave-uniform
+             if constexpr (NSI == 0) {
+               if constexpr (ABL & 8) { ah[j] = __builtin_bit_cast(bf16x8_t, ra0[j]); am[j] = __builtin_bit_cast(bf16x8_t, ra1[j]); al[j] = ah[j]; }
+               else split8(ra0[j], ra1[j], ah[j], am[j], al[j]);
+             }
+             if constexpr (TERMS >= 9) {
+               mfma(w[4], al[j], acc[j][NSI][0]); mfma(w[5], al[j], acc[j][NSI][1]);
+               mfma(w[4], am[j], acc[j][NSI][0]); mfma(w[5], am[j], acc[j][NSI][1]);
+               mfma(w[2], al[j], acc[j][NSI][0]); mfma(w[3], al[j], acc[j][NSI][1]);
+             }
+             if constexpr (TERMS >= 6) {
+               mfma(w[4], ah[j], acc[j][NSI][0]); mfma(w[5], ah[j], acc[j][NSI][1]);      // w lo * a hi
+               mfma(w[0], al[j], acc[j][NSI][0]); mfma(w[1], al[j], acc[j][NSI][1]);      // w hi * a lo
+               mfma(w[2], am[j], acc[j][NSI][0]); mfma(w[3], am[j], acc[j][NSI][1]);      // mid * mid
+             }
+             mfma(w[2], ah[j], acc[j][NSI][0]); mfma(w[3], ah[j], acc[j][NSI][1]);        // w mid * a hi
+             mfma(w[0], am[j], acc[j][NSI][0]); mfma(w[1], am[j], acc[j][NSI][1]);        // w hi * a mid
+             mfma(w[0], ah[j], acc[j][NSI][0]); mfma(w[1], ah[j], acc[j][NSI][1]);        // hi * hi
+           }
+           __builtin_amdgcn_sched_barrier(0);
+         }()), ...);
+      }(std::make_integer_sequence<int, NS>{});
+      k0 = k1; cb0 = cb1; k1 = k2; cb1 = cb2;
+    };
+    const int n_iter = (n_steps + 1) / 2;
+    for (int it = 0; it < n_iter; ++it) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // requests past the end
+
+    // ---- epilogue
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      if (!(gm[j] >> 31)) continue;
+      const int32_t row = orow[j];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        float sums[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int c0 = ns * 32 + nt * 16 + 4 * g4;
+          f32x4 v = acc[j][ns][nt];
+          if (p.scale) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c0);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + c0);
+            v = v * sc + sh;
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+          }
+          if (row >= 0) *reinterpret_cast<f32x4*>(p.out + (int64_t)row * COUT + c0) = v;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sums[nt][u] = row >= 0 ? v[u] : 0.f;
+        }
+        if (p.psum) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sums[nt][u] = sp_row16_sum(sums[nt][u]);
+          if (l15 == 0) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              *reinterpret_cast<f32x4*>(p.psum + (int64_t)(g0 + j) * COUT + ns * 32 + nt * 16 + 4 * g4) =
+                  (f32x4){sums[nt][0], sums[nt][1], sums[nt][2], sums[nt][3]};
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int CIN, int COUT, int G, int TERMS>
+static int launch_wide(const SplitArgs& a, int64_t groups_hint, hipStream_t stream) {
+  const size_t lds = 2 * G * 2048;
+  const int64_t ntask = cdiv(groups_hint, G);
+  int64_t grid = std::min<int64_t>(std::max<int64_t>(ntask, 8), 1 << 20);
+  grid = (grid + 7) / 8 * 8;
+  hipEvent_t* pev = prof_kernel_events();
+  if (pev[0]) {
+    hipExtLaunchKernelGGL((sconv_wide_kernel<CIN, COUT, G, TERMS>), dim3((unsigned)grid), dim3(64), lds, stream, pev[0], pev[1], 0, a);
+    pev[0] = pev[1] = nullptr;
+  } else {
+    hipLaunchKernelGGL((sconv_wide_kernel<CIN, COUT, G, TERMS>), dim3((unsigned)grid), dim3(64), lds, stream, a);
+  }
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
+// exactly the channel plans EGONN_SP_PLAN instantiates below (the forward plans of the trunk and heads + the two
+// input-gradient plans); every other pair stays on the exact kernels of sconv.hip
+bool sconv_split_supported(int cin, int cout) {
+  static const int plans[][2] = {{32, 32}, {32, 64}, {64, 64}, {64, 128}, {128, 128}, {64, 32}, {128, 64}};
+  for (const auto& p : plans)
+    if (p[0] == cin && p[1] == cout) return true;
+  return false;
+}
+
+// cfg = terms_sel * 1000 + G * 100 + NW * 10 + DA (terms_sel 0: 6 terms, 1: 3, 2: 9); 0 = product choice
+int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
+                        int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
+                        int cfg) {
+  EGONN_REQUIRE(rg.built, EGONN_ERR_STATE, "sconv: row-group tables not built");
+  EGONN_REQUIRE(sconv_split_supported(cin, cout), EGONN_ERR_INVALID, "sconv(split): channel plan %d->%d not supported", cin, cout);
+  EGONN_REQUIRE((uint64_t)n_in_cap * cin * 4 < (1ull << 32) - (1ull << 20), EGONN_ERR_INVALID,
+                "sconv: input feature map of %lld rows exceeds the 4 GiB buffer-resource range", (long long)n_in_cap);
+  if (groups_hint <= 0) return EGONN_OK;
+  SplitArgs a;
+  a.in = in; a.snbr = rg.snbr; a.gmask = rg.gmask; a.perm = rg.perm; a.meta = rg.meta; a.Wsp = Wsp;
+  static const bool no_order = getenv("EGONN_NO_TASK_ORDER") != nullptr;   // (measurement switch)
+  a.order = no_order ? nullptr : rg.order4;
+  a.scale = scale; a.shift = shift; a.out = out; a.psum = psum;
+  a.in_rows = (uint32_t)n_in_cap;
+  a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * 6);
+  a.K = rg.K; a.relu = relu ? 1 : 0; a.cap_groups = rg.cap_groups;
+  if (cfg == 0) cfg = sconv_split_default_cfg(cin, cout, groups_hint);
+  const int terms = cfg / 1000;
+  int shape = cfg % 1000;
+  // lock-step kernel: shape = 100 + NW * 10 + 2 [+ 400 * log2(column parts): 0 = automatic]
+  int parts_sel = 0;
+  if (shape >= 500) { parts_sel = shape / 400; shape -= 400 * parts_sel; }
+  const int ns_tot = cout / 32;
+  int parts = 1;
+  if (parts_sel > 0) parts = std::min(ns_tot, 1 << (parts_sel - 1));
+  else if (ns_tot >= 2 && cdiv(groups_hint, 4) < 700) {  // less than one round of the chip: two column parts per task
+    parts = 2;                                           // (measured, profiles/r03i_colparts.txt: L4 128->128 101 / 80 / 93 us
+  }                                                      //  with 1 / 2 / 4 parts, 64->128 56 / 45 / 51, L3 64->64 43 / 41)
+  const int nsw = ns_tot / parts;
+#define EGONN_SP_LOCK1(CI, CO, NWW, NSWW)                                                                 \
+  if (cin == CI && cout == CO && shape == 100 + NWW * 10 + 2 && nsw == NSWW) {                            \
+    if (terms == 0) return launch_split<CI, CO, NWW, NSWW, 6>(a, groups_hint, stream);                    \
+  }
+#define EGONN_SP_LOCK(CI, CO, NWW)                                                                        \
+  EGONN_SP_LOCK1(CI, CO, NWW, (CO / 32))                                                                  \
+  if constexpr (CO >= 64) { EGONN_SP_LOCK1(CI, CO, NWW, (CO / 64)) }                                      \
+  if constexpr (CO >= 128) { EGONN_SP_LOCK1(CI, CO, NWW, (CO / 128)) }
+#define EGONN_SP_LOCK_TRACE(CI, CO, NWW)                                                                  \
+  if (cin == CI && cout == CO && shape == 100 + NWW * 10 + 2 && terms == 9) {                             \
+    a.trace = g_sconv_trace;                                                                              \
+    return launch_split<CI, CO, NWW, (CO / 32), 6, true>(a, groups_hint, stream);                         \
+  }
+  EGONN_SP_LOCK_TRACE(32, 32, 4) EGONN_SP_LOCK_TRACE(32, 32, 8) EGONN_SP_LOCK_TRACE(64, 64, 4)
+#define EGONN_SP_WIDE(CI, CO, GG)                                                                         \
+  if (cin == CI && cout == CO && shape == GG * 100) {                                                     \
+    if (terms == 0) return launch_wide<CI, CO, GG, 6>(a, groups_hint, stream);                            \
+  }
+#define EGONN_SP_WIDE_TERMS(CI, CO, GG)                                                                   \
+  if (cin == CI && cout == CO && shape == GG * 100) {                                                     \
+    if (terms == 1) return launch_wide<CI, CO, GG, 3>(a, groups_hint, stream);                            \
+    if (terms == 2) return launch_wide<CI, CO, GG, 9>(a, groups_hint, stream);                            \
+  }
+  EGONN_SP_WIDE(32, 32, 1) EGONN_SP_WIDE(32, 32, 2) EGONN_SP_WIDE(32, 32, 4) EGONN_SP_WIDE(32, 32, 8)
+  EGONN_SP_WIDE(32, 64, 1) EGONN_SP_WIDE(32, 64, 2) EGONN_SP_WIDE(32, 64, 4)
+  EGONN_SP_WIDE(64, 64, 1) EGONN_SP_WIDE(64, 64, 2) EGONN_SP_WIDE(64, 64, 4)
+  EGONN_SP_WIDE(64, 128, 1) EGONN_SP_WIDE(64, 128, 2)
+  EGONN_SP_WIDE(128, 128, 1) EGONN_SP_WIDE(128, 128, 2)
+  EGONN_SP_WIDE_TERMS(32, 32, 4) EGONN_SP_WIDE_TERMS(64, 64, 2)
+#define EGONN_SP_WIDE_ABL(CI, CO, GG)                                                                     \
+  if (cin == CI && cout == CO && shape == GG * 100) {                                                     \
+    if (terms == 3) return launch_wide<CI, CO, GG, 106>(a, groups_hint, stream);                          \
+    if (terms == 4) return launch_wide<CI, CO, GG, 206>(a, groups_hint, stream);                          \
+    if (terms == 5) return launch_wide<CI, CO, GG, 406>(a, groups_hint, stream);                          \
+    if (terms == 6) return launch_wide<CI, CO, GG, 706>(a, groups_hint, stream);                          \
+    if (terms == 7) return launch_wide<CI, CO, GG, 806>(a, groups_hint, stream);                          \
+    if (terms == 8) return launch_wide<CI, CO, GG, 1506>(a, groups_hint, stream);                         \
+  }
+  EGONN_SP_WIDE_ABL(32, 32, 2) EGONN_SP_WIDE_ABL(64, 64, 2)
+#define EGONN_SP_PLAN(CI, CO) EGONN_SP_LOCK(CI, CO, 8) EGONN_SP_LOCK(CI, CO, 4)
+  EGONN_SP_PLAN(32, 32)
+  EGONN_SP_PLAN(32, 64)
+  EGONN_SP_PLAN(64, 64)
+  EGONN_SP_PLAN(64, 128)
+  EGONN_SP_PLAN(128, 128)
+  EGONN_SP_PLAN(64, 32)
+  EGONN_SP_PLAN(128, 64)
+#undef EGONN_SP_PLAN
+#undef EGONN_SP_LOCK
+#undef EGONN_SP_LOCK1
+#undef EGONN_SP_WIDE
+#undef EGONN_SP_WIDE_TERMS
+#undef EGONN_SP_WIDE_ABL
+  set_error("sconv(split): no instantiation for %d->%d cfg %d", cin, cout, cfg);
+  return EGONN_ERR_INVALID;
+}
+
+int sconv_split_default_cfg(int cin, int cout, int64_t groups_hint) {
+  (void)cin; (void)cout; (void)groups_hint;
+  static const int env_cfg = [] {                        // EGONN_SPLIT_CFG: measurement override
+    const char* e = getenv("EGONN_SPLIT_CFG");
+    return e ? atoi(e) : 0;
+  }();
+  return env_cfg ? env_cfg : 142;                        // lock-step kernel, workgroups of 4 waves
+}
+
+}  // namespace egonn
