@@ -441,7 +441,7 @@ class Context:
         a = _dev_f32(a, self.device)
         n, c = a.shape
         out = torch.empty((2, c), dtype=torch.float32, device=self.device)
-        sc = self.scratch(2 * c * (n // 512 + 2))
+        sc = self.scratch(2 * c * max(1024, n // 512 + 2))
         self._call(self.lib.egonn_col_stats, mode, a.data_ptr(), _ptr(b), _ptr(mask), _ptr(mean), n, c, out.data_ptr(),
                    sc.data_ptr(), sc.numel())
         return out

@@ -138,6 +138,9 @@ __global__ void points_to_keys_kernel(const float* __restrict__ pts, int64_t n_c
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nn = scan_off[B];
   if (i == 0 && nn > n_cap) atomicOr(flags, 2);         // more points than the plan was reserved for
+  // the segmented sort moves only rows inside [off[b], off[b+1]): offsets that do not start at 0 or that decrease would leave
+  // rows unsorted (stale buffer contents) -> reported as a range error (egonn_voxelize raises, egonn_plan_status for reserved plans)
+  if (i <= B && ((i == 0 && scan_off[0] != 0) || (i > 0 && scan_off[i] < scan_off[i - 1]))) atomicOr(flags, 1);
   if (i >= (nn < n_cap ? nn : n_cap)) return;
   // sample index = last b with scan_off[b] <= i
   int lo = 0, hi = B;   // invariant: scan_off[lo] <= i < scan_off[hi]

@@ -48,6 +48,7 @@ struct TailArgs {
   float *y[3], *t1[3], *t2[3], *x[3];   // per level 5..7: strided conv, conv1, conv2 outputs, block output
   float *g7, *g6, *g5, *gh, *out_global;
   const uint16_t *w_k2[3], *w_c1[3], *w_c2[3], *w_1x1[3], *w_t[2], *w_m0, *w_m1;   // pack_tail_weights
+  const float* w_inv;                   // [17 stages][4]: [0] = 1 / weight scale of the stage's kernels (pack_tail_weights trailer)
   const float *bn_s[3], *bn_h[3], *n1_s[3], *n1_h[3], *n2_s[3], *n2_h[3], *eca_w[3], *b0, *b1, *gem_p;
   int eca_k[3];
   float* sums;                          // [B][128] per-scan column sums of conv2 (ECA pooling)
@@ -55,7 +56,8 @@ struct TailArgs {
   int32_t* err;                         // the plan's flag word (bit 2: a cluster wait timed out)
   unsigned long long* trace;            // measurement hook (egonn_debug_set_trace): [blocks][17 stages][8] stamps; null = off
 };
-int pack_tail_weights(const float* W, int K, int cin, int cout, int out_in, void* out, hipStream_t stream);
+int tail_weights_absmax(const float* W, int64_t n, void* trailer, hipStream_t stream);
+int pack_tail_weights(const float* W, int K, int cin, int cout, int out_in, void* out, void* trailer, hipStream_t stream);
 int tail_forward(const TailArgs& a, hipStream_t stream);
 static constexpr size_t SCONV_SCRATCH_FLOATS = (size_t)2 << 20;   // 8 MB: one packed kernel (27 x 256 x 256 fp32 = 7 MB)
 // conv.hip -------------------------------------------------------------------------------------

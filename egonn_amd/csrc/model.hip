@@ -81,6 +81,7 @@ struct egonn_model {
   uint16_t* tail_packed = nullptr;
   size_t tail_cap = 0;
   const uint16_t *t_k2[8] = {}, *t_c1[8] = {}, *t_c2[8] = {}, *t_1x1[8] = {}, *t_gt[8] = {}, *t_m0 = nullptr, *t_m1 = nullptr;
+  const float* t_inv = nullptr;      // [17][4] per-stage 1 / weight scale (behind the packed kernels)
 };
 
 // ------------------------------------------------------------------------------------------ lifecycle
@@ -698,28 +699,43 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
     const size_t need_t = (3 * 8 + 6 * 27 + 3 + 2 * 8) * c2 + (size_t)m->gdec.mid * GLOBAL_CH + (size_t)GLOBAL_DIM * m->gdec.mid;
     if (m->tail_cap < need_t) {
       if (m->tail_packed) HIP_CHECK(hipFree(m->tail_packed));
-      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->tail_packed), need_t * 3 * sizeof(uint16_t)));
+      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->tail_packed), need_t * 2 * sizeof(uint16_t) + 17 * 16));
       m->tail_cap = need_t;
     }
     uint16_t* tc = m->tail_packed;
-    auto packt = [&](const float* w, int K, int ci, int co, int out_in, const uint16_t** dst) -> int {
-      EGONN_TRY(pack_tail_weights(w, K, ci, co, out_in, tc, st));
-      *dst = tc;
-      tc += (size_t)K * ci * co * 3;
+    // one weight scale per STAGE of the tail kernel (tail.hip tl_decode: stage s accumulates its kernels into the same registers)
+    uint32_t* trailers = reinterpret_cast<uint32_t*>(m->tail_packed + need_t * 2);
+    m->t_inv = reinterpret_cast<const float*>(trailers);
+    HIP_CHECK(hipMemsetAsync(trailers, 0, 17 * 16, st));
+    auto packg = [&](int stage, const float* w0, int K0, int ci0, int co0, int out_in, const uint16_t** d0,
+                     const float* w1, int K1, const uint16_t** d1) -> int {
+      uint32_t* tr = trailers + 4 * stage;
+      EGONN_TRY(tail_weights_absmax(w0, (int64_t)K0 * ci0 * co0, tr, st));
+      if (w1) EGONN_TRY(tail_weights_absmax(w1, (int64_t)K1 * ci0 * co0, tr, st));
+      EGONN_TRY(pack_tail_weights(w0, K0, ci0, co0, out_in, tc, tr, st));
+      *d0 = tc;
+      tc += (size_t)K0 * ci0 * co0 * 2;
+      if (w1) {
+        EGONN_TRY(pack_tail_weights(w1, K1, ci0, co0, 0, tc, tr, st));
+        *d1 = tc;
+        tc += (size_t)K1 * ci0 * co0 * 2;
+      }
       return EGONN_OK;
     };
     for (int i = 5; i <= 7; ++i) {
       const BlockRef& b = m->blk[i];
       EGONN_REQUIRE(b.cin == GLOBAL_CH && b.cout == GLOBAL_CH && !b.down, EGONN_ERR_STATE, "model: levels 5-7 are 128-channel blocks");
-      EGONN_TRY(packt(m->convs[i], 8, 128, 128, 0, &m->t_k2[i]));
-      EGONN_TRY(packt(b.conv1, 27, 128, 128, 0, &m->t_c1[i]));
-      EGONN_TRY(packt(b.conv2, 27, 128, 128, 0, &m->t_c2[i]));
-      EGONN_TRY(packt(m->g1x1[i], 1, 128, GLOBAL_CH, 0, &m->t_1x1[i]));
+      const int s0 = 4 * (i - 5);
+      EGONN_TRY(packg(s0 + 0, m->convs[i], 8, 128, 128, 0, &m->t_k2[i], nullptr, 0, nullptr));
+      EGONN_TRY(packg(s0 + 1, b.conv1, 27, 128, 128, 0, &m->t_c1[i], nullptr, 0, nullptr));
+      EGONN_TRY(packg(s0 + 2, b.conv2, 27, 128, 128, 0, &m->t_c2[i], nullptr, 0, nullptr));
     }
-    EGONN_TRY(packt(m->gt[6], 8, GLOBAL_CH, GLOBAL_CH, 0, &m->t_gt[6]));
-    EGONN_TRY(packt(m->gt[7], 8, GLOBAL_CH, GLOBAL_CH, 0, &m->t_gt[7]));
-    EGONN_TRY(packt(m->gdec.w0, 1, GLOBAL_CH, m->gdec.mid, 1, &m->t_m0));
-    EGONN_TRY(packt(m->gdec.w1, 1, m->gdec.mid, GLOBAL_DIM, 1, &m->t_m1));
+    // head: g7 = x7 @ W1x1[7];  g6 = x6 @ W1x1[6] + tconv7(g7);  g5 = x5 @ W1x1[5] + tconv6(g6);  decoder Linear layers
+    EGONN_TRY(packg(12, m->g1x1[7], 1, 128, GLOBAL_CH, 0, &m->t_1x1[7], nullptr, 0, nullptr));
+    EGONN_TRY(packg(13, m->g1x1[6], 1, 128, GLOBAL_CH, 0, &m->t_1x1[6], m->gt[7], 8, &m->t_gt[7]));
+    EGONN_TRY(packg(14, m->g1x1[5], 1, 128, GLOBAL_CH, 0, &m->t_1x1[5], m->gt[6], 8, &m->t_gt[6]));
+    EGONN_TRY(packg(15, m->gdec.w0, 1, GLOBAL_CH, m->gdec.mid, 1, &m->t_m0, nullptr, 0, nullptr));
+    EGONN_TRY(packg(16, m->gdec.w1, 1, m->gdec.mid, GLOBAL_DIM, 1, &m->t_m1, nullptr, 0, nullptr));
   }
   if (!m->conv0_unit) HIP_CHECK(hipMalloc(&m->conv0_unit, 2 * 4 * 3 * 64 * 16));
   EGONN_TRY(conv0_pack_unit(m->conv0, m->conv0_unit, st));
@@ -902,6 +918,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
         ta.out_global = out_global;
       }
       ta.sums = c->tail_sums; ta.flags = c->tail_flags; ta.err = c->dev_flags;
+      ta.w_inv = m->t_inv;
       ta.trace = g_sconv_trace;
       {
         ProfScope ps(c, st, "tail_kernel<128,128>/L5-7+head", PK_TAIL, 5, 27, 128, 128, 4);
@@ -1196,6 +1213,14 @@ API int egonn_conv_backward_weight(egonn_ctx* c, int level_in, int level_out, in
     return conv0_wgrad(c, in, grad_out, grad_kernel, scratch, (size_t)scratch_floats, st);   // in == NULL: all ones
   }
   EGONN_REQUIRE(in, EGONN_ERR_INVALID, "conv_backward_weight: null input");
+  // the MFMA channel plans take their (input row, output row) pairs from the row-group form of the map: built here if no forward
+  // call did it before, so that the pair source — and with it the fp32 summation order — never depends on the call history
+  if ((ks == 3 || ks == 2) && ((cin == 32 && (cout == 32 || cout == 64)) || (cin == 64 && (cout == 64 || cout == 128)) ||
+                               (cin == 128 && cout == 128))) {
+    const int kind = ks == 3 ? 0 : (transposed ? 2 : 1);
+    if (level_out >= (kind == 2 ? 0 : 1) && level_out < EGONN_NUM_LEVELS - (kind == 2 ? 1 : 0))
+      EGONN_TRY(ensure_rowgroups(c, &kind, &level_out, 1, st));
+  }
   if (ks == 1) {
     EGONN_REQUIRE(level_in == level_out && !transposed, EGONN_ERR_INVALID, "1x1 conv cannot change the level");
     return conv_wgrad(in, grad_out, nullptr, P.lv[level_in].n, 1, cin, cout, grad_kernel, scratch, (size_t)scratch_floats, st);

@@ -16,11 +16,12 @@
 //     so (observed placement, block b on XCD b % 8) XCD g streams only the eighth of every kernel that belongs to column tile g:
 //     2.3 MB per XCD over the whole tail, L2-resident, shared by the 16 scans of the batch.  Placement is a speed matter only.
 //   * a stage = out[rows][16g..] = act((sum_ops sum_k in[nbr[row][k]] @ W[k][:, 16g..]) * scale + shift).  The scan's input rows
-//     are split ONCE per workgroup into bf16 hi / mid / lo planes in LDS (the exact three-way split of sconv_split.hip: fp32 x
-//     fp32 = six bf16 MFMA products, fp32 accumulate), in rounds of (<= 406 rows) x (32 / 64 / 128 channels) that fit 3 x 32 KB;
+//     are split ONCE per workgroup into fp16 hi / lo planes in LDS (the two-way split of sconv_split.hip: fp32 x fp32 = three
+//     fp16 MFMA products, fp32 accumulate; weights pre-scaled by a power of two per stage), in rounds of (<= 613 rows) x
+//     (32 / 64 / 128 channels) that fit 2 x 48 KB;
 //     the 8 waves split the K * channel-block ITEMS of a round among themselves (item i -> wave i % 8): every W fragment enters
-//     the CU exactly once, straight into registers (3 x 1 KB per item and wave, prefetched one item ahead), and a wave walks
-//     the <= 16 row tiles of the window for its item (row fragments: 3 x ds_read_b128 per tile, 6 MFMAs).  No barrier inside a round.
+//     the CU exactly once (2 x 1 KB per item and wave by LDS-DMA into the wave's ring, one item group ahead), and a wave walks
+//     the <= 16 row tiles of the window for its item (row fragments: 2 x ds_read_b128 per tile, 3 MFMAs).  No barrier inside a round.
 //   * the 8 partial accumulators of a tile are summed by a fixed three-round exchange tree through LDS that leaves two finished
 //     tiles in every wave (all waves run the epilogue): BN scale/shift or bias, ReLU, 16-byte stores, per-column sums (ECA
 //     pooling, layers/eca_block.py:21-36) or the GeM / MAC / SPoC reduction of the descriptor.
@@ -46,59 +47,88 @@ namespace egonn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef short bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
 static constexpr int TL_THREADS = 512, TL_WAVES = 8;
-static constexpr int TL_PLANE = 27136;                       // bytes of one bf16 plane (2 * TL_PLANE < 65536: ds offsets)
-static constexpr int TL_OFF_W = 3 * TL_PLANE;                // W ring: [8 waves][2 slots][3 parts][1 KB], filled by LDS-DMA
-static constexpr int TL_OFF_TBL = TL_OFF_W + TL_WAVES * 2 * 3072;   // [K][16 slots][16 tiles] int32 input rows of the window
-static constexpr int TL_TBL_BYTES = 27 * 16 * 16 * 4;
+static constexpr int TL_PLANE = 49152;                       // bytes of one fp16 plane (hi | lo; TL_PLANE < 65536: ds offsets)
+static constexpr int TL_OFF_W = 2 * TL_PLANE;                // W ring: [8 waves][2 slots][2 parts][1 KB], filled by LDS-DMA
+static constexpr int TL_OFF_TBL = TL_OFF_W + TL_WAVES * 2 * 2048;   // [K][16 slots][16 tiles] u16: input row of the window's (tile, offset, slot)
+                                                                    // relative to the scan's first row at the input level, 0xFFFF = absent
+static constexpr int TL_TBL_ROW = 48;                        // bytes of one (offset, slot) row of the staged table: 16 tiles x u16 + 16
+                                                             // (12-dword stride: the 16 rows a b128 lane group reads hit disjoint banks;
+                                                             // int32 entries at a 64-byte stride were a 4-way conflict, 64 of the ~170
+                                                             // LDS cycles of an item)
+static constexpr int TL_TBL_BYTES = 27 * 16 * TL_TBL_ROW;
 static constexpr int TL_OFF_PERM = TL_OFF_TBL + TL_TBL_BYTES;   // [16 tiles][16] output rows
 static constexpr int TL_OFF_MISC = TL_OFF_PERM + 1024;          // column sums [8 waves][16], pooled [16], gate [16], scratch
-static constexpr int TL_LDS = TL_OFF_MISC + 1024;               // 160 256 bytes: one workgroup per CU
+static constexpr int TL_LDS = TL_OFF_MISC + 1024;               // 160 768 bytes: one workgroup per CU
 static constexpr int TL_SC1 = 16;                            // buffer aux bits: sc1 (write-through store / L1-bypassing load)
-// rows a round can stage (+ one all-zero row) per channels-per-round: (27136 / (2 * ch + 16)) - 1
-static constexpr int TL_CAP128 = 98, TL_CAP64 = 187, TL_CAP32 = 338;
+// rows a round can stage (+ one all-zero row) per channels-per-round: (49152 / (2 * ch + 16)) - 1
+static constexpr int TL_CAP128 = 179, TL_CAP64 = 340, TL_CAP32 = 613;
+static constexpr int TL_RU = 6;                              // staging units (8 channels of a row) per thread and round
+static_assert((TL_CAP128 + 1) * 16 <= TL_RU * TL_THREADS && (TL_CAP64 + 1) * 8 <= TL_RU * TL_THREADS && (TL_CAP32 + 1) * 4 <= TL_RU * TL_THREADS, "staging loop covers a round");
+static_assert((TL_CAP128 + 1) * (2 * 128 + 16) <= TL_PLANE && (TL_CAP64 + 1) * (2 * 64 + 16) <= TL_PLANE && (TL_CAP32 + 1) * (2 * 32 + 16) <= TL_PLANE, "plane");
+static_assert(TL_WAVES * 8 * 64 * 16 <= 2 * TL_PLANE, "the reduction tree reuses the planes");
 static_assert(TL_LDS <= 160 * 1024, "LDS budget");
 
-static __device__ inline uint32_t tl_bf16_rn_bits(float a) {
-  uint32_t u = __float_as_uint(a);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
-
 // ------------------------------------------------------------------ weight packing
-// W [K][cin][cout] (ME kernel layout; out_in: nn.Linear [cout][cin], K = 1) -> [ct][k][cb][part][lane][e] bf16,
-//   = part( W[k][32 cb + 8 (lane >> 4) + e][16 ct + (lane & 15)] ),  part 0 hi, 1 mid, 2 lo (round to nearest even at every level)
-// The slice of column tile ct is one contiguous block of K * cin/32 * 3 KB; every 1 KB piece is one lane-linear MFMA operand.
-__global__ void pack_tail_weights_kernel(const float* __restrict__ W, int K, int cin, int cout, int out_in,
-                                         uint16_t* __restrict__ out) {
+// fp32 x fp32 on the fp16 matrix pipe as in sconv_split.hip: x = hi + lo (fp16, round to nearest) leaves 2^-22 |x|; a*w = ah*wh +
+// ah*wl + al*wh (three v_mfma_f32_16x16x32_f16, fp32 accumulate).  Weights are scaled by a power of two s per SCALE GROUP (the
+// kernels one stage accumulates into the same registers: max |W| -> [2^13, 2^14)) so that their low parts stay normal fp16 numbers;
+// 1/s is applied exactly in the stage's epilogue.
+// W [K][cin][cout] (ME kernel layout; out_in: nn.Linear [cout][cin], K = 1) -> [ct][k][cb][part][lane][e] fp16,
+//   = part( s * W[k][32 cb + 8 (lane >> 4) + e][16 ct + (lane & 15)] ),  part 0 hi, 1 lo
+// The slice of column tile ct is one contiguous block of K * cin/32 * 2 KB; every 1 KB piece is one lane-linear MFMA operand.
+// trailer (4 words per scale group): [0] float 1/s, [1] bits of max |W| over the group.
+__global__ void tail_absmax_kernel(const float* __restrict__ W, int64_t n, uint32_t* __restrict__ trailer) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)K * cin * cout * 3) return;
+  float m = 0.f;
+  for (int64_t i = t; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = fabsf(W[i]);
+    m = (v == v && v < INFINITY) ? fmaxf(m, v) : m;       // NaN / Inf weights do not pick the scale
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(trailer + 1, __float_as_uint(m));
+}
+static __device__ inline float tl_scale_of(uint32_t maxbits) {          // power of two s with s * max in [2^13, 2^14)
+  const int e = (int)(maxbits >> 23) - 127;
+  const int se = min(max(13 - e, -100), 100);
+  return __uint_as_float((uint32_t)(se + 127) << 23);
+}
+__global__ void pack_tail_weights_kernel(const float* __restrict__ W, int K, int cin, int cout, int out_in,
+                                         uint16_t* __restrict__ out, uint32_t* __restrict__ trailer) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float sc = tl_scale_of(trailer[1]);
+  if (t == 0) reinterpret_cast<float*>(trailer)[0] = 1.f / sc;
+  if (t >= (int64_t)K * cin * cout * 2) return;
   const int ncb = cin / 32;
   int64_t r = t;
   const int e = (int)(r & 7); r >>= 3;
   const int lane = (int)(r & 63); r >>= 6;
-  const int part = (int)(r % 3); r /= 3;
+  const int part = (int)(r & 1); r >>= 1;
   const int cb = (int)(r % ncb); r /= ncb;
   const int k = (int)(r % K); r /= K;
   const int ct = (int)r;
   const int ci = 32 * cb + 8 * (lane >> 4) + e, co = 16 * ct + (lane & 15);
-  const float v = out_in ? W[(int64_t)co * cin + ci] : W[((int64_t)k * cin + ci) * cout + co];
-  const uint32_t hi = tl_bf16_rn_bits(v);
-  const float r1 = v - __uint_as_float(hi << 16);
-  const uint32_t mid = tl_bf16_rn_bits(r1);
-  const float r2 = r1 - __uint_as_float(mid << 16);
-  const uint32_t lo = tl_bf16_rn_bits(r2);
-  out[t] = (uint16_t)(part == 0 ? hi : (part == 1 ? mid : lo));
+  const float v = sc * (out_in ? W[(int64_t)co * cin + ci] : W[((int64_t)k * cin + ci) * cout + co]);
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  out[t] = __builtin_bit_cast(uint16_t, part == 0 ? hi : lo);
 }
 
-int pack_tail_weights(const float* W, int K, int cin, int cout, int out_in, void* out, hipStream_t stream) {
+int tail_weights_absmax(const float* W, int64_t n, void* trailer, hipStream_t stream) {
+  hipLaunchKernelGGL(tail_absmax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 256)), dim3(256), 0, stream, W, n,
+                     reinterpret_cast<uint32_t*>(trailer));
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+int pack_tail_weights(const float* W, int K, int cin, int cout, int out_in, void* out, void* trailer, hipStream_t stream) {
   EGONN_REQUIRE(cin % 32 == 0 && cout % 16 == 0 && (!out_in || K == 1), EGONN_ERR_INVALID, "tail: channel plan %d->%d", cin, cout);
-  const int64_t n = (int64_t)K * cin * cout * 3;
+  const int64_t n = (int64_t)K * cin * cout * 2;
   hipLaunchKernelGGL(pack_tail_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, W, K, cin, cout, out_in,
-                     reinterpret_cast<uint16_t*>(out));
+                     reinterpret_cast<uint16_t*>(out), reinterpret_cast<uint32_t*>(trailer));
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
@@ -110,6 +140,7 @@ struct TlOp {
   const float* in;         // input map [rows][cin]
   const int32_t* tbl;      // [groups][K][16] input row of every (group, offset, slot), -1 = absent
   const uint16_t* W;       // pack_tail_weights
+  const float* inv;        // 1 / (weight scale of the op's scale group)
   const int32_t* in_boff;  // per-scan row offsets of the input level
   int K, cin, in_cap, lin; // in_cap: rows the input map holds; lin: input level (row count = cnt[lin])
   int maskbits;            // 1: offset k is present in a tile iff bit k of its group mask; 0: iff the tile has real rows
@@ -150,23 +181,17 @@ __device__ inline float tl_row16_max(float v) {
   return v;
 }
 
-// fp32 x 8 -> (hi, mid, lo) bf16 x 8, round to nearest even at every level (as sconv_split.hip split8)
-__device__ inline void tl_split8(const f32x4& a0, const f32x4& a1, bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
-  uint32_t h[4], m[4], l[4];
+// fp32 x 8 -> (hi, lo) fp16 x 8, round to nearest even (as sconv_split.hip split8h)
+__device__ inline void tl_split8(const f32x4& a0, const f32x4& a1, f16x8_t& hi, f16x8_t& lo) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const float x0 = p < 2 ? a0[2 * p] : a1[2 * p - 4], x1 = p < 2 ? a0[2 * p + 1] : a1[2 * p - 3];
-    const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){x0, x1}, bf16x2_t));
-    const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xFFFF0000u);
-    const uint32_t mp = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){r0, r1}, bf16x2_t));
-    const float s0 = r0 - __uint_as_float(mp << 16), s1 = r1 - __uint_as_float(mp & 0xFFFF0000u);
-    h[p] = hp;
-    m[p] = mp;
-    l[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){s0, s1}, bf16x2_t));
+    const f16x2_t h = __builtin_convertvector((f32x2){x0, x1}, f16x2_t);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const f16x2_t l = __builtin_convertvector((f32x2){x0 - hf[0], x1 - hf[1]}, f16x2_t);
+    hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
+    lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
   }
-  hi = __builtin_bit_cast(bf16x8_t, (uint4){h[0], h[1], h[2], h[3]});
-  mid = __builtin_bit_cast(bf16x8_t, (uint4){m[0], m[1], m[2], m[3]});
-  lo = __builtin_bit_cast(bf16x8_t, (uint4){l[0], l[1], l[2], l[3]});
 }
 
 __device__ inline uint32_t tl_ld_flag(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -176,10 +201,11 @@ __device__ inline TlDesc tl_decode(const TailArgs& a, int s) {
   TlDesc d;
   d.kind = 0; d.nops = 1; d.scale = nullptr; d.shift = nullptr; d.relu = 0; d.ncoltiles = 8; d.ostride = 128; d.pool = 0;
   d.out = nullptr; d.t2 = nullptr; d.res = nullptr; d.eca_w = nullptr; d.eca_k = 0; d.out_cap = 0; d.lout = 5;
-  d.op[1].in = nullptr; d.op[1].tbl = nullptr; d.op[1].W = nullptr; d.op[1].in_boff = nullptr;
+  d.op[1].in = nullptr; d.op[1].tbl = nullptr; d.op[1].W = nullptr; d.op[1].in_boff = nullptr; d.op[1].inv = nullptr;
   d.op[1].K = 0; d.op[1].cin = 0; d.op[1].in_cap = 0; d.op[1].lin = 0; d.op[1].maskbits = 0;
   TlOp& o = d.op[0];
   o.cin = 128; o.maskbits = 1;
+  o.inv = a.w_inv + 4 * s;          // one scale group per stage (both ops of a head stage share it)
   if (s < 12) {
     const int li = s >> 2, ph = s & 3, lv = 5 + li;
     d.lout = lv; d.out_cap = a.cap[lv];
@@ -229,7 +255,7 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const TailArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g4 = lane >> 4;
   const int b = blockIdx.x >> 3, g = blockIdx.x & 7;
-  int32_t* const s_tbl = reinterpret_cast<int32_t*>(smem + TL_OFF_TBL);
+  char* const s_tbl = smem + TL_OFF_TBL;
   int32_t* const s_perm = reinterpret_cast<int32_t*>(smem + TL_OFF_PERM);
   float* const s_csum = reinterpret_cast<float*>(smem + TL_OFF_MISC);          // [8][16]
   float* const s_pool = s_csum + 128;                                          // [16] accumulated over the windows of a scan
@@ -273,13 +299,14 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const TailArgs a) {
   };
 
   // measurement hook (tools/tail_trace.py): per (workgroup, stage) s_memtime stamps of wave 0; null = off
-  unsigned long long* const trp = (TRACE && a.trace) ? a.trace + (size_t)blockIdx.x * 17 * 8 : nullptr;
+  // (the stamps live 2^19 entries into the buffer: the traced builds of other kernels of the same forward write at its start)
+  unsigned long long* const trp = (TRACE && a.trace) ? a.trace + ((size_t)1 << 19) + (size_t)blockIdx.x * 17 * 8 : nullptr;
   auto now = [] { return (unsigned long long)__builtin_amdgcn_s_memtime(); };
   unsigned long long tr[TRACE ? 8 : 1];
 
   const int nstage = a.do_head ? 17 : 12;
   const void* tbl_cached = nullptr;   // table currently staged in s_tbl (conv1 / conv2 of a block share it)
-  int tbl_cached_base = -1;
+  int tbl_cached_base = -1, tbl_cached_row0 = -1;
 
   for (int s = 0; s < nstage; ++s) {
     const TlDesc d = tl_decode(a, s);
@@ -346,8 +373,10 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const TailArgs a) {
       if (tid < 16) s_pool[tid] = d.pool == 2 && a.pool_mode == 2 ? -INFINITY : 0.f;
       // epilogue vectors of this column tile: in flight from here
       const int col0 = 16 * ct + 4 * g4;
-      f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (d.scale) sc = *reinterpret_cast<const f32x4*>(d.scale + col0);
+      // sc carries 1/s of the stage's weight scale (a power of two: exact)
+      const float winv = d.op[0].inv[0];
+      f32x4 sc = (f32x4){winv, winv, winv, winv}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (d.scale) sc = *reinterpret_cast<const f32x4*>(d.scale + col0) * winv;
       if (d.shift) sh = *reinterpret_cast<const f32x4*>(d.shift + col0);
       for (int p = 0; p < npass; ++p) {
         const int gbase = G0 + 16 * p;
@@ -391,12 +420,13 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const TailArgs a) {
           return rnd_norm(r);
         };
         // geometry of a round
-        struct Geo { const float* in; const uint16_t* W; const int32_t* tbl; int K, cin, ncb, maskbits, in_cap, nr, ncbc, nc8, sh8, stride, nitems; };
+        struct Geo { const float* in; const uint16_t* W; const int32_t* tbl; int K, cin, ncb, maskbits, in_cap, nr, ncbc, nc8, sh8, stride, nitems, row0; };
         auto geo_of = [&](const Rnd& r) {
           Geo q;
           const TlOp& op = r.oi == 0 ? d.op[0] : d.op[1];
           q.in = op.in; q.W = op.W; q.tbl = op.tbl; q.K = op.K; q.cin = op.cin; q.ncb = op.cin >> 5; q.maskbits = op.maskbits;
           q.in_cap = op.in_cap;
+          q.row0 = r.oi == 0 ? o_rs[0] : o_rs[1];            // table entries are stored relative to this row
           const int chc = r.oi == 0 ? o_chc[0] : o_chc[1], cap = r.oi == 0 ? o_cap[0] : o_cap[1], re = r.oi == 0 ? o_re[0] : o_re[1];
           q.nr = min(cap, re - r.r0);
           q.ncbc = min(chc, op.cin - r.c0) >> 5;
@@ -417,29 +447,30 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const TailArgs a) {
         // counted s_waitcnt covers the ring — loads inside wave-uniform branches made it drain vmcnt(0) in front of every item
         // (1.8 k cycles per item, tools/tail_trace.py).
         // W fragments.  The K * ncbc items of a round are walked in GROUPS of 16 consecutive items (item = cbl * K + k); slot u
-        // (0, 1) of this wave holds item 16 gi + wave + 8 u of group gi.  A fragment set (hi | mid | lo, 3 KB) goes global ->
+        // (0, 1) of this wave holds item 16 gi + wave + 8 u of group gi.  A fragment set (hi | lo, 2 KB) goes global ->
         // LDS by LDS-DMA into the wave's own ring slot one group ahead — also across the barriers between rounds — and is read
         // back with three ds_read_b128 when its item starts.  Neither the compiler's wait-count pass (it drained vmcnt(0) in
         // front of every tile: 1.8 k cycles per item, tools/tail_trace.py) nor a register ring filled by asm (hipcc copies such
         // registers while their loads are in flight) survives these loops, so: the DMA is an asm statement with no register
         // result, every request is UNCONDITIONAL and in a fixed order (a slot without an item requests out of range: zeros, no
         // traffic), and the waits are counted by hand — requests return in order, and the number of requests younger than a
-        // slot's at its use is 3 (the other slot's refill), + 8 row loads of the next round in the first group of a round.
+        // slot's at its use is 2 (the other slot's refill), + 2 TL_RU = 12 row loads of the next round in the first group of a round.
         typedef __attribute__((address_space(3))) char lds_char;
-        const uint32_t wslot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_char*)(smem + TL_OFF_W + wave * 6144));
+        const uint32_t wslot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_char*)(smem + TL_OFF_W + wave * 4096));
+        const uint32_t smem_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_char*)smem);
         auto w_dma = [&](const uint16_t* Wp, int K, int ncb, int nitems, int c0, bool valid_r, int gi, int u) {
           const int item = gi * 16 + wave + TL_WAVES * u;
           const bool valid = valid_r && item < nitems;
           const int cbl = (int)(((float)item + 0.5f) * (1.f / (float)K)), k = item - cbl * K;
-          const uint64_t wb = (uint64_t)(uintptr_t)(Wp + (size_t)ct * K * ncb * 1536);
+          const uint64_t wb = (uint64_t)(uintptr_t)(Wp + (size_t)ct * K * ncb * 1024);
           u32x4 rs;
           rs[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wb);
           rs[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wb >> 32)) & 0xFFFFu;
-          rs[2] = (uint32_t)__builtin_amdgcn_readfirstlane(K * ncb * 3072);
+          rs[2] = (uint32_t)__builtin_amdgcn_readfirstlane(K * ncb * 2048);
           rs[3] = 0x00020000u;
-          const int so = __builtin_amdgcn_readfirstlane(valid ? (k * ncb + (c0 >> 5) + cbl) * 3072 : 0);
+          const int so = __builtin_amdgcn_readfirstlane(valid ? (k * ncb + (c0 >> 5) + cbl) * 2048 : 0);
           const int vo = valid ? lane * 16 : (int)0x80000000u;
-          const uint32_t dst = wslot0 + (uint32_t)u * 3072u;
+          const uint32_t dst = wslot0 + (uint32_t)u * 2048u;
           uint32_t keep;
           asm volatile(
               "s_mov_b32 %0, m0\n\t"
@@ -447,18 +478,17 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const TailArgs a) {
               "s_nop 4\n\t"
               "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
               "buffer_load_dwordx4 %1, %2, %4 offen offset:1024 lds\n\t"
-              "buffer_load_dwordx4 %1, %2, %4 offen offset:2048 lds\n\t"
               "s_mov_b32 m0, %0"
               : "=&s"(keep)
               : "v"(vo), "s"(rs), "s"(dst), "s"(so)
               : "memory");
         };
-        // rows of a round: 8 x 16 bytes per thread in flight, then split into the bf16 planes
-        f32x4 rv0[4], rv1[4];
+        // rows of a round: 2 TL_RU x 16 bytes per thread in flight, then split into the fp16 planes
+        f32x4 rv0[TL_RU], rv1[TL_RU];
         auto rows_issue = [&](const Rnd& r, const Geo& q, bool valid_r) {
           const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.in), 0, q.in_cap * q.cin * 4, 0x00020000);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < TL_RU; ++u) {
             const int unit = tid + TL_THREADS * u;
             const int row = unit >> q.sh8, c8 = unit & (q.nc8 - 1);
             const int voff = (valid_r && row < q.nr) ? ((r.r0 + row) * q.cin + r.c0 + 8 * c8) * 4 : (int)0x80000000u;
@@ -468,16 +498,15 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const TailArgs a) {
         };
         auto rows_commit = [&](const Geo& q) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < TL_RU; ++u) {
             const int unit = tid + TL_THREADS * u;
             const int row = unit >> q.sh8, c8 = unit & (q.nc8 - 1);
             if (row <= q.nr) {                          // row nr: the all-zero row absent neighbours read
-              bf16x8_t hi, mid, lo;
-              tl_split8(rv0[u], rv1[u], hi, mid, lo);
+              f16x8_t hi, lo;
+              tl_split8(rv0[u], rv1[u], hi, lo);
               char* dst = smem + row * q.stride + c8 * 16;
-              *reinterpret_cast<bf16x8_t*>(dst) = hi;
-              *reinterpret_cast<bf16x8_t*>(dst + TL_PLANE) = mid;
-              *reinterpret_cast<bf16x8_t*>(dst + 2 * TL_PLANE) = lo;
+              *reinterpret_cast<f16x8_t*>(dst) = hi;
+              *reinterpret_cast<f16x8_t*>(dst + TL_PLANE) = lo;
             }
           }
         };
@@ -499,8 +528,9 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const TailArgs a) {
             const int t = (int)(((float)j + 0.5f) * inv);
             if (t < 16) {
               const int rem = j - t * ppt, k = rem >> 2, s0 = (rem & 3) * 4;
-              int32_t* dst = s_tbl + (k * 16 + s0) * 16 + t;
-              dst[0] = tv[u].x; dst[16] = tv[u].y; dst[32] = tv[u].z; dst[48] = tv[u].w;
+              uint16_t* dst = reinterpret_cast<uint16_t*>(s_tbl + (k * 16 + s0) * TL_TBL_ROW) + t;
+              auto rel = [&](int32_t row) { return (uint16_t)(row < 0 ? 0xFFFF : min(row - q.row0, 0xFFFE)); };
+              dst[0] = rel(tv[u].x); dst[TL_TBL_ROW / 2] = rel(tv[u].y); dst[TL_TBL_ROW] = rel(tv[u].z); dst[3 * TL_TBL_ROW / 2] = rel(tv[u].w);
             }
           }
         };
@@ -512,10 +542,11 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const TailArgs a) {
         for (int u = 0; u < 2; ++u) w_dma(cg.W, cg.K, cg.ncb, cg.nitems, cur.c0, cur.oi < 2, 0, u);
         __syncthreads();                 // previous window / stage: readers of s_perm, s_tbl and the planes are done
         if (tid < 256) s_perm[tid] = perm_v;
-        if (cur.oi < 2 && (cg.tbl != tbl_cached || gbase != tbl_cached_base)) {
+        if (cur.oi < 2 && (cg.tbl != tbl_cached || gbase != tbl_cached_base || cg.row0 != tbl_cached_row0)) {
           tbl_stage(cg);
           tbl_cached = cg.tbl;
           tbl_cached_base = gbase;
+          tbl_cached_row0 = cg.row0;
         }
         if (!synced) { cluster_wait(); synced = true; if constexpr (TRACE) tr[1] = now(); }
         rows_issue(cur, cg, cur.oi < 2);
@@ -542,51 +573,64 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const TailArgs a) {
               const int item = gi * 16 + wave + TL_WAVES * u;
               unsigned long long t_w = 0;
               if constexpr (TRACE) t_w = now();
-              if (gi == 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-              else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+              if (gi == 0) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
               if constexpr (TRACE) tr[7] += now() - t_w;
               if (item < cg.nitems) {
                 const int cbl = (int)(((float)item + 0.5f) * invK), k = item - cbl * cg.K;
-                const char* wp = smem + TL_OFF_W + (wave * 2 + u) * 3072 + lane * 16;
-                const bf16x8_t wh = *reinterpret_cast<const bf16x8_t*>(wp);
-                const bf16x8_t wm = *reinterpret_cast<const bf16x8_t*>(wp + 1024);
-                const bf16x8_t wl = *reinterpret_cast<const bf16x8_t*>(wp + 2048);
+                const char* wp = smem + TL_OFF_W + (wave * 2 + u) * 2048 + lane * 16;
+                const f16x8_t wh = *reinterpret_cast<const f16x8_t*>(wp);
+                const f16x8_t wl = *reinterpret_cast<const f16x8_t*>(wp + 1024);
                 // the 16 input rows of this lane's slot (one per tile) -> LDS offsets of their plane rows; an absent
                 // neighbour (-1), a row outside this round's piece and every slot of a tile without the offset read the zero row
-                const int4* tp = reinterpret_cast<const int4*>(s_tbl + (k * 16 + l15) * 16);
-                const int4 e0 = tp[0], e1 = tp[1], e2 = tp[2], e3 = tp[3];
-                const int32_t ent[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+                const uint4* tp = reinterpret_cast<const uint4*>(s_tbl + (k * 16 + l15) * TL_TBL_ROW);
+                const uint4 e0 = tp[0], e1 = tp[1];
+                const uint32_t ew[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                const int rel0 = cur.r0 - cg.row0;             // first row of this round's piece, relative like the entries
                 const uint32_t am = cg.maskbits ? ((uint32_t)__ballot((gm_l >> k) & 1u) & 0xFFFFu) : act_all;
-                const char* abase = smem + cbl * 64 + g4 * 16;
-                // four tiles at a time: their 12 fragment reads are issued together and the six products of the four tiles are
-                // interleaved — four independent accumulator chains keep the matrix pipe issuing (one tile at a time was a
-                // chain of two LDS round trips + six dependent MFMAs: 400 cycles per tile, tools/tail_trace.py)
+                const uint32_t abase = smem_lds + (uint32_t)(cbl * 64 + g4 * 16);
+                // four tiles at a time.  The eight fragment reads of a quad (hi | lo plane of four rows) are ONE asm statement
+                // that ends with its wait: left to the compiler, the lo-plane reads reused one register quadruple and were
+                // serialised behind the products (five LDS round trips per quad: ~1 500 cycles per item whatever the tile
+                // count, tools/tail_trace.py).  While this wave waits for its reads the other wave of the SIMD feeds the
+                // matrix pipe; the three products of the four tiles are interleaved (four independent accumulator chains).
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
                   if ((am >> (4 * qd)) & 0xFu) {
-                    bf16x8_t ah[4], amid[4], al[4];
+                    uint32_t ad[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                      const int loc = ent[4 * qd + j] - cur.r0;
+                      const int t = 4 * qd + j;
+                      const int loc = (int)((t & 1) ? (ew[t >> 1] >> 16) : (ew[t >> 1] & 0xFFFFu)) - rel0;
                       const int idx = (uint32_t)loc < (uint32_t)cg.nr ? loc : cg.nr;
-                      const char* ap = abase + idx * cg.stride;
-                      ah[j] = *reinterpret_cast<const bf16x8_t*>(ap);
-                      amid[j] = *reinterpret_cast<const bf16x8_t*>(ap + TL_PLANE);
-                      al[j] = *reinterpret_cast<const bf16x8_t*>(ap + 2 * TL_PLANE);
+                      ad[j] = abase + (uint32_t)(idx * cg.stride);
                     }
+                    f32x4 rh0, rh1, rh2, rh3, rl0, rl1, rl2, rl3;
+                    asm volatile(
+                        "ds_read_b128 %0, %8\n\t"
+                        "ds_read_b128 %1, %9\n\t"
+                        "ds_read_b128 %2, %10\n\t"
+                        "ds_read_b128 %3, %11\n\t"
+                        "ds_read_b128 %4, %8 offset:49152\n\t"
+                        "ds_read_b128 %5, %9 offset:49152\n\t"
+                        "ds_read_b128 %6, %10 offset:49152\n\t"
+                        "ds_read_b128 %7, %11 offset:49152\n\t"
+                        "s_waitcnt lgkmcnt(0)"
+                        : "=&v"(rh0), "=&v"(rh1), "=&v"(rh2), "=&v"(rh3), "=&v"(rl0), "=&v"(rl1), "=&v"(rl2), "=&v"(rl3)
+                        : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3])
+                        : "memory");
+                    static_assert(TL_PLANE == 49152, "the lo-plane offset of the asm above");
+                    const f16x8_t ah[4] = {__builtin_bit_cast(f16x8_t, rh0), __builtin_bit_cast(f16x8_t, rh1),
+                                           __builtin_bit_cast(f16x8_t, rh2), __builtin_bit_cast(f16x8_t, rh3)};
+                    const f16x8_t al[4] = {__builtin_bit_cast(f16x8_t, rl0), __builtin_bit_cast(f16x8_t, rl1),
+                                           __builtin_bit_cast(f16x8_t, rl2), __builtin_bit_cast(f16x8_t, rl3)};
                     f32x4 c[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[j], acc[4 * qd + j], 0, 0, 0);   // small terms first
+                    for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[j], acc[4 * qd + j], 0, 0, 0);   // small terms first
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[j], c[j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[j], c[j], 0, 0, 0);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, amid[j], c[j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah[j], c[j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, amid[j], c[j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[4 * qd + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[j], c[j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc[4 * qd + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[j], c[j], 0, 0, 0);
                   }
                 }
               }
@@ -600,6 +644,7 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const TailArgs a) {
             tbl_stage(ng);
             tbl_cached = ng.tbl;
             tbl_cached_base = gbase;
+            tbl_cached_row0 = ng.row0;
           }
           cur = nxt;
           cg = ng;
@@ -655,8 +700,7 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const TailArgs a) {
         for (int j = 0; j < 2; ++j) {
           const int32_t row = s_perm[(tbase + j) * 16 + l15];
           f32x4 v = fin[j];
-          if (d.scale) v = v * sc + sh;
-          else if (d.shift) v = v + sh;
+          v = v * sc + sh;
           if (d.relu) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);

@@ -773,6 +773,9 @@ int col_stats(int mode, const float* a, const float* b, const float* mask, const
     // >= ~500 blocks whenever the map has the rows for it (a function of n only: deterministic)
     int rpb = CS4_ROWS;
     while (rpb > 32 && cdiv(n, rpb) < 512) rpb >>= 1;
+    // never more than 1 023 blocks below CS4_ROWS rows per block, so 2*c*max(1024, ceil(n/512)) floats (the header's contract)
+    // always hold them; a caller with less gets coarser blocks (another fixed summation order) instead of an error
+    while (rpb < CS4_ROWS && (size_t)cdiv(n, rpb) * 2 * c > scratch_floats) rpb <<= 1;
     const int64_t blocks4 = cdiv(n, rpb);
     EGONN_REQUIRE(scratch && scratch_floats >= (size_t)blocks4 * 2 * c, EGONN_ERR_INVALID,
                   "col_stats: scratch too small (%zu < %lld floats)", scratch_floats, (long long)(blocks4 * 2 * c));

@@ -249,7 +249,8 @@ int egonn_conv_backward_weight(egonn_ctx* ctx, int level_in, int level_out, int 
 /* Per-channel reductions over (n,c) rows -> out (2,c).  MinkowskiBatchNorm in train mode = nn.BatchNorm1d over all
  * rows (models/minkgl.py:102,107):  mode 0: sum a, sum a^2;  mode 1: sum (a-mean)^2, 0;
  * mode 2 (backward): g = a*[mask>0] (mask nullable): sum g, sum g*(b-mean);  mode 3: d = a-mean: sum d, sum d^2 (one-pass
- * statistics around a shift point, additive over ranks for SyncBN).  scratch >= 2*c*ceil(n/512) floats. */
+ * statistics around a shift point, additive over ranks for SyncBN).  scratch >= 2*c*max(1024, ceil(n/512)) floats makes the
+ * row blocking (and so the fp32 summation order) a function of n only; the minimum accepted is 2*c*ceil(n/512). */
 int egonn_col_stats(int mode, const float* a, const float* b, const float* mask, const float* mean, int64_t n, int c,
                     float* out, float* scratch, int64_t scratch_floats, void* stream);
 /* Per-channel BatchNorm bookkeeping of nn.BatchNorm1d in train mode, on the device:

@@ -306,7 +306,7 @@ def test_forward_matches_reference_graph(gpu, name):
     assert torch.equal(yg["global"], y["global"])              # deterministic
 
 
-@pytest.mark.parametrize("name", ["egonn_cart01_b1", "egonn_cart01_b2", "egonn_cart03_b1"])
+@pytest.mark.parametrize("name", ["egonn_cart01_b1", "egonn_cart01_b2", "egonn_cart03_b1", "egonn_cart01_50k_b2"])
 def test_compute_embedding_matches_reference_selection(gpu, name):
     """eval/evaluate.py:327-361: quantise -> forward -> 128 lowest-sigma keypoints, ascending."""
     case = H.load_case(name)

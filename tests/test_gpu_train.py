@@ -90,7 +90,37 @@ def test_input_layer_weight_gradient(plan):
     # (unit features run on the bf16 matrix pipe with dout split exactly into three bf16 parts, explicit features on the plain
     #  fp32 kernel: the same sums in another order)
     dk = ctx.conv_backward_weight(0, 0, 5, False, ones, G, (125, 1, 32))
-    assert float((dk - W.grad).abs().max()) <= 2e-6 * float(dk.abs().max()) * np.sqrt(n0), float((dk - W.grad).abs().max())
+    assert float((dk - W.grad).abs().max()) <= 2e-5 * float(dk.abs().max()), float((dk - W.grad).abs().max())
+
+
+@pytest.mark.parametrize("n_pts", [37, 101])
+def test_input_layer_weight_gradient_tail_tile(n_pts):
+    """conv0_wgrad_unit_kernel on maps smaller than one 128-voxel workgroup tile and not a multiple of 32 (tail tile, idle-wave
+    partials): the unit-feature MFMA path against the explicit-feature fp32 path AND a host fp64 sum over the kernel map."""
+    from egonn_amd import _lib
+    dev = _lib.require_gpu()
+    ctx = _lib.Context(dev, coord_bits=12)
+    g = np.random.default_rng(n_pts)
+    pts = (g.integers(-6, 7, size=(n_pts, 3)).astype(np.float32) + 0.5) * 0.2        # a dense little cluster: many k=5 neighbours
+    ctx.voxelize(torch.from_numpy(pts).to(dev), [0, n_pts], 0, [0.2])
+    n0 = ctx.level_count(0)
+    assert 0 < n0 < 128
+    G = rnd((n0, 32), 6, dev)
+    dk_unit = ctx.conv_backward_weight(0, 0, 5, False, None, G, (125, 1, 32))
+    dk_feat = ctx.conv_backward_weight(0, 0, 5, False, torch.ones((n0, 1), device=dev), G, (125, 1, 32))
+    coords = ctx.level_coords(0).cpu().numpy()
+    ref = np.zeros((125, 32))
+    Gn = G.double().cpu().numpy()
+    lut = {tuple(c): i for i, c in enumerate(coords.tolist())}
+    for o, c in enumerate(coords.tolist()):
+        for k in range(125):       # ME kernel index: first spatial axis fastest (SURVEY Appendix A.5)
+            d = (k % 5 - 2, (k // 5) % 5 - 2, k // 25 - 2)
+            j = lut.get((c[0], c[1] + d[0], c[2] + d[1], c[3] + d[2]))
+            if j is not None:
+                ref[k] += Gn[o]
+    for dk in (dk_unit, dk_feat):
+        err = np.abs(dk.double().cpu().numpy().reshape(125, 32) - ref).max()
+        assert err <= 2e-5 * np.abs(ref).max(), err
 
 
 @pytest.mark.parametrize("relu", [True, False])

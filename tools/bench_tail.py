@@ -16,7 +16,8 @@ shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
 m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(7, shapes).items()})
 m = m.to("cuda").eval()
 m.coord_bits = 12
-scans = [lidar_scan(100 + i, 50000) for i in range(B)]
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1000      # 1000: the first batch of bench.py
+scans = [lidar_scan(SEED + i, 50000) for i in range(B)]
 off = [0]
 for s in scans:
     off.append(off[-1] + len(s))
@@ -39,6 +40,21 @@ for mode in (1, 0):
         ex.extract_packed(pts, off)
     torch.cuda.synchronize()
     print(f"tail_mode {mode}: {(time.perf_counter() - t0) / n * 1e3:.3f} ms per eager step (batch {B})")
+    # exclusive durations (HIP events around every tagged launch) of what the tail replaces / of the tail kernel
+    ctx.profile_enable(1)
+    ctx.profile_fetch()
+    for _ in range(5):
+        ex.extract_packed(pts, off)
+    recs = ctx.profile_fetch()
+    ctx.profile_enable(0)
+    agg = {}
+    for nm, ms, by, fl in recs:
+        agg.setdefault(nm, []).append(ms * 1e3)
+    tot_all = sum(np.mean(v) for v in agg.values())
+    sel = {k: np.mean(v) for k, v in agg.items() if any(x in k for x in ("/L5", "/L6", "/L7", "tail_", "gl_", "global", "gem", "pool", "g1x1", "gt", "gdec"))}
+    for k, v in sorted(sel.items(), key=lambda kv: -kv[1]):
+        print(f"   {k:56s} {v:8.1f} us")
+    print(f"   tagged launches: all {tot_all:.1f} us, listed {sum(sel.values()):.1f} us")
 g1, f1 = res[1]
 g0, f0 = res[0]
 for l, a, b in zip((5, 6, 7), f0, f1):
