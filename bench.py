@@ -102,6 +102,10 @@ def parse():
     p.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median one is reported")
     p.add_argument("--distinct-batches", type=int, default=4,
                    help="the timed loop rotates over this many distinct resident batches (1 = replay one batch: A/B with round <= 3)")
+    p.add_argument("--dry-run", action="store_true",
+                   help="plumbing check without a GPU (tests/test_distributed_cpu.py): the distributed branch of this script — env "
+                        "parsing, process group (gloo), barriers, max-over-ranks timing, the ranks-seen all-reduce, rank 0's JSON "
+                        "line — around a stub step; the line is marked dry_run and carries no measurement")
     p.add_argument("--no-extras", action="store_true",
                    help="skip the bounded side measurements of the other BASELINE configs (extra.configs[2], configs[3]_1gpu, db)")
     return p.parse_args()
@@ -129,20 +133,81 @@ def layer_rows(recs, dtype):
     return rows
 
 
-def main():
-    args = parse()
+def dist_setup(args):
+    """Rank layout from the launcher's environment; one process per GPU over RCCL (backend "nccl"), gloo for --dry-run."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+    dist = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
+        if args.dry_run:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif not args.dry_run:
         torch.cuda.set_device(0)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    return world, rank, local_rank, distributed, dist
+
+
+def timed_regions(run_steps, steps, repeats, dist, dev, sync):
+    """`repeats` regions of exactly `steps` steps, each bracketed by a barrier + device sync on both sides; the elapsed time of a
+    region is the MAX over ranks."""
+    out = []
+    for _ in range(max(1, repeats)):
+        if dist is not None:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        run_steps(steps)
+        sync()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        out.append(el)
+    return out
+
+
+def ranks_seen(dist, dev):
+    """an actual all-reduce over the job's ranks (SUM of ones): RCCL on the GPU path"""
+    if dist is None:
+        return None
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    return int(ones.item())
+
+
+def dry_run(args):
+    world, rank, local_rank, distributed, dist = dist_setup(args)
+    dev = torch.device("cpu")
+    run_steps = lambda k: time.sleep(0.002 * k)
+    run_steps(args.warmup)
+    elapsed_all = timed_regions(run_steps, args.steps, args.repeats, dist, dev, lambda: None)
+    elapsed = float(np.median(elapsed_all))
+    seen = ranks_seen(dist, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "LiDAR scans/sec (descriptor extraction), 50k-pt clouds @ 0.1m voxel", "dry_run": True, "value": None,
+                          "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "ranks_seen": seen, "local_rank": local_rank,
+                          "repeats": {"timed_regions": len(elapsed_all)}}), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.dry_run:
+        return dry_run(args)
+    world, rank, local_rank, distributed, dist = dist_setup(args)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -248,23 +313,7 @@ def main():
     for c in ([g.ctx for g in graphs] or [ctx]):
         c.profile_fetch()
 
-    elapsed_all = []
-    for rep in range(max(1, args.repeats)):
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_steps(args.steps)
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        t1 = time.perf_counter()
-        el = t1 - t0
-        if distributed:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        elapsed_all.append(el)
+    elapsed_all = timed_regions(run_steps, args.steps, args.repeats, dist if distributed else None, dev, torch.cuda.synchronize)
     elapsed = float(np.median(elapsed_all))
 
     # ---------------- roofline of the dominant kernel: launches of the timed region(s)
@@ -442,11 +491,7 @@ def main():
         db = os.path.join(REPO, "tools", "bench_ingest.py")
         if os.path.exists(db):
             extra["db"] = side([db, "--json"], lambda d: d)
-    rccl_ranks_seen = None
-    if distributed:                                        # an actual RCCL all-reduce over the job's ranks (SUM of ones)
-        ones = torch.ones(1, device=dev)
-        dist.all_reduce(ones)
-        rccl_ranks_seen = int(ones.item())
+    rccl_ranks_seen = ranks_seen(dist if distributed else None, dev)
     if rank == 0:
         total_scans = args.batch * world * args.steps
         tail_desc = ("one resident launch (csrc/tail.hip), split-operand products with fp32 accumulation" if os.environ.get("EGONN_TAIL")

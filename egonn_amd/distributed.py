@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
+import collections
+
 import torch
 import torch.distributed as dist
 
@@ -29,6 +31,11 @@ def _world() -> Tuple[int, int]:
     return 0, 1
 
 
+# collectives issued by this process through the helpers below, by kind ("all_reduce", "all_gather"): the sharded-step tests
+# pin the communication pattern of a training step with it (tests/test_gpu_train.py); never read by the product path
+COLLECTIVES = collections.Counter()
+
+
 def _staged(t: torch.Tensor) -> bool:
     """gloo has no device collectives on this build: stage HIP tensors through the host (tests only — on the GPU
     box the backend is "nccl" = RCCL and tensors stay on the device)."""
@@ -39,6 +46,7 @@ def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     """in-place SUM all-reduce (RCCL; host-staged under gloo)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return t
+    COLLECTIVES["all_reduce"] += 1
     if _staged(t):
         h = t.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
@@ -49,6 +57,7 @@ def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def _all_gather_list(t: torch.Tensor, world: int) -> List[torch.Tensor]:
+    COLLECTIVES["all_gather"] += 1
     if _staged(t):
         h = t.cpu()
         parts = [torch.empty_like(h) for _ in range(world)]
@@ -71,6 +80,7 @@ def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     pad = torch.zeros((max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = torch.empty((world * max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    COLLECTIVES["all_gather"] += 1
     if dist.get_backend() == "gloo":                      # gloo moves host memory: stage device tensors through the CPU
         hpad = pad.cpu()
         parts = [torch.empty_like(hpad) for _ in range(world)]
@@ -191,6 +201,7 @@ class _AllGatherEmbeddings(torch.autograd.Function):
             parts = _all_gather_list(pad, world)
         else:                                             # ONE collective: RCCL all-gather of the padded blocks
             out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            COLLECTIVES["all_gather"] += 1
             dist.all_gather_into_tensor(out, pad.contiguous())
             if all(v == mx for v in sizes):
                 return out

@@ -163,3 +163,24 @@ def test_syncbn_statistics_and_gradient_allreduce_world2_gloo():
         assert total == 101.0 and skipped
         assert np.allclose(mean, x.mean(0).numpy(), rtol=1e-6, atol=1e-6)          # whole-batch mean on every rank
         assert np.allclose(grad, x.sum(0).numpy(), rtol=1e-6, atol=1e-5)           # SUM, not average
+
+
+def test_bench_distributed_branch_dry_run_world2():
+    """bench.py's distributed branch exactly as the driver launches it (torch.distributed.run, one rank per GPU, rendezvous on
+    127.0.0.1), with the gloo backend and a stub step: env parsing, process group, the barrier-bracketed timed regions with the
+    max-over-ranks reduction, the ranks-seen all-reduce and rank 0's single JSON line."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--repeats", "2", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=repo)
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["value"] is None    # never mistaken for a measurement
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["repeats"]["timed_regions"] == 2 and d["ms_per_step"] > 0

@@ -315,10 +315,14 @@ def _sharded_worker(rank, world, port, out_path, backend="gloo"):
         step = TrainStep(model, torch.optim.SGD(model.parameters(), lr=0.0), margin=0.2)
         pos, neg = _masks()
         mine = [0, 1] if rank == 0 else [2]                            # uneven shards
-        loss, stats = step(_scan_batch(dev, coords, mine), pos, neg, step_optimizer=False)
+        from egonn_amd import distributed as D
+        D.COLLECTIVES.clear()
+        loss, stats = step(_scan_batch(dev, coords, mine), pos, neg, step_optimizer=False, shard_sizes=[2, 1])
+        comm = dict(D.COLLECTIVES)
+        n_bn = sum(1 for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d) and m.weight.grad is not None)
         grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}
         bufs = {k: v.detach().cpu() for k, v in model.state_dict().items() if "running" in k}
-        torch.save({"loss": float(loss), "stats": stats, "grads": grads, "bufs": bufs}, f"{out_path}.{rank}")
+        torch.save({"loss": float(loss), "stats": stats, "grads": grads, "bufs": bufs, "comm": comm, "n_bn": n_bn}, f"{out_path}.{rank}")
     finally:
         dist.destroy_process_group()
 
@@ -360,6 +364,10 @@ def test_sharded_step_equals_single_process_step(tmp_path, backend):
         assert p.exitcode == 0
     for r in range(2):
         got = torch.load(f"{out}.{r}")
+        # the communication pattern of one step: the level row totals (1 all-reduce of 8 values), ONE all-reduce of the (2, C)
+        # sums per BatchNorm and direction (SyncBN), ONE all-gather of the embeddings, ONE flat all-reduce of the gradients
+        assert got["n_bn"] >= 20
+        assert got["comm"] == {"all_reduce": 1 + 2 * got["n_bn"] + 1, "all_gather": 1}, got["comm"]
         assert abs(got["loss"] - float(loss)) <= 1e-4 * max(1.0, abs(float(loss)))
         assert set(got["grads"]) == set(want)
         for k, g in got["grads"].items():
