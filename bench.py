@@ -523,10 +523,10 @@ def main():
                                  "(captured voxelise + forward + select; level sizes stay on the device; capacities calibrated on other scans)"
                                  if args.mode == "graph" else "eager: ~150 launches + one size query per step",
                        "conv_arithmetic": ("bf16 maps and kernels, fp32 accumulate" if args.dtype == "bf16" else
-                                           "fp32 in / fp32 out; sparse convs of levels 1-4 (a function of the layer, not of the batch): operands "
+                                           "fp32 in / fp32 out; sparse convs of levels 1-5 (a function of the layer, not of the batch): operands "
                                            "split into fp16 hi + lo (weights scaled by a power of two per kernel), 3 products on "
                                            "v_mfma_f32_16x16x32_f16 with fp32 accumulation (deviation from the plain fp32 kernel < 3e-6 of the "
-                                           "largest output, tests/test_gpu_graph.py); levels 5-7 and the heads: " + tail_desc + "; conv_variant="
+                                           "largest output, tests/test_gpu_graph.py); levels 6-7 and the global head: " + tail_desc + "; conv_variant="
                                            + str(args.conv_variant))},
             "repeats": {"timed_regions": len(elapsed_all), "reported": "median",
                         "scans_per_s": [round(total_scans / e, 1) for e in elapsed_all],

@@ -191,7 +191,9 @@ struct Ctx {
   unsigned long long* dev_pairs = nullptr;   // [16] kernel-map pair counters: [0] conv0 k5, [l] k3 map of level l
   int device = 0;
   int coord_bits = 16;
-  int split_max_level = 4;    // fp32 sparse convs whose output level is <= this run on the split-bf16 kernels (sconv.hip)
+  int split_max_level = 5;    // fp32 sparse convs whose output level is <= this run on the fp16-split kernels (sconv_split.hip);
+                              // round 5: 4 -> 5 (profiles/r05b_tail_kernel.txt: 25.2 k -> 26.4 k scans/s with four batches in flight; the
+                              // level-5 launches alone get slower, one-batch graph latency 1.17 -> 1.23 ms — the headline metric is scans/s)
   int conv_variant = 0;       // tests / A-B measurements only (egonn_debug_set_naive_conv): 0 = product choice, 1 = per-wave
                               // MFMA kernel, 2 = workgroup-cooperative MFMA kernel, 3 = plain one-thread-per-output kernel
   Arena plan_arena;           // keys, maps (lives until the next plan)

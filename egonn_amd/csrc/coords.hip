@@ -385,8 +385,8 @@ __device__ static inline int32_t level_rows(const int32_t* __restrict__ counts, 
   return v < cap ? v : cap;
 }
 
-__global__ void block_mask_kernel(MaskArgs a) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ static inline void block_mask_body(const MaskArgs& a, uint32_t vblock) {
+  const int64_t t = (int64_t)vblock * 256 + threadIdx.x;
   if (t >= a.prefix[NL]) return;
   int L = 2;
   while (L < NL - 1 && t >= a.prefix[L + 1]) ++L;
@@ -437,10 +437,22 @@ __device__ static inline int32_t lookup_local(const uint64_t* nbm, const int32_t
 // from the table two levels up (nbr27_kernel), so no level with many rows ever binary-searches.
 // (the two searched levels are independent: one launch covers both; threads past the first level's cap0 * 27 slots
 //  belong to the second)
-__global__ void adj27_search_kernel(const uint64_t* __restrict__ keys0, const uint64_t* __restrict__ keys1,
-                                    const int32_t* __restrict__ counts, int level0, int level1, int32_t cap0, int32_t cap1,
-                                    int cbL0, int cbL1, int32_t* __restrict__ adj0, int32_t* __restrict__ adj1) {
-  int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+struct Adj27Args {
+  const uint64_t *keys0, *keys1;
+  const int32_t* counts;
+  int level0, level1, cbL0, cbL1;
+  int32_t cap0, cap1;
+  int32_t *adj0, *adj1;
+};
+__device__ static inline void adj27_search_body(const Adj27Args& a, uint32_t vblock) {
+  const uint64_t* __restrict__ keys0 = a.keys0;
+  const uint64_t* __restrict__ keys1 = a.keys1;
+  const int32_t* __restrict__ counts = a.counts;
+  const int level0 = a.level0, level1 = a.level1, cbL0 = a.cbL0, cbL1 = a.cbL1;
+  const int32_t cap0 = a.cap0, cap1 = a.cap1;
+  int32_t* __restrict__ adj0 = a.adj0;
+  int32_t* __restrict__ adj1 = a.adj1;
+  int32_t t = (int32_t)(vblock * 256 + threadIdx.x);
   const bool second = t >= cap0 * 27;
   if (second) t -= cap0 * 27;
   const uint64_t* __restrict__ keys = second ? keys1 : keys0;
@@ -476,12 +488,33 @@ struct Nbr27Job {
   int32_t* nbr;
   int32_t level, cap_blocks, cap_vox;
 };
+struct Blk27Args {              // first-layer (k=5) helper: per level-2 block the (mask, first row) of its 27 neighbours
+  const int32_t* badj;
+  const uint64_t* bmask;
+  const int32_t* bstart;
+  int32_t cap2;
+  uint64_t* t2m;
+  int32_t* t2s;
+};
 struct Nbr27Pair {
   Nbr27Job job[2];
   const int32_t* counts;
   uint32_t split;              // workgroups of job[0]
+  uint32_t tail_at;            // first workgroup of the blk27 rider (the launch of level 1 carries it: it reads the level-2
+  Blk27Args blk;               //  table finished by the launch before); ~0u = none
 };
+__device__ static inline void blk27_body(const Blk27Args& b, const int32_t* __restrict__ counts, uint32_t vblock) {
+  const int32_t t = (int32_t)(vblock * 256 + threadIdx.x);
+  if (t >= level_rows(counts, 2, b.cap2) * 27) return;
+  const int32_t a = b.badj[t];
+  b.t2m[t] = a >= 0 ? b.bmask[a] : 0ull;
+  b.t2s[t] = a >= 0 ? b.bstart[a] : 0;
+}
 __global__ __launch_bounds__(256) void nbr27_kernel(const Nbr27Pair a) {
+  if (blockIdx.x >= a.tail_at) {                       // workgroup-uniform
+    blk27_body(a.blk, a.counts, blockIdx.x - a.tail_at);
+    return;
+  }
   const bool second = blockIdx.x >= a.split;
   const Nbr27Job& J = a.job[second ? 1 : 0];
   const uint64_t* __restrict__ vkeys = J.vkeys;
@@ -578,22 +611,6 @@ int count_map_pairs(Ctx* ctx, hipStream_t stream) {
   return EGONN_OK;
 }
 
-// first-layer helpers: level-2 block of every level-0 row, and per block the (mask, first row) of its 27 neighbours
-__global__ void grandparent_kernel(const int32_t* __restrict__ parent0, const int32_t* __restrict__ parent1,
-                                   const int32_t* __restrict__ counts, int32_t cap, int32_t* __restrict__ g0) {
-  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < level_rows(counts, 0, cap)) g0[i] = parent1[parent0[i]];
-}
-__global__ void blk27_kernel(const int32_t* __restrict__ badj, const uint64_t* __restrict__ bmask,
-                             const int32_t* __restrict__ bstart, const int32_t* __restrict__ counts, int32_t cap2,
-                             uint64_t* __restrict__ t2m, int32_t* __restrict__ t2s) {
-  const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= level_rows(counts, 2, cap2) * 27) return;
-  const int32_t a = badj[t];
-  t2m[t] = a >= 0 ? bmask[a] : 0ull;
-  t2s[t] = a >= 0 ? bstart[a] : 0;
-}
-
 // ------------------------------------------------------------------ k=2,s=2 tables
 __global__ void nbr8_kernel(const int32_t* __restrict__ cstart, const uint64_t* __restrict__ ckeys, int32_t n,
                             int32_t* __restrict__ nbr8) {
@@ -637,8 +654,8 @@ struct Nbr8TArgs {
   const int32_t* counts;                      // device row counts per level
   int32_t prefix[EGONN_NUM_LEVELS + 1];       // prefix over levels 1..7 of their row capacities; [0] unused
 };
-__global__ void nbr8T_all_kernel(Nbr8TArgs a) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ static inline void nbr8T_all_body(const Nbr8TArgs& a, uint32_t vblock) {
+  const int64_t t = (int64_t)vblock * 256 + threadIdx.x;
   if (t >= a.prefix[EGONN_NUM_LEVELS]) return;
   int l = 1;
   while (l < EGONN_NUM_LEVELS - 1 && t >= a.prefix[l + 1]) ++l;
@@ -668,6 +685,33 @@ __global__ void nbr8T_all_kernel(Nbr8TArgs a) {
     o[0] = make_int4(r[0], r[1], r[2], r[3]);
     o[1] = make_int4(r[4], r[5], r[6], r[7]);
   }
+}
+
+// Everything a plan derives from the pyramid alone, in ONE launch (workgroup ranges): the 4x4x4 occupancy masks of levels 2..9,
+// the searched adjacency of the two virtual levels, the level-2 block of every level-0 row (first-layer helper) and the k=2 /
+// transposed tables of levels 1..7.  Round 5: these were four launches of 4-10 us each in the plan's dependent chain.
+struct PlanTablesArgs {
+  MaskArgs ma;
+  Adj27Args adj;
+  Nbr8TArgs na;
+  const int32_t *parent0, *parent1;     // grandparent: g0[i] = parent1[parent0[i]]
+  int32_t* g0;
+  int32_t cap0;
+  uint32_t b_mask, b_adj, b_gp, b_n8;   // workgroups of every part, in this order
+};
+__global__ __launch_bounds__(256) void plan_tables_kernel(const PlanTablesArgs a) {
+  uint32_t b = blockIdx.x;
+  if (b < a.b_mask) { block_mask_body(a.ma, b); return; }
+  b -= a.b_mask;
+  if (b < a.b_adj) { adj27_search_body(a.adj, b); return; }
+  b -= a.b_adj;
+  if (b < a.b_gp) {
+    const int32_t i = (int32_t)(b * 256 + threadIdx.x);
+    if (i < level_rows(a.ma.counts, 0, a.cap0)) a.g0[i] = a.parent1[a.parent0[i]];
+    return;
+  }
+  b -= a.b_gp;
+  nbr8T_all_body(a.na, b);
 }
 
 __global__ void decode_coords_kernel(const uint64_t* __restrict__ keys, int32_t n, int level, int cb,
@@ -807,8 +851,9 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
   P.valid = false;                                           // until the maps are enqueued
   const int32_t* counts = ctx->dev_counts;
 
-  // ---- masks for levels 2..9 (blocks of levels 0..7)
-  MaskArgs ma;
+  // ---- one launch for everything that needs the pyramid only (plan_tables_kernel)
+  PlanTablesArgs ta;
+  MaskArgs& ma = ta.ma;
   int32_t pre = 0;
   for (int L = 0; L < NL; ++L) {
     ma.cstartL[L] = P.lv[L].cstart;
@@ -826,61 +871,30 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
     pre += (int32_t)P.cap[L];
   }
   ma.prefix[NL] = pre;
-  if (pre > 0) hipLaunchKernelGGL(block_mask_kernel, dim3((unsigned)cdiv(pre, 256)), dim3(256), 0, stream, ma);
-
-  // ---- kernel maps, top-down: the two virtual levels by search (tiny), every other level from the k=3
-  //      table of the level two above (which is the adjacency of its 4x4x4 blocks)
-  Nbr27Pair pair;
-  int npair = 0;
-  pair.counts = counts;
-  pair.split = 0;
-  auto flush = [&]() {
-    if (npair == 0) return;
-    if (npair == 1) pair.job[1] = pair.job[0];
-    const unsigned g0 = pair.split, g1 = npair == 2 ? (unsigned)cdiv(pair.job[1].cap_blocks, 4) : 0u;
-    hipLaunchKernelGGL(nbr27_kernel, dim3(g0 + g1), dim3(256), 0, stream, pair);
-    npair = 0;
-  };
+  ta.b_mask = (unsigned)cdiv(pre, 256);
+  // the k=3 tables of every level (allocated top-down as before)
   for (int l = NL - 1; l >= 1; --l) {
-    Level& V = P.lv[l];
-    const int32_t nv = (int32_t)P.cap[l];
-    V.nbr27 = A.alloc<int32_t>((size_t)nv * 27);
-    EGONN_REQUIRE(V.nbr27, EGONN_ERR_STATE, "plan arena too small");
-    if (nv == 0) continue;
-    if (l + 2 >= NL) {
-      if (l == NL - 1) continue;                         // searched together with level NL - 2 (next iteration)
-      Level& V1 = P.lv[NL - 1];
-      const int32_t nv1 = V1.nbr27 ? (int32_t)P.cap[NL - 1] : 0;
-      hipLaunchKernelGGL(adj27_search_kernel, dim3((unsigned)cdiv(((int64_t)nv + nv1) * 27, 256)), dim3(256), 0, stream, V.keys,
-                         V1.keys, counts, l, NL - 1, nv, nv1, cb - l, cb - (NL - 1), V.nbr27, V1.nbr27);
-    } else {
-      const Level& Bk = P.lv[l + 2];
-      // levels (NL-3, NL-4), (NL-5, NL-6), ... pair up: both members of a pair read tables finished by earlier launches
-      if (npair == 1 && pair.job[0].level != l + 1) flush();
-      Nbr27Job& J = pair.job[npair];
-      J.vkeys = V.keys; J.badj = Bk.nbr27; J.bmask = Bk.mask; J.bstart = Bk.bstart; J.nbr = V.nbr27;
-      J.level = l; J.cap_blocks = (int32_t)P.cap[l + 2]; J.cap_vox = nv;
-      if (npair == 0) pair.split = (unsigned)cdiv(P.cap[l + 2], 4);
-      ++npair;
-      if (npair == 2) flush();
-    }
+    P.lv[l].nbr27 = A.alloc<int32_t>((size_t)P.cap[l] * 27);
+    EGONN_REQUIRE(P.lv[l].nbr27, EGONN_ERR_STATE, "plan arena too small");
   }
-  flush();
+  {   // the two virtual levels by search (tiny)
+    Level& V = P.lv[NL - 2];
+    Level& V1 = P.lv[NL - 1];
+    const int32_t nv = (int32_t)P.cap[NL - 2], nv1 = (int32_t)P.cap[NL - 1];
+    ta.adj = Adj27Args{V.keys, V1.keys, counts, NL - 2, NL - 1, cb - (NL - 2), cb - (NL - 1), nv, nv1, V.nbr27, V1.nbr27};
+    ta.b_adj = (unsigned)cdiv(((int64_t)nv + nv1) * 27, 256);
+  }
+  const int32_t n0 = (int32_t)P.cap[0], n2 = (int32_t)P.cap[2];
   {   // first-layer (k=5) helpers
-    const int32_t n0 = (int32_t)P.cap[0], n2 = (int32_t)P.cap[2];
     P.g0 = A.alloc<int32_t>(n0);
     P.t2m = A.alloc<uint64_t>((size_t)n2 * 27);
     P.t2s = A.alloc<int32_t>((size_t)n2 * 27);
     EGONN_REQUIRE(P.g0 && P.t2m && P.t2s, EGONN_ERR_STATE, "plan arena too small");
-    if (n0 > 0) {
-      hipLaunchKernelGGL(grandparent_kernel, dim3((unsigned)cdiv(n0, 256)), dim3(256), 0, stream, P.lv[0].parent,
-                         P.lv[1].parent, counts, n0, P.g0);
-      hipLaunchKernelGGL(blk27_kernel, dim3((unsigned)cdiv((int64_t)n2 * 27, 256)), dim3(256), 0, stream, P.lv[2].nbr27,
-                         P.lv[2].mask, P.lv[2].bstart, counts, n2, P.t2m, P.t2s);
-    }
+    ta.parent0 = P.lv[0].parent; ta.parent1 = P.lv[1].parent; ta.g0 = P.g0; ta.cap0 = n0;
+    ta.b_gp = (unsigned)cdiv(n0, 256);
   }
   {
-    Nbr8TArgs na;
+    Nbr8TArgs& na = ta.na;
     na.prefix[0] = na.prefix[1] = 0;
     na.counts = counts;
     for (int l = 1; l < EGONN_NUM_LEVELS; ++l) {
@@ -899,10 +913,54 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
     }
     na.cstart[0] = nullptr; na.ckeys[0] = nullptr; na.parent[0] = nullptr; na.keys[0] = nullptr;
     na.nbr8[0] = nullptr; na.nbrT[0] = nullptr;
-    const int64_t tot = na.prefix[EGONN_NUM_LEVELS];
-    if (tot > 0)
-      hipLaunchKernelGGL(nbr8T_all_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, stream, na);
+    ta.b_n8 = (unsigned)cdiv(na.prefix[EGONN_NUM_LEVELS], 256);
   }
+  {
+    const unsigned nb = ta.b_mask + ta.b_adj + ta.b_gp + ta.b_n8;
+    if (nb > 0) hipLaunchKernelGGL(plan_tables_kernel, dim3(nb), dim3(256), 0, stream, ta);
+  }
+
+  // ---- k=3 kernel maps, top-down: every level from the k=3 table of the level two above (= the adjacency of its 4x4x4
+  //      blocks); levels (l, l-1) are independent and share a launch.  The last launch (level 1) also carries the first
+  //      layer's per-block neighbour table (blk27: reads the level-2 table, finished by the launch before).
+  Nbr27Pair pair;
+  int npair = 0;
+  pair.counts = counts;
+  pair.split = 0;
+  pair.tail_at = ~0u;
+  pair.blk = Blk27Args{nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+  bool blk_done = false;
+  auto flush = [&](bool last) {
+    if (npair == 0 && !(last && !blk_done && n0 > 0)) return;
+    if (npair == 1) pair.job[1] = pair.job[0];
+    const unsigned g0 = npair >= 1 ? pair.split : 0u, g1 = npair == 2 ? (unsigned)cdiv(pair.job[1].cap_blocks, 4) : 0u;
+    if (npair == 0) { pair.split = 0; pair.job[0] = Nbr27Job{nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0}; pair.job[1] = pair.job[0]; }
+    unsigned extra = 0;
+    pair.tail_at = ~0u;
+    if (last && !blk_done && n0 > 0) {
+      pair.tail_at = g0 + g1;
+      pair.blk = Blk27Args{P.lv[2].nbr27, P.lv[2].mask, P.lv[2].bstart, n2, P.t2m, P.t2s};
+      extra = (unsigned)cdiv((int64_t)n2 * 27, 256);
+      blk_done = true;
+    }
+    if (g0 + g1 + extra > 0) hipLaunchKernelGGL(nbr27_kernel, dim3(g0 + g1 + extra), dim3(256), 0, stream, pair);
+    npair = 0;
+  };
+  for (int l = NL - 3; l >= 1; --l) {
+    Level& V = P.lv[l];
+    const int32_t nv = (int32_t)P.cap[l];
+    if (nv == 0) continue;
+    const Level& Bk = P.lv[l + 2];
+    // levels (NL-3, NL-4), (NL-5, NL-6), ... pair up: both members of a pair read tables finished by earlier launches
+    if (npair == 1 && pair.job[0].level != l + 1) flush(false);
+    Nbr27Job& J = pair.job[npair];
+    J.vkeys = V.keys; J.badj = Bk.nbr27; J.bmask = Bk.mask; J.bstart = Bk.bstart; J.nbr = V.nbr27;
+    J.level = l; J.cap_blocks = (int32_t)P.cap[l + 2]; J.cap_vox = nv;
+    if (npair == 0) pair.split = (unsigned)cdiv(P.cap[l + 2], 4);
+    ++npair;
+    if (npair == 2) flush(false);
+  }
+  flush(true);
   HIP_CHECK(hipGetLastError());
   P.valid = true;
   return EGONN_OK;
