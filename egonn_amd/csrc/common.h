@@ -247,7 +247,8 @@ size_t radix_sort_scratch_bytes(int64_t n);
 // Per-scan variant: every segment [off[b], off[b+1]) (DEVICE int64 offsets, B+1) is sorted on its own on bits [0, nbits), 9 bits
 // per pass — no pass is spent on the batch index of contiguous scans.  The result lands in whichever pair the last pass wrote.
 int radix_sort_segments(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, int64_t n,
-                        const int64_t* off_dev, int B, int nbits, hipStream_t stream, uint64_t** keys_res, uint32_t** vals_res);
+                        const int64_t* off_dev, int B, int nbits, hipStream_t stream, uint64_t** keys_res, uint32_t** vals_res,
+                        int idx_bits = 0);
 size_t radix_sort_segments_scratch_bytes(int64_t n, int B);
 
 // ------------------------------------------------------------------ coords.hip

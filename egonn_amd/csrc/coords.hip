@@ -132,9 +132,11 @@ __device__ static inline bool encode_key(int32_t b, int32_t cx, int32_t cy, int3
 }
 
 // n_cap sizes the grid; the true point count is scan_off[B] (device memory: capturable plans never tell the host)
+// idx_bits > 0: PACKED output for the segmented sort (sort.hip) — keys[i] = (Morton bits << idx_bits) | (i - first point of
+// the scan), no value array: the batch index is implied by the segment and restored by the sort's last pass.
 __global__ void points_to_keys_kernel(const float* __restrict__ pts, int64_t n_cap, const int64_t* __restrict__ scan_off,
                                       int B, QuantParams qp, int cb, uint64_t* __restrict__ keys,
-                                      uint32_t* __restrict__ vals, int32_t* __restrict__ flags) {
+                                      uint32_t* __restrict__ vals, int32_t* __restrict__ flags, int idx_bits) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nn = scan_off[B];
   if (i == 0 && nn > n_cap) atomicOr(flags, 2);         // more points than the plan was reserved for
@@ -164,8 +166,12 @@ __global__ void points_to_keys_kernel(const float* __restrict__ pts, int64_t n_c
                   qz = finite ? min(max(cz, lo_c), hi) : 0;
     encode_key(lo, qx, qy, qz, cb, key);
   }
-  keys[i] = key;
-  vals[i] = (uint32_t)i;
+  if (idx_bits > 0) {
+    keys[i] = ((key & ((1ull << (3 * cb)) - 1)) << idx_bits) | (uint64_t)(i - scan_off[lo]);
+  } else {
+    keys[i] = key;
+    vals[i] = (uint32_t)i;
+  }
 }
 
 __global__ void coords_to_keys_kernel(const int32_t* __restrict__ c4, int64_t n, int cb, int Bmax,
@@ -790,18 +796,31 @@ int plan_sync(Ctx* ctx, hipStream_t stream) {
 // n_cap: rows the key buffers hold; n_dev (nullable): device-resident row count.  reserved = false: the level capacities
 // are the exact row counts (one host sync right after the pyramid); true: ctx->reserve_cap[] (no host sync at all).
 // seg_off (nullable): DEVICE scan offsets (B+1) when the rows arrive scan by scan (plans built from points)
+// measurement switch: the round-3 flat sort of (batch | Morton) keys also for plans built from points
+static bool plan_flat_sort() {
+  static const bool v = getenv("EGONN_FLAT_SORT") != nullptr;
+  return v;
+}
+// bits of the point index inside its scan that a packed sort element can carry next to the 3 * cb Morton bits (0 = pairs)
+static int plan_packed_idx_bits(int cb, int64_t n) {
+  static const bool off = getenv("EGONN_SORT_PAIRS") != nullptr;          // measurement switch: (key, value) pairs as in round 4
+  const int room = std::min(64 - 3 * cb, 30);
+  if (off || plan_flat_sort() || room < 1 || n >= (int64_t(1) << room)) return 0;
+  return room;
+}
+
 static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* vals_raw, uint64_t* keys_sorted,
                                         uint32_t* vals_sorted, int64_t n, const int64_t* n_dev, const int64_t* seg_off, int B,
-                                        bool reserved, hipStream_t stream) {
+                                        bool reserved, hipStream_t stream, int idx_bits = 0) {
   Plan& P = ctx->plan;
   const int cb = ctx->coord_bits;
   Arena& A = ctx->plan_arena;
   // (the sorted pairs land in whichever pair the last pass wrote: batches of 17-64 scans need six passes, an even number)
-  static const bool flat_sort = getenv("EGONN_FLAT_SORT") != nullptr;      // measurement switch: the round-3 flat sort
+  const bool flat_sort = plan_flat_sort();
   if (seg_off && !flat_sort) {
-    // plans built from points: the scans are contiguous, each is sorted on its Morton bits
+    // plans built from points: the scans are contiguous, each is sorted on its Morton bits (packed elements when they fit)
     EGONN_TRY(radix_sort_segments(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, seg_off, B, 3 * cb, stream, &keys_sorted,
-                                  &vals_sorted));
+                                  &vals_sorted, idx_bits));
   } else {
     EGONN_TRY(radix_sort_pairs(ctx, keys_raw, vals_raw, keys_sorted, vals_sorted, n, 3 * cb + batch_bits(B), stream, n_dev, &keys_sorted,
                                &vals_sorted));
@@ -1075,9 +1094,10 @@ int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets,
   ctx->plan.scan_off = doff;
   HIP_CHECK(hipMemsetAsync(ctx->dev_flags, 0, sizeof(int32_t), stream));
   QuantParams qp{mode, step[0], mode ? step[1] : step[0], mode ? step[2] : step[0]};
+  const int idx_bits = plan_packed_idx_bits(ctx->coord_bits, n);
   hipLaunchKernelGGL(points_to_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, points, n, doff, B, qp,
-                     ctx->coord_bits, k0, v0, ctx->dev_flags);
-  return build_plan_from_sorted_input(ctx, k0, v0, k1, v1, n, doff + B, doff, B, offsets_on_device != 0, stream);
+                     ctx->coord_bits, k0, v0, ctx->dev_flags, idx_bits);
+  return build_plan_from_sorted_input(ctx, k0, v0, k1, v1, n, doff + B, doff, B, offsets_on_device != 0, stream, idx_bits);
 }
 
 int plan_from_coords(Ctx* ctx, const int32_t* coords, int64_t n, int B, hipStream_t stream) {

@@ -342,10 +342,14 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_seg_hist_kernel(const uint64_
   }
 }
 
+// MODE 0: (key, value) pairs.  MODE 1 / 2: PACKED elements — one u64 = (Morton bits << idx_bits) | index of the point inside
+// its scan: 8 bytes per element and pass instead of 12 (round 5).  MODE 1 moves packed elements; MODE 2 is the last pass: it
+// writes the pair form the pyramid kernels read — key = (scan << key_bits) | Morton bits, value = first row of the scan + index.
+template <int MODE>
 __global__ __launch_bounds__(SORT_BLOCK) void sort_seg_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int64_t n_cap, const int64_t* __restrict__ off, int B, int shift,
-    const int32_t* __restrict__ tilehist, const int32_t* __restrict__ scanhist) {
+    const int32_t* __restrict__ tilehist, const int32_t* __restrict__ scanhist, int idx_bits, int key_bits) {
   __shared__ int32_t whist[SORT_WAVES][SEG_DIGITS];   // running per-wave digit counts
   __shared__ int32_t dbase[SEG_DIGITS];               // global base of every digit for this tile
   __shared__ int32_t delta[SEG_DIGITS];               // global position - local position, per digit
@@ -367,7 +371,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_seg_scatter_kernel(
     const int32_t i = wbase + r * 64 + lane;
     const bool valid = i < nk;
     k[r] = valid ? keys_in[k0 + i] : ~0ull;
-    v[r] = valid ? vals_in[k0 + i] : 0u;
+    if constexpr (MODE == 0) v[r] = valid ? vals_in[k0 + i] : 0u;
+    else v[r] = 0u;
   }
   // ---- global base of digit d (thread tid owns digits 2 tid, 2 tid + 1: a wave covers 128 consecutive digits)
   {
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_seg_scatter_kernel(
       const uint32_t d = (uint32_t)(k[r] >> shift) & (SEG_DIGITS - 1);
       const int32_t pos = whist[wave][d] + rank[r];
       lkey[pos] = k[r];
-      lval[pos] = v[r];
+      if constexpr (MODE == 0) lval[pos] = v[r];
     }
   }
   __syncthreads();
@@ -489,8 +494,15 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_seg_scatter_kernel(
     if (p < nk) {
       const uint64_t kk = lkey[p];
       const int64_t dst = (int64_t)delta[(uint32_t)(kk >> shift) & (SEG_DIGITS - 1)] + p;
-      keys_out[dst] = kk;
-      vals_out[dst] = lval[p];
+      if constexpr (MODE == 0) {
+        keys_out[dst] = kk;
+        vals_out[dst] = lval[p];
+      } else if constexpr (MODE == 1) {
+        keys_out[dst] = kk;
+      } else {
+        keys_out[dst] = ((uint64_t)scan << key_bits) | (kk >> idx_bits);
+        vals_out[dst] = (uint32_t)(kk & ((1ull << idx_bits) - 1)) + (uint32_t)min(off[scan], n_cap);
+      }
     }
   }
 }
@@ -502,10 +514,14 @@ size_t radix_sort_segments_scratch_bytes(int64_t n, int B) {
 
 // Sorts every scan [off[b], off[b+1]) of (keys, vals) on bits [0, nbits) of the key (stable).  off: DEVICE int64 (B+1), clipped
 // to n (the capacity the buffers and the grid are sized for).  Result: as radix_sort_pairs (keys_res / vals_res).
+// idx_bits > 0: keys_in holds PACKED elements (Morton bits << idx_bits | index inside the scan; vals_in is not read): every pass
+// but the last moves 8 bytes per element, the last one writes the (key | scan, value) pairs described above.
 int radix_sort_segments(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, int64_t n,
-                        const int64_t* off_dev, int B, int nbits, hipStream_t stream, uint64_t** keys_res, uint32_t** vals_res) {
+                        const int64_t* off_dev, int B, int nbits, hipStream_t stream, uint64_t** keys_res, uint32_t** vals_res,
+                        int idx_bits) {
   EGONN_REQUIRE(n >= 0 && n < (int64_t(1) << 31), EGONN_ERR_INVALID, "radix_sort: n=%lld out of range", (long long)n);
-  EGONN_REQUIRE(nbits >= 1 && nbits <= 64 && off_dev && B >= 1, EGONN_ERR_INVALID, "radix_sort_segments: bad arguments");
+  EGONN_REQUIRE(nbits >= 1 && nbits <= 64 && off_dev && B >= 1 && idx_bits >= 0 && nbits + idx_bits <= 64, EGONN_ERR_INVALID,
+                "radix_sort_segments: bad arguments");
   const int passes = (nbits + SEG_BITS - 1) / SEG_BITS;
   EGONN_REQUIRE(passes <= 8, EGONN_ERR_INVALID, "radix_sort_segments: %d passes", passes);
   *keys_res = keys_out;
@@ -523,10 +539,17 @@ int radix_sort_segments(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t
   int src = 0;
   for (int p = 0; p < passes; ++p) {
     int32_t* sh = scanhist + (int64_t)p * B * SEG_DIGITS;
-    const int shift = SEG_BITS * p;
+    const int shift = SEG_BITS * p + idx_bits;
     hipLaunchKernelGGL(sort_seg_hist_kernel, dim3((unsigned)tiles), dim3(SORT_BLOCK), 0, stream, kb[src], n, off_dev, B, shift, tilehist, sh);
-    hipLaunchKernelGGL(sort_seg_scatter_kernel, dim3((unsigned)tiles), dim3(SORT_BLOCK), 0, stream, kb[src], vb[src], kb[src ^ 1],
-                       vb[src ^ 1], n, off_dev, B, shift, tilehist, sh);
+    if (idx_bits == 0)
+      hipLaunchKernelGGL(sort_seg_scatter_kernel<0>, dim3((unsigned)tiles), dim3(SORT_BLOCK), 0, stream, kb[src], vb[src], kb[src ^ 1],
+                         vb[src ^ 1], n, off_dev, B, shift, tilehist, sh, 0, nbits);
+    else if (p + 1 < passes)
+      hipLaunchKernelGGL(sort_seg_scatter_kernel<1>, dim3((unsigned)tiles), dim3(SORT_BLOCK), 0, stream, kb[src], vb[src], kb[src ^ 1],
+                         vb[src ^ 1], n, off_dev, B, shift, tilehist, sh, idx_bits, nbits);
+    else
+      hipLaunchKernelGGL(sort_seg_scatter_kernel<2>, dim3((unsigned)tiles), dim3(SORT_BLOCK), 0, stream, kb[src], vb[src], kb[src ^ 1],
+                         vb[src ^ 1], n, off_dev, B, shift, tilehist, sh, idx_bits, nbits);
     src ^= 1;
   }
   *keys_res = kb[src];                                    // whichever pair the last pass wrote
