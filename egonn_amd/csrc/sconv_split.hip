@@ -490,7 +490,7 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
   a.K = rg.K; a.relu = relu ? 1 : 0; a.cap_groups = rg.cap_groups;
   if (cfg == 0) cfg = sconv_split_default_cfg(cin, cout, groups_hint);
   const bool trace = cfg >= 9000;                        // 9000 + shape: the s_memtime build (tools/split_trace.py)
-  int shape = cfg % 1000;
+  int shape = trace ? cfg - 9000 : cfg;
   int parts_sel = 0;
   if (shape >= 500) { parts_sel = shape / 400; shape -= 400 * parts_sel; }
   const int ns_tot = cout / 32;
@@ -498,7 +498,8 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
   if (parts_sel > 0) parts = std::min(ns_tot, 1 << (parts_sel - 1));
   else if (ns_tot >= 2 && cdiv(groups_hint, 4) < 700) {  // less than one round of the chip: two column parts per task
     parts = 2;                                           // (measured, profiles/r03i_colparts.txt: L4 128->128 101 / 80 / 93 us
-  }                                                      //  with 1 / 2 / 4 parts, 64->128 56 / 45 / 51, L3 64->64 43 / 41)
+  }                                                      //  with 1 / 2 / 4 parts, 64->128 56 / 45 / 51, L3 64->64 43 / 41; round 5, fp16 kernels:
+                                                         //  4 parts change neither the layers (profiles/r05g_parts4.txt) nor scans/s)
   const int nsw = ns_tot / parts;
 #define EGONN_SP_LOCK1(CI, CO, NWW, NSWW)                                                                 \
   if (cin == CI && cout == CO && shape == 100 + NWW * 10 + 2 && nsw == NSWW && !trace)                    \
