@@ -109,6 +109,53 @@ def test_quantizer_random_cloud_vs_oracle(gpu):
         assert np.array_equal(_np(c)[perm], oc) and np.array_equal(_np(i)[perm], oi)
 
 
+@pytest.mark.parametrize("cb,n_scans,max_pts", [(13, 7, 3000), (10, 64, 3000), (12, 64, 3000), (15, 64, 3000), (16, 5, 40000),
+                                                (11, 1, 5000), (12, 3, 0)])
+def test_batched_voxelize_segmented_sort_variants(gpu, cb, n_scans, max_pts):
+    """The segmented radix sort of plans built from points (csrc/sort.hip), through the C ABI: odd and even pass counts
+    (3 * coord_bits key bits, 9 per pass: 4 / 5 / 6 passes), 64 scans with empty ones in front, in the middle and at the end,
+    PACKED elements (Morton bits | index in scan: whenever the point count fits the spare bits) and (key, value) pairs
+    (coord_bits 16 with more than 65 536 points), an all-empty-but-one batch.  Per scan: the voxel set and the first-point index
+    of every voxel against the reference restatement (datasets/quantization.py:79-85 -> ME sparse_quantize)."""
+    from egonn_amd import _lib
+    from oracle import me_ops as ops
+    dev = _lib.require_gpu()
+    rng = np.random.default_rng(1000 * cb + n_scans)
+    lim = min(0.1 * ((1 << (cb - 1)) - 2), 60.0)
+    sizes = rng.integers(0, max_pts + 1, size=n_scans) if max_pts > 0 else np.zeros(n_scans, np.int64)
+    if n_scans >= 7:
+        sizes[[0, 3, n_scans - 1]] = 0                      # empty scans in front, inside, at the end
+    if max_pts == 0:
+        sizes[1] = 257                                      # all scans empty but one
+    if cb == 16:
+        sizes[:] = max_pts                                  # 200 000 points: beyond the 16 spare bits -> (key, value) pairs
+    scans = []
+    for n in sizes:
+        p = rng.uniform(-lim, lim, size=(int(n), 3)).astype(np.float32)
+        p[:, 2] = rng.uniform(-min(lim, 3.0), min(lim, 8.0), size=int(n))
+        if n > 10:
+            p[5:10] = p[0:5]                                # exact duplicates: the FIRST point of a voxel wins
+        scans.append(p)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ctx = _lib.Context(dev, coord_bits=cb)
+    allp = np.concatenate(scans) if off[-1] > 0 else np.zeros((0, 3), np.float32)
+    ctx.voxelize(torch.from_numpy(np.ascontiguousarray(allp)).to(dev), off.tolist(), 0, [0.1])
+    coords = _np(ctx.level_coords(0))
+    first = _np(ctx.input_index())
+    boff = ctx.level_batch_offsets(0)
+    assert boff[0] == 0 and boff[-1] == len(coords)
+    for b in range(n_scans):
+        c, f = coords[boff[b]:boff[b + 1]], first[boff[b]:boff[b + 1]]
+        oc, oi = (ops.sparse_quantize(scans[b], 0.1) if len(scans[b]) else (np.zeros((0, 3), np.int32), np.zeros((0,), np.int64)))
+        assert len(c) == len(oc), (b, len(c), len(oc))
+        if len(c) == 0:
+            continue
+        assert (c[:, 0] == b).all()
+        perm = H.join_perm(c, np.c_[np.full(len(oc), b, np.int32), oc])
+        assert np.array_equal(c[perm][:, 1:], oc)
+        assert np.array_equal(f[perm], oi)                  # first point of every voxel, as an index into its scan
+
+
 # ------------------------------------------------------------------------------------ coordinate pyramid (a3)
 @pytest.mark.parametrize("name", H.CASES)
 def test_pyramid_matches_reference(gpu, name):
