@@ -194,6 +194,8 @@ struct Ctx {
   int split_max_level = 5;    // fp32 sparse convs whose output level is <= this run on the fp16-split kernels (sconv_split.hip);
                               // round 5: 4 -> 5 (profiles/r05b_tail_kernel.txt: 25.2 k -> 26.4 k scans/s with four batches in flight; the
                               // level-5 launches alone get slower, one-batch graph latency 1.17 -> 1.23 ms — the headline metric is scans/s)
+  int split_io = 0;           // set by egonn_forward around ONE sconv_map call: bit 0 = the input map is in split form (fp16 hi | lo
+                              // per 32-channel block, sconv_split.hip), bit 1 = write the output in split form
   int conv_variant = 0;       // tests / A-B measurements only (egonn_debug_set_naive_conv): 0 = product choice, 1 = per-wave
                               // MFMA kernel, 2 = workgroup-cooperative MFMA kernel, 3 = plain one-thread-per-output kernel
   Arena plan_arena;           // keys, maps (lives until the next plan)

@@ -865,6 +865,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
                                   (flags & EGONN_FLAG_IGNORE_KP_REGRESSOR) ? 1 : 0, out_desc, out_kp, out_sigma, st));
     return EGONN_OK;
   };
+  static const bool presplit_ok = getenv("EGONN_NO_PRESPLIT") == nullptr;     // measurement switch: conv2 splits in its loop
   // levels 5-7 + global head + decoder + pooling: one resident launch for fp32 maps (tail.hip)
   const bool use_tail = !bf16 && c->tail_mode == 0 && c->conv_variant == 0 && m->t_m1 != nullptr && B <= EGONN_MAX_BATCH;
   bool tail_done = false;
@@ -940,12 +941,19 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     DBG_SYNC("L%d k2s2", i);
     // ECABasicBlock (layers/eca_block.py:56-73)
     FALLOC(t1, n * b.cout);
+    // conv1's output has ONE reader, conv2: when both run on the split kernel, conv1's epilogue writes it in split form (the
+    // fp16 hi | lo operands conv2 would otherwise make of every gathered fragment in its step loop; sconv_split.hip)
+    const bool t1_split = presplit_ok && sconv_uses_split(b.cin, b.cout, bf16, i, c->conv_variant, c->split_max_level) &&
+                          sconv_uses_split(b.cout, b.cout, bf16, i, c->conv_variant, c->split_max_level);
     {
       snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv1", sconv_kernel_name(c, 0, i, b.cin, b.cout, bf16),
                b.cin, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cin, b.cout, (int)es);
-      EGONN_TRY(sconv_map(c, 0, i, y, nullptr, bf16 ? m->q_c1[i] : m->p_c1[i], m->s_c1[i], b.cin, b.cout, bf16, b.n1.scale, b.n1.shift, 1, t1,
-                          nullptr, nullptr, 0, st));
+      c->split_io = t1_split ? 2 : 0;
+      const int rc = sconv_map(c, 0, i, y, nullptr, bf16 ? m->q_c1[i] : m->p_c1[i], m->s_c1[i], b.cin, b.cout, bf16, b.n1.scale, b.n1.shift, 1, t1,
+                               nullptr, nullptr, 0, st);
+      c->split_io = 0;
+      EGONN_TRY(rc);
     }
     FALLOC(t2, n * b.cout);
     WALLOC(psum, (size_t)L.rg27.cap_groups * b.cout);
@@ -953,8 +961,11 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
       snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k3.conv2", sconv_kernel_name(c, 0, i, b.cout, b.cout, bf16),
                b.cout, b.cout, i);
       ProfScope ps(c, st, tag, PK_K3, i, 27, b.cout, b.cout, (int)es);
-      EGONN_TRY(sconv_map(c, 0, i, t1, nullptr, bf16 ? m->q_c2[i] : m->p_c2[i], m->s_c2[i], b.cout, b.cout, bf16, b.n2.scale, b.n2.shift, 0, t2,
-                          psum, nullptr, 0, st));
+      c->split_io = t1_split ? 1 : 0;
+      const int rc = sconv_map(c, 0, i, t1, nullptr, bf16 ? m->q_c2[i] : m->p_c2[i], m->s_c2[i], b.cout, b.cout, bf16, b.n2.scale, b.n2.shift, 0, t2,
+                               psum, nullptr, 0, st);
+      c->split_io = 0;
+      EGONN_TRY(rc);
     }
     WALLOC(gate, (size_t)B * b.cout);
     DBG_SYNC("L%d convs", i);

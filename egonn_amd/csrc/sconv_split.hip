@@ -135,6 +135,11 @@ struct SplitArgs {
   float* psum;               // [groups][COUT] column sums of the stored values (nullable)
   uint32_t in_rows, w_bytes;
   int K, relu, cap_groups;
+  int in_split, out_split;   // the input / output map is in SPLIT FORM: per row and 32-channel block the 128 bytes hold the fp16 hi
+                             // parts (chunk g = channels sp_chan(g, 0..7)) and lo parts (chunk 4 + g) the consumer's MFMA operands
+                             // are made of, instead of 32 fp32 values.  Same size, same gather; the consumer's in-loop split
+                             // (24 vector instructions per 16 x 32 fragment) moves into the producer's epilogue.  hi / lo are
+                             // computed by the same split8h either way: results are bitwise those of fp32 maps.
   unsigned long long* trace = nullptr;   // measurement builds only (tools/split_trace.py): 12 u64 per wave task
 };
 
@@ -327,7 +332,8 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1)::"memory");
       wwait(w);
       f16x8_t ah, al;
-      split8h(ra0, ra1, ah, al);
+      if (p.in_split) { ah = __builtin_bit_cast(f16x8_t, ra0); al = __builtin_bit_cast(f16x8_t, ra1); }   // (uniform branch)
+      else split8h(ra0, ra1, ah, al);
       [&]<int... NSI>(std::integer_sequence<int, NSI...>) {
         (([&] {
            f32x4 wn[4];
@@ -392,6 +398,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
         float sums[2][4];
+        f32x4 vv[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const int c0 = (ns0 + ns) * 32 + nt * 16 + 4 * g4;
@@ -405,9 +412,18 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
           }
-          if (row >= 0) *reinterpret_cast<f32x4*>(p.out + (int64_t)row * COUT + c0) = v;
+          if (row >= 0 && !p.out_split) *reinterpret_cast<f32x4*>(p.out + (int64_t)row * COUT + c0) = v;
+          vv[nt] = v;
 #pragma unroll
           for (int u = 0; u < 4; ++u) sums[nt][u] = row >= 0 ? v[u] : 0.f;
+        }
+        if (p.out_split && row >= 0) {
+          // this lane holds exactly the eight channels sp_chan(g4, 0..7) of its row: columns 4 g4.. of tile 0 and of tile 1
+          f16x8_t oh, ol;
+          split8h(vv[0], vv[1], oh, ol);
+          char* o = reinterpret_cast<char*>(p.out) + ((int64_t)row * COUT + (ns0 + ns) * 32) * 4 + 16 * g4;
+          *reinterpret_cast<f16x8_t*>(o) = oh;
+          *reinterpret_cast<f16x8_t*>(o + 64) = ol;
         }
         if (p.psum) {
 #pragma unroll
@@ -474,7 +490,7 @@ bool sconv_split_supported(int cin, int cout) {
 // cfg = 100 + NW * 10 + 2 [+ 400 * (1 + log2(column parts))]; 0 = product choice (142: workgroups of 4 waves, automatic parts)
 int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
                         int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
-                        int cfg) {
+                        int cfg, int split_io) {
   EGONN_REQUIRE(rg.built, EGONN_ERR_STATE, "sconv: row-group tables not built");
   EGONN_REQUIRE(sconv_split_supported(cin, cout), EGONN_ERR_INVALID, "sconv(split): channel plan %d->%d not supported", cin, cout);
   EGONN_REQUIRE((uint64_t)n_in_cap * cin * 4 < (1ull << 32) - (1ull << 20), EGONN_ERR_INVALID,
@@ -488,6 +504,8 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
   a.in_rows = (uint32_t)n_in_cap;
   a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * 4);           // the fragments; the pack scale's inverse sits right behind them
   a.K = rg.K; a.relu = relu ? 1 : 0; a.cap_groups = rg.cap_groups;
+  a.in_split = (split_io & 1) ? 1 : 0;
+  a.out_split = (split_io & 2) ? 1 : 0;
   if (cfg == 0) cfg = sconv_split_default_cfg(cin, cout, groups_hint);
   const bool trace = cfg >= 9000;                        // 9000 + shape: the s_memtime build (tools/split_trace.py)
   int shape = trace ? cfg - 9000 : cfg;
