@@ -249,6 +249,16 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const void* __restrict
   }
 }
 
+// sample (scan) of row r: last b with boff[b] <= r
+__device__ static inline int sample_of_row(const int32_t* __restrict__ boff, int B, int32_t r) {
+  int lo = 0, hi = B;   // boff[lo] <= r < boff[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (boff[mid] <= r) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 // The same product with the weights staged ONCE per workgroup into LDS as MFMA fragments
 //   frag[(nt * CIN/16 + t) * 64 + lane] = W(col = 16 nt + (lane & 15), ci = 16 t + 4 (lane >> 4) .. +3)
 // (whatever the caller's layout), workgroups persistent over the row tiles, operands swapped (D^T = W^T A^T) so that lane
@@ -262,7 +272,8 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const void* __restrict__
                                                         const float* __restrict__ bias, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int act,
                                                         const void* __restrict__ residual_v, void* __restrict__ out_v, int io,
-                                                        const int32_t* __restrict__ n_dev, int colblk) {
+                                                        const int32_t* __restrict__ n_dev, int colblk,
+                                                        const float* __restrict__ gate, const int32_t* __restrict__ boff, int B) {
   extern __shared__ __attribute__((aligned(16))) f32x4 dl_frags[];
   if (n_dev) n = min((int64_t)*n_dev, n);
   constexpr int KS = CIN / 16;
@@ -325,6 +336,9 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const void* __restrict__
     const int64_t row = tile * 16 + l15;
     const bool ok = row < n;
     load_rows(tile + tstep, an);                             // next tile's rows in flight while this one is computed
+    // gate != null: the ECA tail of a block with a 1x1 downsample branch (layers/eca_block.py:66-73) fused into this launch —
+    // out = relu(residual * gate[sample of the row] + this layer's output): the downsample output never goes to memory
+    const int64_t gbase = (gate && ok) ? (int64_t)sample_of_row(boff, B, (int32_t)row) * cout : 0;
     for (int nt = 0; nt < NT; ++nt) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const f32x4* fr = dl_frags + (int64_t)nt * KS * 64 + lane;
@@ -341,11 +355,23 @@ __global__ __launch_bounds__(256) void dense_lds_kernel(const void* __restrict__
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = apply_act(v[u], act);
         if (residual_v) {
+          f32x4 r;
           if (io & 1) {
             const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(residual_v) + row * cout + c0);
-            v += (f32x4){bf2f(h.x & 0xFFFFu), bf2f(h.x >> 16), bf2f(h.y & 0xFFFFu), bf2f(h.y >> 16)};
+            r = (f32x4){bf2f(h.x & 0xFFFFu), bf2f(h.x >> 16), bf2f(h.y & 0xFFFFu), bf2f(h.y >> 16)};
           } else {
-            v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(residual_v) + row * cout + c0);
+            r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(residual_v) + row * cout + c0);
+          }
+          if (gate) {
+            const f32x4 gq = *reinterpret_cast<const f32x4*>(gate + gbase + c0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              // (bf16 maps: the downsample output was a bf16 map between the two launches this replaces; same rounding here)
+              const float d = (io & 2) ? bf2f(f2bf_rn(v[u])) : v[u];
+              v[u] = fmaxf(r[u] * gq[u] + d, 0.f);           // the expression of eca_apply_kernel
+            }
+          } else {
+            v += r;
           }
         }
         if (io & 2) {
@@ -374,10 +400,19 @@ __global__ void dense_any_kernel(const float* __restrict__ in, int64_t total, in
   out[i] = apply_act(s, act);
 }
 
+// true: dense_forward_ex(..., gate, boff, B) can fuse the gated-residual ECA tail for this shape (the LDS-staged kernel runs it)
+bool dense_gate_fusable(int64_t n, int cin, int cout) {
+  const bool plan = cin == 32 || cin == 64 || cin == 96 || cin == 128 || cin == 192 || cin == 256;
+  return plan && cout % 16 == 0 && n >= 8192 && (size_t)cin * cout * sizeof(float) <= 96 * 1024;
+}
+
 int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const float* W, int w_out_in, int cout,
                      const float* bias, const float* scale, const float* shift, int act, const void* residual, int res_bf16,
-                     void* out, int out_bf16, hipStream_t stream, const int32_t* n_dev) {
+                     void* out, int out_bf16, hipStream_t stream, const int32_t* n_dev, const float* gate, const int32_t* boff,
+                     int B) {
   if (n == 0) return EGONN_OK;
+  EGONN_REQUIRE(!gate || (residual && boff && B >= 1 && dense_gate_fusable(n, cin, cout)), EGONN_ERR_INVALID,
+                "dense: the fused gated residual needs the LDS-staged kernel (%lld rows, %d->%d)", (long long)n, cin, cout);
   const dim3 grid((unsigned)cdiv(n, 64), (unsigned)cdiv(cout, 64));
   const int io = (res_bf16 ? 1 : 0) | (out_bf16 ? 2 : 0);
   const size_t frag_bytes = (size_t)cin * cout * sizeof(float);
@@ -400,7 +435,7 @@ int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const floa
       attr_done.mark();                                                                                                \
     }                                                                                                                 \
     hipLaunchKernelGGL((dense_lds_kernel<WOI, CI, INB>), dim3(g1, ny), dim3(256), blk_bytes + 3 * (size_t)colblk * sizeof(float), stream, in, n, W, cout, bias, scale, \
-                       shift, act, residual, out, io, n_dev, colblk);                                                 \
+                       shift, act, residual, out, io, n_dev, colblk, gate, boff, B);                                  \
   }
 #define EGONN_DENSE_LDS_CASE(CI)                                                                                      \
   if (cin == CI) {                                                                                                    \
@@ -553,14 +588,6 @@ __global__ void eca_gate_kernel(const float* __restrict__ partial, const int32_t
   }
 }
 
-__device__ static inline int sample_of_row(const int32_t* __restrict__ boff, int B, int32_t r) {
-  int lo = 0, hi = B;   // boff[lo] <= r < boff[hi]
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (boff[mid] <= r) lo = mid; else hi = mid;
-  }
-  return lo;
-}
 
 // thread = 16 bytes of a row (4 fp32 or 8 bf16 channels): full-width accesses for both precisions (8-byte accesses run at
 // 0.5-0.7 of the 16-byte rate); cq = channels / (16 bytes' worth) is a power of two

@@ -76,9 +76,11 @@ int dense_forward(const float* in, int64_t n, int cin, const float* W, int w_out
                   const float* scale, const float* shift, int act, const float* residual, float* out,
                   hipStream_t stream);
 // the same with bf16 feature maps on any of the three row operands (weights and arithmetic stay fp32)
+bool dense_gate_fusable(int64_t n, int cin, int cout);
 int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const float* W, int w_out_in, int cout,
                      const float* bias, const float* scale, const float* shift, int act, const void* residual, int res_bf16,
-                     void* out, int out_bf16, hipStream_t stream, const int32_t* n_dev = nullptr);
+                     void* out, int out_bf16, hipStream_t stream, const int32_t* n_dev = nullptr, const float* gate = nullptr,
+                     const int32_t* boff = nullptr, int B = 0);   // gate: out = relu(residual * gate[sample][col] + layer output)
 int bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps, int c, float* scale,
             float* shift, hipStream_t stream);
 // n_dev (nullable, here and below): device-resident row count (<= n); n then only sizes the grid

@@ -972,14 +972,23 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     EGONN_TRY(eca_gate_groups(psum, L.rg27, L.boff, B, b.cout, b.eca, b.eca_k, gate, st));
     DBG_SYNC("L%d eca gate", i);
     const void* res = y;
-    if (b.down) {
-      FALLOC(rd, n * b.cout);
-      EGONN_TRY(dense_forward_ex(y, bf16, n, b.cin, b.down, 0, b.cout, nullptr, b.dn.scale, b.dn.shift, ACT_NONE, nullptr, 0, rd,
-                                 bf16, st, cnt + i));
-      res = rd;
-    }
     FALLOC(xo, n * b.cout);
-    EGONN_TRY(eca_apply_gate(t2, res, gate, L.boff, B, n, b.cout, xo, bf16, st));
+    static const bool fuse_down = getenv("EGONN_NO_FUSED_DOWN") == nullptr;      // measurement switch
+    if (b.down && fuse_down && dense_gate_fusable(n, b.cin, b.cout)) {
+      // blocks with a 1x1 downsample branch (levels 2 and 4): the branch, its BatchNorm and the gated residual + ReLU of the block's
+      // tail in ONE launch — out = relu(t2 * gate[scan] + bn(y @ Wd)); the branch output never goes to memory (bitwise the result
+      // of the two launches it replaces)
+      EGONN_TRY(dense_forward_ex(y, bf16, n, b.cin, b.down, 0, b.cout, nullptr, b.dn.scale, b.dn.shift, ACT_NONE, t2, bf16, xo,
+                                 bf16, st, cnt + i, gate, L.boff, B));
+    } else {
+      if (b.down) {
+        FALLOC(rd, n * b.cout);
+        EGONN_TRY(dense_forward_ex(y, bf16, n, b.cin, b.down, 0, b.cout, nullptr, b.dn.scale, b.dn.shift, ACT_NONE, nullptr, 0, rd,
+                                   bf16, st, cnt + i));
+        res = rd;
+      }
+      EGONN_TRY(eca_apply_gate(t2, res, gate, L.boff, B, n, b.cout, xo, bf16, st));
+    }
     DBG_SYNC("L%d eca apply", i);
     x[i] = xo;
     c->level_feat[i] = xo;

@@ -1,5 +1,7 @@
-"""conv1 -> conv2 through the split-form map (sconv_split.hip, egonn_forward) against the in-loop split (EGONN_NO_PRESPLIT=1):
-the two must be BITWISE equal (the same split8h makes the hi / lo parts either way).  Runs itself twice in subprocesses."""
+"""Fusions of egonn_forward that must not change a bit, each against its measurement switch (runs itself in subprocesses):
+  EGONN_NO_PRESPLIT=1    conv2 splits its operands in the step loop instead of reading conv1's split-form output (sconv_split.hip)
+  EGONN_NO_FUSED_DOWN=1  1x1 downsample branch + BatchNorm and the gated residual + ReLU as two launches instead of one (dense.hip)
+fp32 maps (4 scans) and bf16 maps."""
 import os, subprocess, sys, hashlib
 import numpy as np
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -15,6 +17,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(7, shapes).items()})
     m = m.to("cuda").eval()
     m.coord_bits = 12
+    m.precision = os.environ.get("CHECK_PRECISION", "fp32")
     scans = [lidar_scan(300 + i, 50000) for i in range(4)]
     off = [0]
     for s in scans:
@@ -27,14 +30,20 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     for l in (1, 2, 3, 4, 5):
         ctx = m.context(0)
         h.update(ctx.forward_level_features(l, [0, 32, 64, 64, 128, 128][l]).cpu().numpy().tobytes())
+        torch.cuda.synchronize()
     print("DIGEST", h.hexdigest())
 else:
-    d = []
-    for env in ({}, {"EGONN_NO_PRESPLIT": "1"}):
-        r = subprocess.run([sys.executable, __file__, "child"], capture_output=True, text=True, env=dict(os.environ, **env))
-        line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")]
-        assert line, r.stderr[-2000:]
-        d.append(line[0])
-        print(env, line[0])
-    print("bitwise equal:", d[0] == d[1])
-    sys.exit(0 if d[0] == d[1] else 1)
+    ok = True
+    for prec in ("fp32", "bf16"):
+        d = []
+        for env in ({}, {"EGONN_NO_PRESPLIT": "1"}, {"EGONN_NO_FUSED_DOWN": "1"}):
+            r = subprocess.run([sys.executable, __file__, "child"], capture_output=True, text=True,
+                               env=dict(os.environ, CHECK_PRECISION=prec, **env))
+            line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")]
+            assert line, r.stderr[-2000:]
+            d.append(line[0])
+            print(prec, env, line[0])
+        same = len(set(d)) == 1
+        print(prec, "bitwise equal:", same)
+        ok &= same
+    sys.exit(0 if ok else 1)

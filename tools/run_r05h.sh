@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-python tools/check_presplit.py 2>&1 | tail -3
+python tools/check_bitwise_switches.py 2>&1 | tail -3
 python -m pytest tests -m gpu -x -q > gpurun_out/r05h_tests.log 2>&1; echo "tests rc=$?" ; tail -3 gpurun_out/r05h_tests.log
 for v in "" "EGONN_NO_PRESPLIT=1"; do
 env $v python bench.py --no-extras --no-cpu-baseline --repeats 3 --layer-table gpurun_out/r05h_layers_${v:-presplit}.json 2>/dev/null | python -c "
