@@ -889,6 +889,8 @@ int keypoint_positions(const uint64_t* keys, int64_t n, int level, int cb, const
 // 16t + 4g + u), i.e. the MLPs chain in registers.  Weights are read in nn.Linear (out,in) layout, one float4 per lane.
 struct LocalHeadsArgs {
   const float* x;                                          // (n, 64)
+  const float *lw, *lres;                                  // non-null: the head's lateral 1x1 convolution runs here first —
+                                                           // x := x @ lw + lres (lw (64,64) in (cin, cout) layout, lres (n,64))
   const float *dw0, *db0, *dw1, *db1;                      // descriptor decoder: (96,64),(96),(128,96),(128)
   const float *kw0, *kb0, *kw1, *kb1;                      // keypoint regressor: (32,64),(32),(3,32),(3)
   const float *sw0, *sb0, *sw1, *sb1;                      // sigma regressor:    (32,64),(32),(1,32),(1)
@@ -932,6 +934,17 @@ __device__ static inline void mlp_layer(const f32x4* __restrict__ frags, const f
     __builtin_amdgcn_sched_barrier(0);                   // keep the fragment reads of later tiles from being hoisted (spills)
   }
 }
+// the same staging for a (cin, cout)-layout matrix (1x1 convolution kernels): frag = W[16 t + 4 (lane >> 4) .. +3][16 nt + (lane & 15)]
+template <int CIN, int NT>
+__device__ static inline void stage_frags_t(const float* __restrict__ W, int cout, f32x4* __restrict__ dst, int tid, int nthreads) {
+  constexpr int T = CIN / 16;
+  for (int i = tid; i < NT * T * 64; i += nthreads) {
+    const int lane = i & 63, ft = i >> 6;
+    const int nt = ft / T, t = ft - nt * T;
+    const float* wp = W + (int64_t)(16 * t + 4 * (lane >> 4)) * cout + 16 * nt + (lane & 15);
+    dst[i] = (f32x4){wp[0], wp[cout], wp[2 * (int64_t)cout], wp[3 * (int64_t)cout]};
+  }
+}
 constexpr int LH_WAVES = 8;
 constexpr int LH_F_DW0 = 0, LH_F_DW1 = LH_F_DW0 + 6 * 4, LH_F_KW0 = LH_F_DW1 + 8 * 6, LH_F_KW1 = LH_F_KW0 + 2 * 4,
               LH_F_SW0 = LH_F_KW1 + 1 * 2, LH_F_SW1 = LH_F_SW0 + 2 * 4, LH_FRAGS = LH_F_SW1 + 1 * 2;      // 92 fragments of 1 KB
@@ -945,6 +958,7 @@ __global__ __launch_bounds__(LH_WAVES * 64) void local_heads_kernel(const LocalH
   stage_frags<32, 1>(p.kw1, 3, lh_frags + LH_F_KW1 * 64, tid, LH_WAVES * 64);
   stage_frags<64, 2>(p.sw0, 32, lh_frags + LH_F_SW0 * 64, tid, LH_WAVES * 64);
   stage_frags<32, 1>(p.sw1, 1, lh_frags + LH_F_SW1 * 64, tid, LH_WAVES * 64);
+  if (p.lw) stage_frags_t<64, 4>(p.lw, 64, lh_frags + LH_FRAGS * 64, tid, LH_WAVES * 64);
   __syncthreads();
   int64_t n = p.n;
   if (p.n_dev) n = min((int64_t)*p.n_dev, n);
@@ -956,6 +970,18 @@ __global__ __launch_bounds__(LH_WAVES * 64) void local_heads_kernel(const LocalH
 #pragma unroll
     for (int t = 0; t < 4; ++t)
       x[t] = ok ? *reinterpret_cast<const f32x4*>(p.x + row * 64 + 16 * t + 4 * g4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.lw) {
+      // ---- MinkHead's last lateral (models/minkgl.py:46-60): conv1x1(x3) + the transposed convolution's output, in the
+      //      accumulation order of the dense kernel it replaces (bitwise the same rows); the 64-channel map the three heads read
+      //      never goes to memory
+      f32x4 r[4], l[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        r[t] = ok ? *reinterpret_cast<const f32x4*>(p.lres + row * 64 + 16 * t + 4 * g4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      mlp_layer<64, 4>(lh_frags + LH_FRAGS * 64, x, lane, l);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) x[t] = l[t] + r[t];
+    }
     // ---- descriptor decoder + L2 normalisation
     {
       f32x4 h[6], o[8];
@@ -1021,10 +1047,13 @@ __global__ __launch_bounds__(LH_WAVES * 64) void local_heads_kernel(const LocalH
 }
 int local_heads_forward(const float* x, int64_t n, const int32_t* n_dev, const float* const* w /*12 pointers*/,
                         const uint64_t* keys, int level, int cb, int mode, const float* step, int ignore_offsets,
-                        float* out_desc, float* out_kp, float* out_sigma, hipStream_t stream) {
+                        float* out_desc, float* out_kp, float* out_sigma, hipStream_t stream, const float* lateral_w,
+                        const float* lateral_res) {
   if (n == 0) return EGONN_OK;
+  EGONN_REQUIRE((lateral_w == nullptr) == (lateral_res == nullptr), EGONN_ERR_INVALID, "local heads: lateral kernel and residual go together");
   LocalHeadsArgs a;
   a.x = x; a.n = n; a.n_dev = n_dev;
+  a.lw = lateral_w; a.lres = lateral_res;
   a.dw0 = w[0]; a.db0 = w[1]; a.dw1 = w[2]; a.db1 = w[3];
   a.kw0 = w[4]; a.kb0 = w[5]; a.kw1 = w[6]; a.kb1 = w[7];
   a.sw0 = w[8]; a.sb0 = w[9]; a.sw1 = w[10]; a.sb1 = w[11];
@@ -1032,7 +1061,7 @@ int local_heads_forward(const float* x, int64_t n, const int32_t* n_dev, const f
   a.s0 = step[0]; a.s1 = mode ? step[1] : step[0]; a.s2 = mode ? step[2] : step[0];
   a.out_desc = out_desc; a.out_kp = out_kp; a.out_sigma = out_sigma;
   const int64_t tiles = cdiv(n, 16);
-  const size_t lds = (size_t)LH_FRAGS * 64 * sizeof(f32x4);
+  const size_t lds = (size_t)(LH_FRAGS + (lateral_w ? 16 : 0)) * 64 * sizeof(f32x4);
   static AttrOnce attr_done;
   if (attr_done.need()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&local_heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
