@@ -543,6 +543,8 @@ __global__ __launch_bounds__(256) void nbr27_kernel(const Nbr27Pair a) {
   // of latencies at full occupancy (a block has ~6 voxels), so the number of dependent trips is its run time.
   // (Measured and rejected: persistent workgroups with the loads issued one block ahead and a (position, offset) lookup
   // table in LDS — 70 vs 62 us per step at batch 16, 136 vs 143 at batch 64.)
+  // (Round 5, also rejected: two blocks per wave — lanes 0-26 / 32-58 fetch two adjacency rows together: 52 -> 59 us per step;
+  // with 32 waves per CU the two round trips are hidden already, what counts is the item loop, which then runs twice per wave.)
   // (clamped: when level `level` overflows its reservation but level + 2 does not, bstart still holds unclipped rows
   //  and the table write below would leave the cap_vox x 27 allocation)
   const int32_t s = min(bstart[j], nvox);
