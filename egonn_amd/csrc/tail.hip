@@ -529,7 +529,12 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const TailArgs a) {
             if (t < 16) {
               const int rem = j - t * ppt, k = rem >> 2, s0 = (rem & 3) * 4;
               uint16_t* dst = reinterpret_cast<uint16_t*>(s_tbl + (k * 16 + s0) * TL_TBL_ROW) + t;
-              auto rel = [&](int32_t row) { return (uint16_t)(row < 0 ? 0xFFFF : min(row - q.row0, 0xFFFE)); };
+              // (a scan with more than 65 534 rows at the input level does not fit the 16-bit entries: flagged like a timed-out
+              //  wait — bit 2 of the plan's flag word, egonn_plan_status — instead of silently reading a wrong row)
+              auto rel = [&](int32_t row) {
+                if (row - q.row0 > 0xFFFE) atomicOr(a.err, 4);
+                return (uint16_t)(row < 0 ? 0xFFFF : min(row - q.row0, 0xFFFE));
+              };
               dst[0] = rel(tv[u].x); dst[TL_TBL_ROW / 2] = rel(tv[u].y); dst[TL_TBL_ROW] = rel(tv[u].z); dst[3 * TL_TBL_ROW / 2] = rel(tv[u].w);
             }
           }
