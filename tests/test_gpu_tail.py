@@ -1,8 +1,8 @@
 """GPU tests of the resident tail kernel (csrc/tail.hip): levels 5-7 of MinkTrunk + MinkHead + descriptor decoder + pooling
 (models/minkgl.py:136-153, 46-60, 207-225; layers/pooling.py:29-86) in ONE launch, against the per-layer launches of the same
 library (egonn_debug_set_tail(1)) — the two paths differ by summation order only — and against itself (bitwise: reruns,
-batch invariance, eager vs graph, scans too large / too small for the staging rounds).  The fixture / oracle tests of
-test_gpu_parity.py run on the resident kernel by default."""
+batch invariance, eager vs graph, scans too large / too small for the staging rounds).  The per-layer launches are the product
+path (the resident kernel is slower: DESIGN.md 3.1e); the fixture / oracle tests of test_gpu_parity.py run on them."""
 import numpy as np
 import pytest
 import torch
@@ -48,7 +48,7 @@ def _run(gpu, m, pts, off, tail_mode, slot=0, levels=(5, 6, 7)):
     feats = {l: ctx.forward_level_features(l, 128).clone() for l in levels}
     ctx.plan_status()
     res = {k: v.clone() for k, v in out.items()}
-    ctx.set_tail(0)
+    ctx.set_tail(1)                                   # back to the product path
     return res, feats
 
 
@@ -132,9 +132,12 @@ def test_tail_graph_replay_matches_eager_bitwise(gpu):
     batches = [_batch([700, 701, 702, 703], [20000, 15000, 20000, 12000]),
                _batch([710, 711, 712, 713], [9000, 20000, 20000, 20000]),
                _batch([720, 721, 722, 723], [20000, 500, 18000, 3])]
+    m.context(1).set_tail(0)                          # the resident kernel (opt-in), eager ...
     eager = [{k: v.clone() for k, v in ex.extract_packed(p, o, slot=1).items()} for p, o in batches]
     caps = ex.calibrate(batches[0][0], batches[0][1], margin=1.5)
+    m.context(0).set_tail(0)                          # ... and in the captured step
     gx = ex.graph(batch_size=4, max_points=80000, level_capacity=caps)
+    gx.ctx.set_tail(0)
     for rnd in range(3):
         for (p, o), want in zip(batches, eager):
             out = gx.run(p, o)
@@ -148,6 +151,8 @@ def test_tail_concurrent_streams(gpu):
     m = _model(gpu, 66)
     ex = gpu.DescriptorExtractor(m, n_k=128)
     batches = [_batch([800 + 4 * i + j for j in range(4)], [20000, 15000, 18000, 12000]) for i in range(8)]
+    for s in range(4):
+        m.context(s).set_tail(0)                      # the resident kernel on every stream's context
     want = [ex.extract_packed(p, o, slot=0)["global"].clone() for p, o in batches]
     torch.cuda.synchronize()
     for rnd in range(3):
