@@ -333,7 +333,7 @@ class Context:
         check(self.lib.egonn_debug_set_naive_conv(self.h, int(on)))
 
     def set_tail(self, mode: int):
-        """tests only: 1 = levels 5-7 + global head as per-layer launches, 0 = the resident tail kernel (product path)."""
+        """tests / A-B only: 1 = levels 5-7 + global head as per-layer launches (default, product path), 0 = the resident tail kernel."""
         check(self.lib.egonn_debug_set_tail(self.h, int(mode)))
 
     def global_avg_pool(self, level: int, x: torch.Tensor):

@@ -207,7 +207,7 @@ struct Ctx {
   int32_t* dev_flags = nullptr;      // bit 0 = out-of-range coordinate seen, bit 1 = batch larger than the reserved capacities
   uint32_t* tail_flags = nullptr;    // [EGONN_MAX_BATCH][8] stage counters of the resident tail kernel (tail.hip), zeroed once
   float* tail_sums = nullptr;        // [EGONN_MAX_BATCH][128]
-  int tail_mode = 0;                 // 0 = levels 5-7 + global head in the resident tail kernel (fp32 maps), 1 = per-layer launches
+  int tail_mode = 1;                 // 1 = per-layer launches (product path), 0 = levels 5-7 + global head in the resident tail kernel (fp32 maps)
                                      // (egonn_debug_set_tail; the cross-check path of tests/test_gpu_tail.py)
   bool reserved = false;             // egonn_ctx_reserve: fixed capacities, plans neither allocate nor synchronise
   int64_t reserve_points = 0;

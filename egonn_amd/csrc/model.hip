@@ -94,8 +94,8 @@ API int egonn_debug_set_naive_conv(egonn_ctx* c, int on) {
   return EGONN_OK;
 }
 
-// 0 = levels 5-7 + the global head run in the resident tail kernel (tail.hip; fp32 maps: the product path), 1 = the per-layer
-// launches (the cross-check path of tests/test_gpu_tail.py and of A/B measurements)
+// 0 = levels 5-7 + the global head run in the resident tail kernel (tail.hip; fp32 maps; opt-in: measured slower),
+// 1 = the per-layer launches (the default and product path)
 API int egonn_debug_set_tail(egonn_ctx* c, int mode) {
   EGONN_REQUIRE(c && (mode == 0 || mode == 1), EGONN_ERR_INVALID, "debug_set_tail: bad argument");
   c->tail_mode = mode;

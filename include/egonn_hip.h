@@ -49,10 +49,10 @@ const char* egonn_last_error(void);
  * HIP kernel (cross-check of the MFMA kernels), on = 2 / 4 force the per-wave / the workgroup-cooperative MFMA kernel (A/B
  * timing); 0 = product choice.  Never set by the product path. */
 int egonn_debug_set_naive_conv(egonn_ctx* ctx, int on);
-/* tests / measurements only: mode 1 runs levels 5-7 of the trunk and the global head of egonn_forward as per-layer launches
- * (the cross-check path); 0 = the product path for fp32 maps: ONE resident launch (csrc/tail.hip: clusters of 8 workgroups
- * per scan, weights streamed once per 16-column tile, sample-cluster epoch flags between stages).  Results of the two paths
- * differ by summation order only (<= 3e-6 of the largest output). */
+/* tests / measurements only: mode 1 (the default, the product path) runs levels 5-7 of the trunk and the global head of
+ * egonn_forward as per-layer launches; 0 = fp32 maps: ONE resident launch (csrc/tail.hip: clusters of 8 workgroups per scan,
+ * weights streamed once per 16-column tile, epoch flags between stages) — built as a replacement, measured slower (DESIGN.md
+ * 3.1e), kept opt-in and tested.  Results of the two paths differ by summation order only (<= 3e-6 of the largest output). */
 int egonn_debug_set_tail(egonn_ctx* ctx, int mode);
 /* measurement hook: buffer for the traced sparse-conv build (debug variant 128): 8 u64 per wave task; NULL = off */
 int egonn_debug_set_trace(void* device_buffer);
