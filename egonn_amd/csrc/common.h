@@ -196,6 +196,8 @@ struct Ctx {
                               // level-5 launches alone get slower, one-batch graph latency 1.17 -> 1.23 ms — the headline metric is scans/s)
   int split_io = 0;           // set by egonn_forward around ONE sconv_map call: bit 0 = the input map is in split form (fp16 hi | lo
                               // per 32-channel block, sconv_split.hip), bit 1 = write the output in split form
+  const float* gated_in2 = nullptr;   // set by egonn_forward around ONE sconv_map call: the convolution's input row r is
+  const float* gated_gate = nullptr;  // relu(in[r] * gate[scan] + in2[r]) — the tail of the ECA block below, never materialised
   int conv_variant = 0;       // tests / A-B measurements only (egonn_debug_set_naive_conv): 0 = product choice, 1 = per-wave
                               // MFMA kernel, 2 = workgroup-cooperative MFMA kernel, 3 = plain one-thread-per-output kernel
   Arena plan_arena;           // keys, maps (lives until the next plan)

@@ -35,7 +35,8 @@ size_t split_weights_bytes(int K, int cin, int cout);   // fragments + 16 bytes 
 int sconv_split_default_cfg(int cin, int cout, int64_t groups_hint);
 int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
                         int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
-                        int cfg = 0, int split_io = 0);      // split_io: bit 0 = input map in split form, bit 1 = write split form
+                        int cfg = 0, int split_io = 0,       // split_io: bit 0 = input map in split form, bit 1 = write split form
+                        const float* gated_in2 = nullptr, const float* gated_gate = nullptr, int B = 0);   // input row = relu(in * gate[scan] + in2)
 // tail.hip: levels 5-7 + global head + descriptor decoder + pooling of the EgoNN graph as ONE resident launch (fp32 maps)
 struct TailMap { const int32_t* snbr; const uint32_t* gmask; const int32_t* perm; const int32_t* meta; };
 struct TailArgs {

@@ -878,6 +878,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   // levels 5-7 + global head + decoder + pooling: one resident launch for fp32 maps (tail.hip)
   const bool use_tail = !bf16 && c->tail_mode == 0 && c->conv_variant == 0 && m->t_m1 != nullptr && B <= EGONN_MAX_BATCH;
   bool tail_done = false;
+  const float *gated_t2 = nullptr, *gated_res = nullptr, *gated_gate = nullptr;     // level 1's block tail, evaluated by level 2's k=2 conv
   for (int i = 1; i <= 7; ++i) {
     const BlockRef& b = m->blk[i];
     const Level& L = P.lv[i];
@@ -944,8 +945,15 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
       snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/k2s2", sconv_kernel_name(c, 1, i, b.cin, b.cin, bf16), b.cin,
                b.cin, i);
       ProfScope ps(c, st, tag, PK_K2S2, i, 8, b.cin, b.cin, (int)es);
-      EGONN_TRY(sconv_map(c, 1, i, x[i - 1], nullptr, bf16 ? m->q_convs[i] : m->p_convs[i], m->s_convs[i], b.cin, b.cin, bf16, m->bn[i].scale,
-                          m->bn[i].shift, 1, y, nullptr, nullptr, 0, st));
+      // (level 2 with a gated input: the block output of level 1 is evaluated on the gathered rows — see below)
+      const bool gin = gated_t2 != nullptr && i == 2;
+      c->gated_in2 = gin ? gated_res : nullptr;
+      c->gated_gate = gin ? gated_gate : nullptr;
+      const int rc = sconv_map(c, 1, i, gin ? gated_t2 : x[i - 1], nullptr, bf16 ? m->q_convs[i] : m->p_convs[i], m->s_convs[i], b.cin, b.cin, bf16,
+                               m->bn[i].scale, m->bn[i].shift, 1, y, nullptr, nullptr, 0, st);
+      c->gated_in2 = nullptr;
+      c->gated_gate = nullptr;
+      EGONN_TRY(rc);
     }
     DBG_SYNC("L%d k2s2", i);
     // ECABasicBlock (layers/eca_block.py:56-73)
@@ -981,6 +989,21 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     EGONN_TRY(eca_gate_groups(psum, L.rg27, L.boff, B, b.cout, b.eca, b.eca_k, gate, st));
     DBG_SYNC("L%d eca gate", i);
     const void* res = y;
+    static const bool gated_ok = getenv("EGONN_NO_GATED_K2S2") == nullptr;        // measurement switch
+    if (i == 1 && gated_ok && !bf16 && !b.down && c->conv_variant == 0 && b.cout == 32 && m->blk[2].cin == 32 &&
+        sconv_uses_split(32, 32, 0, 2, c->conv_variant, c->split_max_level)) {
+      // level 1's block output has ONE reader, the strided convolution into level 2, which reads every row exactly once: it
+      // evaluates relu(t2 * gate[scan] + y) on the rows it gathers (sconv_split_kernel<32,32,...,GATED>) — the 23 MB map is neither
+      // written nor read back and the element-wise launch is gone; bitwise the same level-2 input.  egonn_forward_level_features(1)
+      // has nothing to return then.
+      gated_t2 = reinterpret_cast<const float*>(t2);
+      gated_res = reinterpret_cast<const float*>(y);
+      gated_gate = gate;
+      x[i] = nullptr;
+      c->level_feat[i] = nullptr;
+      c->level_ch[i] = b.cout;
+      continue;
+    }
     FALLOC(xo, n * b.cout);
     static const bool fuse_down = getenv("EGONN_NO_FUSED_DOWN") == nullptr;      // measurement switch
     if (b.down && fuse_down && dense_gate_fusable(n, b.cin, b.cout)) {

@@ -1243,9 +1243,11 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
     }
     return sconv_split_forward(reinterpret_cast<const float*>(in), P.cap[lin], rg, rg.cap_groups, Wsp, cin, cout, scale, shift,
                                relu, reinterpret_cast<float*>(out), psum, stream,
-                               ctx->conv_variant >= 1000 ? ctx->conv_variant - 1000 : 0, ctx->split_io);
+                               ctx->conv_variant >= 1000 ? ctx->conv_variant - 1000 : 0, ctx->split_io, ctx->gated_in2, ctx->gated_gate,
+                               P.batch);
   }
-  EGONN_REQUIRE(ctx->split_io == 0, EGONN_ERR_STATE, "sconv: split-form maps are read and written by the split kernel only");
+  EGONN_REQUIRE(ctx->split_io == 0 && !ctx->gated_in2, EGONN_ERR_STATE,
+                "sconv: split-form maps and gated inputs are read and written by the split kernel only");
   if (!Wp) {      // stand-alone operator call: pack into the caller's scratch
     const size_t wn = (size_t)K * cin * cout;
     EGONN_REQUIRE(W && scratch && scratch_floats >= wn, EGONN_ERR_STATE, "sconv: no scratch to pack the kernel into");

@@ -140,6 +140,11 @@ struct SplitArgs {
                              // are made of, instead of 32 fp32 values.  Same size, same gather; the consumer's in-loop split
                              // (24 vector instructions per 16 x 32 fragment) moves into the producer's epilogue.  hi / lo are
                              // computed by the same split8h either way: results are bitwise those of fp32 maps.
+  // GATED instantiation only: the input map does not exist — row r of it is relu(in[r] * gate[scan][c] + in2[r]) (the tail of the
+  // ECA block below, layers/eca_block.py:66-73), evaluated on the gathered fragments with the expression of eca_apply_kernel
+  const float* in2 = nullptr;
+  const float* gate = nullptr;            // [B][CIN]
+  int B = 0;
   unsigned long long* trace = nullptr;   // measurement builds only (tools/split_trace.py): 12 u64 per wave task
 };
 
@@ -168,14 +173,14 @@ __device__ static inline void split8h(const f32x4& a0, const f32x4& a1, f16x8_t&
   }
 }
 
-template <int NSW, int NW>
+template <int NSW, int NW, bool GATED = false>
 struct SplitGeom {
   static constexpr int NS = NSW;                         // 32-column slices a workgroup owns
   static constexpr int SLAB = NS * 4096;                 // bytes of W[k][cb][its columns]: hi | lo fragments
   static constexpr int NPIECE = NS * 4;                  // 1 KB DMA pieces per slab
   static constexpr int WPP = (NPIECE + NW - 1) / NW;     // pieces a wave issues per step (at most)
   static constexpr int TBL_BYTES = 27 * 64;              // one group's table: 27 offsets x 16 slots
-  static constexpr int WAVE_LDS = 2048 + 2 * 2048;       // table (padded) + two ring slots of 16 x 128 B
+  static constexpr int WAVE_LDS = 2048 + 2 * 2048 + (GATED ? 2 * 2048 : 0);   // table (padded) + two ring slots of 16 x 128 B (+ two of the second operand)
   static constexpr int WAVES_AT = 2 * SLAB;
   static constexpr int LDS_BYTES = WAVES_AT + NW * WAVE_LDS;
 };
@@ -184,9 +189,10 @@ struct SplitGeom {
 // than one round of the chip) are a chain of K*CIN/32 dependent steps per task; giving every column part its own workgroup
 // shortens the step (fewer MFMAs, a smaller slab) and multiplies the workgroups in flight; the rows are then gathered once
 // per part, which small maps can afford.  Columns are independent: the results are bitwise the same for every NSW.
-template <int CIN, int COUT, int NW, int NSW, bool TRACE = false>
+template <int CIN, int COUT, int NW, int NSW, bool TRACE = false, bool GATED = false>
 __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p) {
-  using GEO = SplitGeom<NSW, NW>;
+  using GEO = SplitGeom<NSW, NW, GATED>;
+  static_assert(!GATED || CIN == 32, "gated input: one channel block");
   constexpr int NS = NSW, NSTOT = COUT / 32, NCB = CIN / 32;
   static_assert(NSTOT % NSW == 0, "column parts");
   const int ns0 = blockIdx.y * NSW;                      // first column slice of this workgroup
@@ -214,6 +220,8 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
   const __amdgpu_buffer_rsrc_t a_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), (short)(CIN * 4), (int)p.in_rows, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wsp), 0, (int)p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t a2_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATED ? p.in2 : p.in), (short)(CIN * 4), (int)p.in_rows, 0x00020000);
 
   const int ngroups = __builtin_amdgcn_readfirstlane(min(p.meta[0], p.cap_groups));
   const int ntask = (ngroups + NW - 1) / NW;
@@ -240,6 +248,17 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
     if (!(U >> 31)) continue;                            // nothing but padding groups
     const uint32_t gm = (uint32_t)__builtin_amdgcn_readlane((int)mload, wave);
     const bool live = (gm >> 31) != 0;
+    f32x4 gq0 = {0.f, 0.f, 0.f, 0.f}, gq1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (GATED) {
+      // scan of this wave's group (a group never straddles two scans): last b with meta[1 + b] <= gw; the gate of the lane's channels
+      int lo = 0, hi = p.B;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (p.meta[1 + mid] <= gw) lo = mid; else hi = mid;
+      }
+      gq0 = *reinterpret_cast<const f32x4*>(p.gate + (int64_t)lo * CIN + 4 * g4);
+      gq1 = *reinterpret_cast<const f32x4*>(p.gate + (int64_t)lo * CIN + 16 + 4 * g4);
+    }
 
     // ---- the group's neighbour table -> wave-private LDS (two 16-byte pieces per lane); output rows of the epilogue
     int32_t orow = -1;
@@ -290,6 +309,10 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
       if ((gm >> k) & 1u) {
         __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(ring + slot * 2048), 16, i0, dma_chunk, cb * 128, 0, 0);
         __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(ring + slot * 2048 + 1024), 16, i1, dma_chunk, cb * 128, 0, 0);
+        if constexpr (GATED) {
+          __builtin_amdgcn_struct_ptr_buffer_load_lds(a2_rsrc, (lds_char*)(ring + 4096 + slot * 2048), 16, i0, dma_chunk, cb * 128, 0, 0);
+          __builtin_amdgcn_struct_ptr_buffer_load_lds(a2_rsrc, (lds_char*)(ring + 4096 + slot * 2048 + 1024), 16, i1, dma_chunk, cb * 128, 0, 0);
+        }
       }
     };
     auto idx_read = [&](int k, int32_t& i0, int32_t& i1) {   // issued; awaited by the lgkmcnt(0) in front of the barrier
@@ -322,17 +345,29 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
     };
     // ---- one step of this wave's group: rows of ring slot x slab of the same slot
     auto compute = [&](int slot) {
-      f32x4 ra0, ra1, w[4];
+      f32x4 ra0, ra1, rb0, rb1, w[4];
       {
         const uint32_t r0 = rd0 + (uint32_t)(slot * 2048), r1 = rd1 + (uint32_t)(slot * 2048);
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(ra0), "=&v"(ra1) : "v"(r0), "v"(r1) : "memory");
+        if constexpr (GATED) {
+          const uint32_t q0 = r0 + 4096u, q1 = r1 + 4096u;
+          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(rb0), "=&v"(rb1) : "v"(q0), "v"(q1) : "memory");
+        }
       }
       const uint32_t wa = wrd + (uint32_t)(slot * SLAB);
       wread(wa, std::integral_constant<int, 0>{}, w);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1)::"memory");
+      if constexpr (GATED) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(rb0), "+v"(rb1)::"memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1)::"memory");
       wwait(w);
       f16x8_t ah, al;
-      if (p.in_split) { ah = __builtin_bit_cast(f16x8_t, ra0); al = __builtin_bit_cast(f16x8_t, ra1); }   // (uniform branch)
+      if constexpr (GATED) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          ra0[u] = fmaxf(ra0[u] * gq0[u] + rb0[u], 0.f);        // eca_apply_kernel's expression
+          ra1[u] = fmaxf(ra1[u] * gq1[u] + rb1[u], 0.f);
+        }
+        split8h(ra0, ra1, ah, al);
+      } else if (p.in_split) { ah = __builtin_bit_cast(f16x8_t, ra0); al = __builtin_bit_cast(f16x8_t, ra1); }   // (uniform branch)
       else split8h(ra0, ra1, ah, al);
       [&]<int... NSI>(std::integer_sequence<int, NSI...>) {
         (([&] {
@@ -453,12 +488,12 @@ __global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p)
   }
 }
 
-template <int CIN, int COUT, int NW, int NSW, bool TRACE = false>
+template <int CIN, int COUT, int NW, int NSW, bool TRACE = false, bool GATED = false>
 static int launch_split(const SplitArgs& a, int64_t groups_hint, hipStream_t stream) {
-  using GEO = SplitGeom<NSW, NW>;
+  using GEO = SplitGeom<NSW, NW, GATED>;
   static AttrOnce attr_done;
   if (attr_done.need()) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_split_kernel<CIN, COUT, NW, NSW, TRACE>),
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_split_kernel<CIN, COUT, NW, NSW, TRACE, GATED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done.mark();
   }
@@ -468,11 +503,11 @@ static int launch_split(const SplitArgs& a, int64_t groups_hint, hipStream_t str
   const dim3 grid((unsigned)gridx, (unsigned)(COUT / 32 / NSW));
   hipEvent_t* pev = prof_kernel_events();
   if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
-    hipExtLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, NSW, TRACE>), grid, dim3(NW * 64), GEO::LDS_BYTES, stream,
+    hipExtLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, NSW, TRACE, GATED>), grid, dim3(NW * 64), GEO::LDS_BYTES, stream,
                           pev[0], pev[1], 0, a);
     pev[0] = pev[1] = nullptr;
   } else {
-    hipLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, NSW, TRACE>), grid, dim3(NW * 64), GEO::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, NSW, TRACE, GATED>), grid, dim3(NW * 64), GEO::LDS_BYTES, stream, a);
   }
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
@@ -490,7 +525,7 @@ bool sconv_split_supported(int cin, int cout) {
 // cfg = 100 + NW * 10 + 2 [+ 400 * (1 + log2(column parts))]; 0 = product choice (142: workgroups of 4 waves, automatic parts)
 int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
                         int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
-                        int cfg, int split_io) {
+                        int cfg, int split_io, const float* gated_in2, const float* gated_gate, int B) {
   EGONN_REQUIRE(rg.built, EGONN_ERR_STATE, "sconv: row-group tables not built");
   EGONN_REQUIRE(sconv_split_supported(cin, cout), EGONN_ERR_INVALID, "sconv(split): channel plan %d->%d not supported", cin, cout);
   EGONN_REQUIRE((uint64_t)n_in_cap * cin * 4 < (1ull << 32) - (1ull << 20), EGONN_ERR_INVALID,
@@ -519,6 +554,12 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
   }                                                      //  with 1 / 2 / 4 parts, 64->128 56 / 45 / 51, L3 64->64 43 / 41; round 5, fp16 kernels:
                                                          //  4 parts change neither the layers (profiles/r05g_parts4.txt) nor scans/s)
   const int nsw = ns_tot / parts;
+  if (gated_in2) {
+    EGONN_REQUIRE(cin == 32 && cout == 32 && gated_gate && B >= 1 && !a.in_split && cfg == 142, EGONN_ERR_INVALID,
+                  "sconv(split): the gated input exists for the 32->32 plan only");
+    a.in2 = gated_in2; a.gate = gated_gate; a.B = B;
+    return launch_split<32, 32, 4, 1, false, true>(a, groups_hint, stream);
+  }
 #define EGONN_SP_LOCK1(CI, CO, NWW, NSWW)                                                                 \
   if (cin == CI && cout == CO && shape == 100 + NWW * 10 + 2 && nsw == NSWW && !trace)                    \
     return launch_split<CI, CO, NWW, NSWW>(a, groups_hint, stream);

@@ -2,6 +2,7 @@
   EGONN_NO_PRESPLIT=1    conv2 splits its operands in the step loop instead of reading conv1's split-form output (sconv_split.hip)
   EGONN_NO_FUSED_DOWN=1  1x1 downsample branch + BatchNorm and the gated residual + ReLU as two launches instead of one (dense.hip)
   EGONN_NO_FUSED_LATERAL=1  the local head's level-3 lateral 1x1 convolution as its own launch instead of the heads' first layer
+  EGONN_NO_GATED_K2S2=1  level 1's block tail as its own launch + a 23 MB map instead of being evaluated by level 2's strided convolution
 fp32 maps (4 scans) and bf16 maps."""
 import os, subprocess, sys, hashlib
 import numpy as np
@@ -30,7 +31,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         h.update(out[k].cpu().numpy().tobytes())
     for t in m._last_local:                            # every row of the three local heads
         h.update(t.cpu().numpy().tobytes())
-    for l in (1, 2, 3, 4, 5):
+    for l in (2, 3, 4, 5):                              # (level 1's block output is not materialised in the product path)
         ctx = m.context(0)
         h.update(ctx.forward_level_features(l, [0, 32, 64, 64, 128, 128][l]).cpu().numpy().tobytes())
         torch.cuda.synchronize()
@@ -39,7 +40,7 @@ else:
     ok = True
     for prec in ("fp32", "bf16"):
         d = []
-        for env in ({}, {"EGONN_NO_PRESPLIT": "1"}, {"EGONN_NO_FUSED_DOWN": "1"}, {"EGONN_NO_FUSED_LATERAL": "1"}):
+        for env in ({}, {"EGONN_NO_PRESPLIT": "1"}, {"EGONN_NO_FUSED_DOWN": "1"}, {"EGONN_NO_FUSED_LATERAL": "1"}, {"EGONN_NO_GATED_K2S2": "1"}):
             r = subprocess.run([sys.executable, __file__, "child"], capture_output=True, text=True,
                                env=dict(os.environ, CHECK_PRECISION=prec, **env))
             line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")]
