@@ -181,7 +181,9 @@ int egonn_model_finalize(egonn_model* model, void* stream);
 int egonn_forward(egonn_ctx* ctx, egonn_model* model, const float* features, int quant_mode, const float* step,
                   int flags, float* out_global, float* out_descriptors, float* out_keypoints, float* out_sigma,
                   void* stream);
-/* Feature map of a trunk level produced by the last egonn_forward (debug / parity tests): (N_l, C_l). */
+/* Feature map of a trunk level produced by the last egonn_forward (debug / parity tests): (N_l, C_l).  Levels whose block output
+ * egonn_forward does not materialise return EGONN_ERR_STATE: with fp32 maps level 1's block output is evaluated on the fly by the
+ * strided convolution into level 2 (EGONN_NO_GATED_K2S2=1 in the environment materialises it again). */
 int egonn_forward_level_features(egonn_ctx* ctx, int level, float* out, int channels, void* stream);
 
 /* Keypoint selection — MinkLocGLEvaluator.get_keypoints_idxes, eval/evaluate.py:352-361: per sample the n_k
