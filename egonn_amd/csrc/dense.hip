@@ -899,6 +899,7 @@ struct LocalHeadsArgs {
   float *out_desc, *out_kp, *out_sigma;
   int64_t n;
   int level, cb, mode, ignore_offsets;
+  int in_bf16;                                             // x and lres are bf16 maps (bf16 feature maps; only with lw)
   float s0, s1, s2;
 };
 // The six weight matrices (92 KB as MFMA fragments) are staged ONCE per workgroup into LDS in fragment order
@@ -967,17 +968,23 @@ __global__ __launch_bounds__(LH_WAVES * 64) void local_heads_kernel(const LocalH
     const int64_t row = tile * 16 + l15;
     const bool ok = row < n;
     f32x4 x[4];
+    auto load4 = [&](const float* base, int t) -> f32x4 {     // four channels of the row: fp32, or bf16 widened
+      if (!ok) return (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.in_bf16) {
+        const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + row * 64 + 16 * t + 4 * g4);
+        return (f32x4){bf2f(h.x & 0xFFFFu), bf2f(h.x >> 16), bf2f(h.y & 0xFFFFu), bf2f(h.y >> 16)};
+      }
+      return *reinterpret_cast<const f32x4*>(base + row * 64 + 16 * t + 4 * g4);
+    };
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      x[t] = ok ? *reinterpret_cast<const f32x4*>(p.x + row * 64 + 16 * t + 4 * g4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 4; ++t) x[t] = load4(p.x, t);
     if (p.lw) {
       // ---- MinkHead's last lateral (models/minkgl.py:46-60): conv1x1(x3) + the transposed convolution's output, in the
       //      accumulation order of the dense kernel it replaces (bitwise the same rows); the 64-channel map the three heads read
       //      never goes to memory
       f32x4 r[4], l[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        r[t] = ok ? *reinterpret_cast<const f32x4*>(p.lres + row * 64 + 16 * t + 4 * g4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < 4; ++t) r[t] = load4(p.lres, t);
       mlp_layer<64, 4>(lh_frags + LH_FRAGS * 64, x, lane, l);
 #pragma unroll
       for (int t = 0; t < 4; ++t) x[t] = l[t] + r[t];
@@ -1048,12 +1055,14 @@ __global__ __launch_bounds__(LH_WAVES * 64) void local_heads_kernel(const LocalH
 int local_heads_forward(const float* x, int64_t n, const int32_t* n_dev, const float* const* w /*12 pointers*/,
                         const uint64_t* keys, int level, int cb, int mode, const float* step, int ignore_offsets,
                         float* out_desc, float* out_kp, float* out_sigma, hipStream_t stream, const float* lateral_w,
-                        const float* lateral_res) {
+                        const float* lateral_res, int in_bf16) {
   if (n == 0) return EGONN_OK;
   EGONN_REQUIRE((lateral_w == nullptr) == (lateral_res == nullptr), EGONN_ERR_INVALID, "local heads: lateral kernel and residual go together");
   LocalHeadsArgs a;
   a.x = x; a.n = n; a.n_dev = n_dev;
   a.lw = lateral_w; a.lres = lateral_res;
+  a.in_bf16 = in_bf16 ? 1 : 0;
+  EGONN_REQUIRE(!in_bf16 || lateral_w, EGONN_ERR_INVALID, "local heads: bf16 input rows only through the fused lateral");
   a.dw0 = w[0]; a.db0 = w[1]; a.dw1 = w[2]; a.db1 = w[3];
   a.kw0 = w[4]; a.kb0 = w[5]; a.kw1 = w[6]; a.kb1 = w[7];
   a.sw0 = w[8]; a.sb0 = w[9]; a.sw1 = w[10]; a.sb1 = w[11];

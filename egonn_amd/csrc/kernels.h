@@ -115,7 +115,8 @@ int keypoint_positions(const uint64_t* keys, int64_t n, int level, int cb, const
 // in one launch on the (n,64) local feature map; w: dw0,db0,dw1,db1, kw0,kb0,kw1,kb1, sw0,sb0,sw1,sb1 (nn.Linear layouts)
 int local_heads_forward(const float* x, int64_t n, const int32_t* n_dev, const float* const* w, const uint64_t* keys,
                         int level, int cb, int mode, const float* step, int ignore_offsets, float* out_desc, float* out_kp,
-                        float* out_sigma, hipStream_t stream, const float* lateral_w = nullptr, const float* lateral_res = nullptr);
+                        float* out_sigma, hipStream_t stream, const float* lateral_w = nullptr, const float* lateral_res = nullptr,
+                        int in_bf16 = 0);
 // top-k smallest sigma per sample, ascending, ties by row (= Z-order) — eval/evaluate.py:352-361 — and the gather of the
 // selected keypoints / descriptors, one launch (workgroup = scan); out_kp / out_desc nullable
 int select_topk(const float* sigma, const int32_t* boff_dev, int B, int k, const float* kp, const float* desc, int dc,

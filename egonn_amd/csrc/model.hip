@@ -860,12 +860,12 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     const float* hw[12] = {m->ldec.w0, m->ldec.b0, m->ldec.w1, m->ldec.b1, m->kp.w0, m->kp.b0, m->kp.w1, m->kp.b1,
                            m->sg.w0, m->sg.b0, m->sg.w1, m->sg.b1};
     static const bool fuse_lateral = getenv("EGONN_NO_FUSED_LATERAL") == nullptr;      // measurement switch
-    if (fuse_lateral && !bf16 && LOCAL_CH == 64) {
-      // fp32 maps: the level-3 lateral 1x1 convolution + the transposed convolution's output are the first layer of the heads'
-      // kernel — the 64-channel map they read is never written (bitwise the rows of the dense launch this replaces)
+    if (fuse_lateral && LOCAL_CH == 64) {
+      // the level-3 lateral 1x1 convolution + the transposed convolution's output are the first layer of the heads' kernel — the
+      // 64-channel map they read is never written (bitwise the rows of the dense launch this replaces; bf16 maps are widened on load)
       EGONN_TRY(local_heads_forward(reinterpret_cast<const float*>(x[3]), n3, cnt + 3, hw, P.lv[3].keys, 3, P.coord_bits, quant_mode,
                                     step, (flags & EGONN_FLAG_IGNORE_KP_REGRESSOR) ? 1 : 0, out_desc, out_kp, out_sigma, st,
-                                    m->l1x1[3], reinterpret_cast<const float*>(u3)));
+                                    m->l1x1[3], reinterpret_cast<const float*>(u3), bf16));
       return EGONN_OK;
     }
     WALLOC(l3, n3 * LOCAL_CH);
