@@ -27,7 +27,7 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
 int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, const void* Wsp, int cin, int cout,
               int bf16, const float* scale, const float* shift, int relu, void* out, float* psum, float* scratch,
               size_t scratch_floats, hipStream_t stream);
-bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int split_max_level);
+bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int split_max_level, int kind = 0);
 // sconv_split.hip: fp32 maps on the fp16 matrix pipe (two-way split operands, three products, fp32 accumulate)
 bool sconv_split_supported(int cin, int cout);
 int pack_split_weights(const float* W, int K, int cin, int cout, int flip, int transpose, void* out, hipStream_t stream);

@@ -991,7 +991,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     const void* res = y;
     static const bool gated_ok = getenv("EGONN_NO_GATED_K2S2") == nullptr;        // measurement switch
     if (i == 1 && gated_ok && !bf16 && !b.down && c->conv_variant == 0 && b.cout == 32 && m->blk[2].cin == 32 &&
-        sconv_uses_split(32, 32, 0, 2, c->conv_variant, c->split_max_level)) {
+        sconv_uses_split(32, 32, 0, 2, c->conv_variant, c->split_max_level, 1)) {
       // level 1's block output has ONE reader, the strided convolution into level 2, which reads every row exactly once: it
       // evaluates relu(t2 * gate[scan] + y) on the rows it gathers (sconv_split_kernel<32,32,...,GATED>) — the 23 MB map is neither
       // written nor read back and the element-wise launch is gone; bitwise the same level-2 input.  egonn_forward_level_features(1)

@@ -1182,7 +1182,7 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
 // the kernel rocprofv3 names).  Mirrors the choices in sconv_map / sconv_rg_forward / launch_rg.
 const char* sconv_kernel_name(const Ctx* ctx, int kind, int level, int cin, int cout, int bf16) {
   const int variant = ctx->conv_variant;
-  if (sconv_uses_split(cin, cout, bf16, level, variant, ctx->split_max_level)) return "sconv_split_kernel";
+  if (sconv_uses_split(cin, cout, bf16, level, variant, ctx->split_max_level, kind)) return "sconv_split_kernel";
   const bool small = level >= (bf16 ? 6 : 5);
   const bool coop = variant == 2 || (variant == 0 && bf16 && level <= 4 && cin * cout >= 32 * 64);
   if (coop) return "sconv_wg_kernel";
@@ -1201,7 +1201,7 @@ const char* sconv_kernel_name(const Ctx* ctx, int kind, int level, int cin, int 
 // kernel wins from ~4 000 row groups up (L1 k3 60 -> 54 us, L2 64->64 89 -> 79) and loses below; with batches in flight it
 // pays much earlier because it leaves the matrix pipe to the other batches: scans/s with the split kernel on launches of
 // >= inf / 4096 / 2000 / 700 / 200 groups = 21.8 k / 23.3 k / 24.3 k / 24.8 k / 23.6 k, i.e. levels <= 0 / 2 / 3 / 4 / 6.
-bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int split_max_level) {
+bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int split_max_level, int kind) {
   if (bf16 || !sconv_split_supported(cin, cout)) return false;
   if (variant >= 1000) return true;
   if (variant != 0) return false;
@@ -1209,6 +1209,11 @@ bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int s
     const char* e = getenv("EGONN_SPLIT_MAX_LEVEL");
     return e ? atoi(e) : -1;
   }();
+  static const int env_k8 = [] {                          // EGONN_SPLIT_MAX_LEVEL_K8: measurement override for the 8-slot maps
+    const char* e = getenv("EGONN_SPLIT_MAX_LEVEL_K8");
+    return e ? atoi(e) : -1;
+  }();
+  if (kind != 0 && env_k8 >= 0) return level <= env_k8;
   return level <= (env_level >= 0 ? env_level : split_max_level);
 }
 
@@ -1234,7 +1239,7 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
   }
   EGONN_TRY(ensure_rowgroups(ctx, &kind, &level, 1, stream));
   const RowGroups& rg = kind == 0 ? V.rg27 : (kind == 1 ? V.rg8 : V.rgT);
-  if (sconv_uses_split(cin, cout, bf16, level, ctx->conv_variant, ctx->split_max_level)) {
+  if (sconv_uses_split(cin, cout, bf16, level, ctx->conv_variant, ctx->split_max_level, kind)) {
     if (!Wsp) {   // stand-alone operator call: pack into the caller's scratch
       const size_t wn = (split_weights_bytes(K, cin, cout) + 3) / 4;
       EGONN_REQUIRE(W && scratch && scratch_floats >= wn, EGONN_ERR_STATE, "sconv: no scratch to pack the kernel into");
