@@ -494,8 +494,8 @@ def main():
     rccl_ranks_seen = ranks_seen(dist if distributed else None, dev)
     if rank == 0:
         total_scans = args.batch * world * args.steps
-        tail_desc = ("one resident launch (csrc/tail.hip), split-operand products with fp32 accumulation" if os.environ.get("EGONN_TAIL")
-                     else "per-layer launches on exact v_mfma_f32_16x16x4_f32")
+        tail_desc = ("per-layer launches on exact v_mfma_f32_16x16x4_f32; the maps of levels 3-5 split their offsets over 2-4 waves "
+                     "per SIMD inside a workgroup (fixed partition, fixed order: deterministic and batch-invariant)")
         cfg = "configs[1]" if (args.dtype == "f32" and args.batch == 16) else \
               ("configs[2]" if (args.dtype == "bf16" and args.batch == 64 and args.mode == "graph") else "configs[1] variant")
         line = {

@@ -25,7 +25,7 @@ _SIGS = [
     ("egonn_ctx_destroy", None, [_P]),
     ("egonn_last_error", C.c_char_p, []),
     ("egonn_debug_set_naive_conv", C.c_int, [_P, C.c_int]),
-    ("egonn_debug_set_tail", C.c_int, [_P, C.c_int]),
+    ("egonn_debug_set_ksplit", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("egonn_debug_set_trace", C.c_int, [_P]),
     ("egonn_prepare_maps", C.c_int, [_P, C.c_int, _P]),
     ("egonn_debug_rowgroup_tables", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int64), _P]),
@@ -332,9 +332,9 @@ class Context:
         """tests only: route this context's sparse convolutions through the plain (non-MFMA) kernel."""
         check(self.lib.egonn_debug_set_naive_conv(self.h, int(on)))
 
-    def set_tail(self, mode: int):
-        """tests / A-B only: 1 = levels 5-7 + global head as per-layer launches (default, product path), 0 = the resident tail kernel."""
-        check(self.lib.egonn_debug_set_tail(self.h, int(mode)))
+    def set_ksplit(self, map_class: int, level: int, kparts: int = -1, kw: int = -1, col_parts: int = -1):
+        """tests / A-B only: offset-split rule of the fp32 sparse convolutions (map_class 0: k=3 maps, 1: 8-slot maps); -1 keeps a field."""
+        check(self.lib.egonn_debug_set_ksplit(self.h, int(map_class), int(level), int(kparts), int(kw), int(col_parts)))
 
     def global_avg_pool(self, level: int, x: torch.Tensor):
         x = _dev_f32(x, self.device)

@@ -168,7 +168,7 @@ struct Plan {
 };
 
 // ------------------------------------------------------------------ per-launch HIP-event timing (bench.py roofline leg)
-enum ProfKind { PK_CONV0 = 0, PK_K3 = 1, PK_K2S2 = 2, PK_TCONV = 3, PK_OTHER = 4, PK_TAIL = 5 };
+enum ProfKind { PK_CONV0 = 0, PK_K3 = 1, PK_K2S2 = 2, PK_TCONV = 3, PK_OTHER = 4 };
 struct ProfRec {
   char name[64];
   int kind, level, K, cin, cout;     // enough to evaluate the algorithmic-bytes formula of SURVEY.md §8(d)
@@ -185,8 +185,16 @@ struct Profiler {
   hipEvent_t get();
 };
 
+// Offset-split rule of the fp32 lock-step kernels (sconv_ksplit_rule): [0] = k=3 maps, [1] = 8-slot maps, indexed by output level
+struct KsRule {
+  int8_t kparts[2][EGONN_NUM_LEVELS];   // offset parts as separate workgroups + reducer launch (1 = none)
+  int8_t kw[2][EGONN_NUM_LEVELS];       // offset parts inside a workgroup (0 / 1 = none)
+  int8_t col_parts[EGONN_NUM_LEVELS];   // column parts per task (0 = automatic)
+};
+
 struct Ctx {
   Profiler prof;
+  KsRule ks_rule;             // set at context creation (sconv_ksplit_defaults); egonn_debug_set_ksplit
   uint16_t* conv0_lut = nullptr;             // first-layer lookup table (64 positions x 128 offsets), built on first use
   unsigned long long* dev_pairs = nullptr;   // [16] kernel-map pair counters: [0] conv0 k5, [l] k3 map of level l
   int device = 0;
@@ -198,6 +206,8 @@ struct Ctx {
                               // per 32-channel block, sconv_split.hip), bit 1 = write the output in split form
   const float* gated_in2 = nullptr;   // set by egonn_forward around ONE sconv_map call: the convolution's input row r is
   const float* gated_gate = nullptr;  // relu(in[r] * gate[scan] + in2[r]) — the tail of the ECA block below, never materialised
+  float* ks_part = nullptr;   // scratch for the partial tiles of the offset-split launches (sconv_split.hip): carved from the work arena
+  size_t ks_part_floats = 0;  // by egonn_forward / the stand-alone operator entry points (sconv_ksplit_scratch_floats)
   int conv_variant = 0;       // tests / A-B measurements only (egonn_debug_set_naive_conv): 0 = product choice, 1 = per-wave
                               // MFMA kernel, 2 = workgroup-cooperative MFMA kernel, 3 = plain one-thread-per-output kernel
   Arena plan_arena;           // keys, maps (lives until the next plan)
@@ -207,10 +217,6 @@ struct Ctx {
   int32_t* host_counts = nullptr;    // pinned staging for the size query
   int32_t* dev_counts = nullptr;
   int32_t* dev_flags = nullptr;      // bit 0 = out-of-range coordinate seen, bit 1 = batch larger than the reserved capacities
-  uint32_t* tail_flags = nullptr;    // [EGONN_MAX_BATCH][8] stage counters of the resident tail kernel (tail.hip), zeroed once
-  float* tail_sums = nullptr;        // [EGONN_MAX_BATCH][128]
-  int tail_mode = 1;                 // 1 = per-layer launches (product path), 0 = levels 5-7 + global head in the resident tail kernel (fp32 maps)
-                                     // (egonn_debug_set_tail; the cross-check path of tests/test_gpu_tail.py)
   bool reserved = false;             // egonn_ctx_reserve: fixed capacities, plans neither allocate nor synchronise
   int64_t reserve_points = 0;
   int reserve_batch = 0;
@@ -238,6 +244,7 @@ int ensure_level0_parent_table(Ctx* ctx, hipStream_t stream);   // coords.hip
 // row-group form of kernel maps (coords.hip): kind 0 = k=3 map of `level`, 1 = k=2,s=2 map into `level`,
 // 2 = transposed map onto `level`; every missing table of the request is built in one launch
 int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, hipStream_t stream);
+int rowgroup_cap_groups(const Plan& P, int level);   // groups the row-group tables of a map onto `level` hold (a function of P.cap, P.batch)
 
 // ------------------------------------------------------------------ sort.hip
 // LSD radix sort of (u64 key, u32 value) pairs on bits [0, nbits).  Result lands in (keys_out, vals_out) — or, when the caller

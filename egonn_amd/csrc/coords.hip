@@ -1003,6 +1003,11 @@ int ensure_level0_parent_table(Ctx* ctx, hipStream_t stream) {
 // ------------------------------------------------------------------ row-group tables (rowgroup.hip) of the plan's maps
 static int rg_window(int level) { return level <= 3 ? 512 : 256; }   // measured: 256 everywhere costs 7 % on the level-1 convs (builder no faster); 512 up to level 5 costs 5 % on the 128-channel convs
 
+int rowgroup_cap_groups(const Plan& P, int level) {
+  const int win = rg_window(level);
+  return (int)((cdiv(P.cap[level], win) + P.batch) * (win / 16));
+}
+
 // Builds the row-group form of the requested maps that do not exist yet, all in ONE launch.
 // kind: 0 = k=3 map of `level`, 1 = k=2,s=2 map into `level` (from level-1), 2 = transposed map onto `level` (from level+1)
 int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, hipStream_t stream) {
@@ -1024,8 +1029,7 @@ int ensure_rowgroups(Ctx* ctx, const int* kinds, const int* levels, int count, h
     EGONN_REQUIRE(nbr, EGONN_ERR_STATE, "rowgroups: the plan has no kernel map of kind %d at level %d", kind, l);
     rg.K = kind == 0 ? 27 : 8;
     rg.win = rg_window(l);
-    const int gpw = rg.win / 16;
-    rg.cap_groups = (int)((cdiv(P.cap[l], rg.win) + P.batch) * gpw);
+    rg.cap_groups = rowgroup_cap_groups(P, l);
     Arena& A = ctx->plan_arena;
     rg.perm = A.alloc<int32_t>((size_t)rg.cap_groups * 16);
     rg.snbr = A.alloc<int32_t>((size_t)rg.cap_groups * rg.K * 16);

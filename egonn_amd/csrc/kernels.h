@@ -36,30 +36,16 @@ int sconv_split_default_cfg(int cin, int cout, int64_t groups_hint);
 int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
                         int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
                         int cfg = 0, int split_io = 0,       // split_io: bit 0 = input map in split form, bit 1 = write split form
-                        const float* gated_in2 = nullptr, const float* gated_gate = nullptr, int B = 0);   // input row = relu(in * gate[scan] + in2)
-// tail.hip: levels 5-7 + global head + descriptor decoder + pooling of the EgoNN graph as ONE resident launch (fp32 maps)
-struct TailMap { const int32_t* snbr; const uint32_t* gmask; const int32_t* perm; const int32_t* meta; };
-struct TailArgs {
-  int B, do_head, pool_mode;            // pool_mode: 0 SPoC (mean), 1 GeM, 2 MAC (max)
-  const int32_t* cnt;                   // device row counts per level
-  const int32_t* boff[8];               // per-scan row offsets per level (4..7 used)
-  int cap[8];                           // rows the level's maps hold
-  TailMap rg27[3], rg8[3], rgT[2];      // k=3 / k=2,s=2 maps of levels 5..7; transposed maps onto level 6 and onto level 5
-  const float* x4;                      // level-4 output of the trunk
-  float *y[3], *t1[3], *t2[3], *x[3];   // per level 5..7: strided conv, conv1, conv2 outputs, block output
-  float *g7, *g6, *g5, *gh, *out_global;
-  const uint16_t *w_k2[3], *w_c1[3], *w_c2[3], *w_1x1[3], *w_t[2], *w_m0, *w_m1;   // pack_tail_weights
-  const float* w_inv;                   // [17 stages][4]: [0] = 1 / weight scale of the stage's kernels (pack_tail_weights trailer)
-  const float *bn_s[3], *bn_h[3], *n1_s[3], *n1_h[3], *n2_s[3], *n2_h[3], *eca_w[3], *b0, *b1, *gem_p;
-  int eca_k[3];
-  float* sums;                          // [B][128] per-scan column sums of conv2 (ECA pooling)
-  uint32_t* flags;                      // [B][8] monotonic stage counters of the clusters
-  int32_t* err;                         // the plan's flag word (bit 2: a cluster wait timed out)
-  unsigned long long* trace;            // measurement hook (egonn_debug_set_trace): [blocks][17 stages][8] stamps; null = off
-};
-int tail_weights_absmax(const float* W, int64_t n, void* trailer, hipStream_t stream);
-int pack_tail_weights(const float* W, int K, int cin, int cout, int out_in, void* out, void* trailer, hipStream_t stream);
-int tail_forward(const TailArgs& a, hipStream_t stream);
+                        const float* gated_in2 = nullptr, const float* gated_gate = nullptr, int B = 0,    // input row = relu(in * gate[scan] + in2)
+                        int kparts = 1, float* part = nullptr, size_t part_floats = 0,   // offset-split launch: parts, scratch for the partial tiles
+                        int col_parts = 0,                                                // column parts per task (0 = automatic)
+                        int kw = 0);                                                      // offset parts INSIDE a workgroup (0 / 1: none; 2, 3, 4)
+size_t sconv_split_part_floats(const RowGroups& rg, int cout, int kparts);
+// Offset-split rule of the fp32 lock-step kernels: parts of the map's K offsets (1 = unsplit) and column parts per task for
+// (map kind, output level) — a function of the LAYER only (the partition changes the summation order of a row)
+void sconv_ksplit_rule(const Ctx* ctx, int kind, int level, int* kparts, int* col_parts, int* kw = nullptr);
+void sconv_ksplit_defaults(KsRule* r);                  // the product rule (+ the EGONN_KSPLIT* measurement overrides)
+size_t sconv_ksplit_scratch_floats(const Ctx* ctx);    // partial-tile scratch that covers every map of the context's plan
 static constexpr size_t SCONV_SCRATCH_FLOATS = (size_t)2 << 20;   // 8 MB: one packed kernel (27 x 256 x 256 fp32 = 7 MB)
 // conv.hip -------------------------------------------------------------------------------------
 int sconv_naive(const float* in, const int32_t* nbr, const float* W, const float* scale, const float* shift, int relu,

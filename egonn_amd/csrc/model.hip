@@ -77,11 +77,6 @@ struct egonn_model {
   const float *q_convs[8] = {}, *q_c1[8] = {}, *q_c2[8] = {}, *q_gt[8] = {}, *q_lt[8] = {};
   // the same kernels as hi|mid|lo bf16 fragments for the split-bf16 fp32 path (sconv_split.hip)
   const float *s_convs[8] = {}, *s_c1[8] = {}, *s_c2[8] = {}, *s_gt[8] = {}, *s_lt[8] = {};
-  // levels 5-7 + global head packed per 16-column tile for the resident tail kernel (tail.hip)
-  uint16_t* tail_packed = nullptr;
-  size_t tail_cap = 0;
-  const uint16_t *t_k2[8] = {}, *t_c1[8] = {}, *t_c2[8] = {}, *t_1x1[8] = {}, *t_gt[8] = {}, *t_m0 = nullptr, *t_m1 = nullptr;
-  const float* t_inv = nullptr;      // [17][4] per-stage 1 / weight scale (behind the packed kernels)
 };
 
 // ------------------------------------------------------------------------------------------ lifecycle
@@ -94,11 +89,16 @@ API int egonn_debug_set_naive_conv(egonn_ctx* c, int on) {
   return EGONN_OK;
 }
 
-// 0 = levels 5-7 + the global head run in the resident tail kernel (tail.hip; fp32 maps; opt-in: measured slower),
-// 1 = the per-layer launches (the default and product path)
-API int egonn_debug_set_tail(egonn_ctx* c, int mode) {
-  EGONN_REQUIRE(c && (mode == 0 || mode == 1), EGONN_ERR_INVALID, "debug_set_tail: bad argument");
-  c->tail_mode = mode;
+// Offset-split rule of this context's fp32 sparse convolutions (tests / A-B measurements; sconv_ksplit_rule): map_class 0 = the
+// k=3 maps, 1 = the 8-slot maps (k=2,s=2 and transposed); kparts = offset parts as separate workgroups + reducer launch (1 = none),
+// kw = offset parts inside a workgroup (0 / 1 = none, 2..4), col_parts = column parts per task (0 = automatic).  -1 keeps a field.
+API int egonn_debug_set_ksplit(egonn_ctx* c, int map_class, int level, int kparts, int kw, int col_parts) {
+  EGONN_REQUIRE(c && (map_class == 0 || map_class == 1) && level >= 0 && level < EGONN_NUM_LEVELS, EGONN_ERR_INVALID,
+                "debug_set_ksplit: bad argument");
+  EGONN_REQUIRE(kparts <= 27 && kw <= 4 && col_parts <= 4, EGONN_ERR_INVALID, "debug_set_ksplit: kparts <= 27, kw <= 4, col_parts <= 4");
+  if (kparts >= 0) c->ks_rule.kparts[map_class][level] = (int8_t)std::max(kparts, 1);
+  if (kw >= 0) c->ks_rule.kw[map_class][level] = (int8_t)kw;
+  if (col_parts >= 0) c->ks_rule.col_parts[level] = (int8_t)col_parts;
   return EGONN_OK;
 }
 
@@ -126,18 +126,7 @@ API int egonn_ctx_create(egonn_ctx** out, int device, int coord_bits) {
     return EGONN_ERR_HIP;
   }
   c->dev_flags = c->dev_counts + 16;   // counts[0..11], flags at [16]: fetched by one copy
-  // resident tail kernel (tail.hip): per-scan stage counters (monotonic over launches: zeroed once, here) and ECA column sums
-  if (hipMalloc(reinterpret_cast<void**>(&c->tail_flags), sizeof(uint32_t) * 8 * EGONN_MAX_BATCH) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&c->tail_sums), sizeof(float) * 128 * EGONN_MAX_BATCH) != hipSuccess ||
-      hipMemset(c->tail_flags, 0, sizeof(uint32_t) * 8 * EGONN_MAX_BATCH) != hipSuccess) {
-    set_error("ctx_create: allocation failed");
-    egonn_ctx_destroy(c);
-    return EGONN_ERR_HIP;
-  }
-  {
-    static const bool use_tail = getenv("EGONN_TAIL") != nullptr;       // (work in progress: the resident tail is opt-in until it wins)
-    c->tail_mode = use_tail ? 0 : 1;
-  }
+  sconv_ksplit_defaults(&c->ks_rule);
   if (conv0_lut_init(c) != EGONN_OK) {
     egonn_ctx_destroy(c);
     return EGONN_ERR_HIP;
@@ -157,8 +146,6 @@ API void egonn_ctx_destroy(egonn_ctx* c) {
   if (c->dev_counts) (void)hipFree(c->dev_counts);
   if (c->dev_pairs) (void)hipFree(c->dev_pairs);
   if (c->conv0_lut) (void)hipFree(c->conv0_lut);
-  if (c->tail_flags) (void)hipFree(c->tail_flags);
-  if (c->tail_sums) (void)hipFree(c->tail_sums);
 
   for (auto& r : c->prof.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto& r : c->prof.graph_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -312,9 +299,17 @@ API int egonn_input_index(egonn_ctx* c, int64_t* out, void* stream) {
 // scratch for the stand-alone operator entry points (the forward carves its own from the work arena)
 static float* op_scratch(egonn_ctx* c) {
   for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
-  if (c->work_arena.ensure(SCONV_SCRATCH_FLOATS * sizeof(float) + 4096) != EGONN_OK) return nullptr;
+  const size_t ks = sconv_ksplit_scratch_floats(c);
+  c->ks_part = nullptr;
+  c->ks_part_floats = 0;
+  if (c->work_arena.ensure((SCONV_SCRATCH_FLOATS + ks) * sizeof(float) + 8192) != EGONN_OK) return nullptr;
   c->work_arena.reset();
-  return c->work_arena.alloc<float>(SCONV_SCRATCH_FLOATS);
+  float* scratch = c->work_arena.alloc<float>(SCONV_SCRATCH_FLOATS);
+  if (ks) {
+    c->ks_part = c->work_arena.alloc<float>(ks);
+    c->ks_part_floats = c->ks_part ? ks : 0;
+  }
+  return scratch;
 }
 
 API int egonn_conv(egonn_ctx* c, int level_in, int level_out, int ks, const float* in, int cin, const float* kernel,
@@ -533,7 +528,6 @@ API void egonn_model_destroy(egonn_model* m) {
   if (m->folded) (void)hipFree(m->folded);
   if (m->packed) (void)hipFree(m->packed);
   if (m->conv0_unit) (void)hipFree(m->conv0_unit);
-  if (m->tail_packed) (void)hipFree(m->tail_packed);
   delete m;
 }
 
@@ -693,50 +687,6 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
     EGONN_TRY(pack2(m->gt[7], 8, GLOBAL_CH, GLOBAL_CH, &m->p_gt[7], &m->q_gt[7], &m->s_gt[7]));
     EGONN_TRY(pack2(m->lt[4], 8, LOCAL_CH, LOCAL_CH, &m->p_lt[4], &m->q_lt[4], &m->s_lt[4]));
   }
-  // ---- levels 5-7 + global head + descriptor decoder per 16-column tile (tail.hip)
-  {
-    const size_t c2 = (size_t)GLOBAL_CH * GLOBAL_CH;
-    const size_t need_t = (3 * 8 + 6 * 27 + 3 + 2 * 8) * c2 + (size_t)m->gdec.mid * GLOBAL_CH + (size_t)GLOBAL_DIM * m->gdec.mid;
-    if (m->tail_cap < need_t) {
-      if (m->tail_packed) HIP_CHECK(hipFree(m->tail_packed));
-      HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->tail_packed), need_t * 2 * sizeof(uint16_t) + 17 * 16));
-      m->tail_cap = need_t;
-    }
-    uint16_t* tc = m->tail_packed;
-    // one weight scale per STAGE of the tail kernel (tail.hip tl_decode: stage s accumulates its kernels into the same registers)
-    uint32_t* trailers = reinterpret_cast<uint32_t*>(m->tail_packed + need_t * 2);
-    m->t_inv = reinterpret_cast<const float*>(trailers);
-    HIP_CHECK(hipMemsetAsync(trailers, 0, 17 * 16, st));
-    auto packg = [&](int stage, const float* w0, int K0, int ci0, int co0, int out_in, const uint16_t** d0,
-                     const float* w1, int K1, const uint16_t** d1) -> int {
-      uint32_t* tr = trailers + 4 * stage;
-      EGONN_TRY(tail_weights_absmax(w0, (int64_t)K0 * ci0 * co0, tr, st));
-      if (w1) EGONN_TRY(tail_weights_absmax(w1, (int64_t)K1 * ci0 * co0, tr, st));
-      EGONN_TRY(pack_tail_weights(w0, K0, ci0, co0, out_in, tc, tr, st));
-      *d0 = tc;
-      tc += (size_t)K0 * ci0 * co0 * 2;
-      if (w1) {
-        EGONN_TRY(pack_tail_weights(w1, K1, ci0, co0, 0, tc, tr, st));
-        *d1 = tc;
-        tc += (size_t)K1 * ci0 * co0 * 2;
-      }
-      return EGONN_OK;
-    };
-    for (int i = 5; i <= 7; ++i) {
-      const BlockRef& b = m->blk[i];
-      EGONN_REQUIRE(b.cin == GLOBAL_CH && b.cout == GLOBAL_CH && !b.down, EGONN_ERR_STATE, "model: levels 5-7 are 128-channel blocks");
-      const int s0 = 4 * (i - 5);
-      EGONN_TRY(packg(s0 + 0, m->convs[i], 8, 128, 128, 0, &m->t_k2[i], nullptr, 0, nullptr));
-      EGONN_TRY(packg(s0 + 1, b.conv1, 27, 128, 128, 0, &m->t_c1[i], nullptr, 0, nullptr));
-      EGONN_TRY(packg(s0 + 2, b.conv2, 27, 128, 128, 0, &m->t_c2[i], nullptr, 0, nullptr));
-    }
-    // head: g7 = x7 @ W1x1[7];  g6 = x6 @ W1x1[6] + tconv7(g7);  g5 = x5 @ W1x1[5] + tconv6(g6);  decoder Linear layers
-    EGONN_TRY(packg(12, m->g1x1[7], 1, 128, GLOBAL_CH, 0, &m->t_1x1[7], nullptr, 0, nullptr));
-    EGONN_TRY(packg(13, m->g1x1[6], 1, 128, GLOBAL_CH, 0, &m->t_1x1[6], m->gt[7], 8, &m->t_gt[7]));
-    EGONN_TRY(packg(14, m->g1x1[5], 1, 128, GLOBAL_CH, 0, &m->t_1x1[5], m->gt[6], 8, &m->t_gt[6]));
-    EGONN_TRY(packg(15, m->gdec.w0, 1, GLOBAL_CH, m->gdec.mid, 1, &m->t_m0, nullptr, 0, nullptr));
-    EGONN_TRY(packg(16, m->gdec.w1, 1, m->gdec.mid, GLOBAL_DIM, 1, &m->t_m1, nullptr, 0, nullptr));
-  }
   if (!m->conv0_unit) HIP_CHECK(hipMalloc(&m->conv0_unit, 2 * 4 * 3 * 64 * 16));
   EGONN_TRY(conv0_pack_unit(m->conv0, m->conv0_unit, st));
   EGONN_TRY(fold(m->bn[0], st));
@@ -810,10 +760,16 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   for (int i = 1; i <= 7; ++i) need += (size_t)P.cap[i] * 128 * 4 * 6 + (size_t)P.lv[i].rg27.cap_groups * 128 * 4;
   need += (size_t)P.cap[5] * (192 + 256 + 128 * 2) * 4 + (size_t)P.cap[3] * (96 + 32 + 32 + 3 + 64 * 2) * 4;
   need += (size_t)B * SEG_CHUNKS * 256 * 4 * 10 + (size_t)P.cap[3] * 32 + (4u << 20);
+  const size_t ks_floats = sconv_ksplit_scratch_floats(c);
+  need += ks_floats * 4 + 4096;
   for (int l = 0; l < EGONN_NUM_LEVELS; ++l) c->level_feat[l] = nullptr;
   EGONN_TRY(c->work_arena.ensure(need));
   Arena& A = c->work_arena;
   A.reset();
+  // partial tiles of the offset-split launches: ONE buffer, written by a convolution and consumed by its reducer before the
+  // next launch of the same stream writes it again
+  c->ks_part = ks_floats ? A.alloc<float>(ks_floats) : nullptr;
+  c->ks_part_floats = c->ks_part ? ks_floats : 0;
 #define WALLOC(var, count)                                                         \
   float* var = A.alloc<float>((size_t)(count));                                    \
   EGONN_REQUIRE(var != nullptr, EGONN_ERR_STATE, "work arena too small (" #var ")")
@@ -875,70 +831,11 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     return EGONN_OK;
   };
   static const bool presplit_ok = getenv("EGONN_NO_PRESPLIT") == nullptr;     // measurement switch: conv2 splits in its loop
-  // levels 5-7 + global head + decoder + pooling: one resident launch for fp32 maps (tail.hip)
-  const bool use_tail = !bf16 && c->tail_mode == 0 && c->conv_variant == 0 && m->t_m1 != nullptr && B <= EGONN_MAX_BATCH;
-  bool tail_done = false;
   const float *gated_t2 = nullptr, *gated_res = nullptr, *gated_gate = nullptr;     // level 1's block tail, evaluated by level 2's k=2 conv
   for (int i = 1; i <= 7; ++i) {
     const BlockRef& b = m->blk[i];
     const Level& L = P.lv[i];
     const int64_t n = P.cap[i];
-    if (use_tail && i == 5) {
-      TailArgs ta;
-      memset(&ta, 0, sizeof(ta));
-      ta.B = B;
-      ta.do_head = do_global ? 1 : 0;
-      ta.pool_mode = (flags & EGONN_FLAG_POOL_MAC) ? 2 : ((flags & EGONN_FLAG_POOL_SPOC) ? 0 : 1);
-      if (do_global && ta.pool_mode == 1)
-        EGONN_REQUIRE(m->gem_p, EGONN_ERR_STATE, "forward: GeM pooling needs the tensor 'global_pooling.pooling.p'");
-      ta.cnt = cnt;
-      for (int l = 0; l < EGONN_NUM_LEVELS; ++l) { ta.boff[l] = P.lv[l].boff; ta.cap[l] = (int)P.cap[l]; }
-      auto tmap = [](const RowGroups& rg) { return TailMap{rg.snbr, rg.gmask, rg.perm, rg.meta}; };
-      for (int li = 0; li < 3; ++li) {
-        const int lv = 5 + li;
-        const BlockRef& tb = m->blk[lv];
-        ta.rg27[li] = tmap(P.lv[lv].rg27);
-        ta.rg8[li] = tmap(P.lv[lv].rg8);
-        FALLOC(ty, P.cap[lv] * 128);
-        FALLOC(tt1, P.cap[lv] * 128);
-        FALLOC(tt2, P.cap[lv] * 128);
-        FALLOC(tx, P.cap[lv] * 128);
-        ta.y[li] = (float*)ty; ta.t1[li] = (float*)tt1; ta.t2[li] = (float*)tt2; ta.x[li] = (float*)tx;
-        ta.w_k2[li] = m->t_k2[lv]; ta.w_c1[li] = m->t_c1[lv]; ta.w_c2[li] = m->t_c2[lv]; ta.w_1x1[li] = m->t_1x1[lv];
-        ta.bn_s[li] = m->bn[lv].scale; ta.bn_h[li] = m->bn[lv].shift;
-        ta.n1_s[li] = tb.n1.scale; ta.n1_h[li] = tb.n1.shift;
-        ta.n2_s[li] = tb.n2.scale; ta.n2_h[li] = tb.n2.shift;
-        ta.eca_w[li] = tb.eca; ta.eca_k[li] = tb.eca_k;
-        x[lv] = tx;
-        c->level_feat[lv] = tx;
-        c->level_ch[lv] = 128;
-      }
-      ta.x4 = (const float*)x[4];
-      if (do_global) {
-        ta.rgT[0] = tmap(P.lv[6].rgT);
-        ta.rgT[1] = tmap(P.lv[5].rgT);
-        ta.w_t[0] = m->t_gt[7]; ta.w_t[1] = m->t_gt[6];
-        ta.w_m0 = m->t_m0; ta.w_m1 = m->t_m1;
-        ta.b0 = m->gdec.b0; ta.b1 = m->gdec.b1; ta.gem_p = m->gem_p;
-        EGONN_REQUIRE(m->gdec.cin == 128 && m->gdec.mid == 192 && m->gdec.cout == 256, EGONN_ERR_STATE, "global decoder: unexpected layer sizes");
-        WALLOC(tg7, P.cap[7] * GLOBAL_CH);
-        WALLOC(tg6, P.cap[6] * GLOBAL_CH);
-        WALLOC(tg5, P.cap[5] * GLOBAL_CH);
-        WALLOC(tgh, P.cap[5] * 192);
-        ta.g7 = tg7; ta.g6 = tg6; ta.g5 = tg5; ta.gh = tgh;
-        ta.out_global = out_global;
-      }
-      ta.sums = c->tail_sums; ta.flags = c->tail_flags; ta.err = c->dev_flags;
-      ta.w_inv = m->t_inv;
-      ta.trace = g_sconv_trace;
-      {
-        ProfScope ps(c, st, "tail_kernel<128,128>/L5-7+head", PK_TAIL, 5, 27, 128, 128, 4);
-        EGONN_TRY(tail_forward(ta, st));
-      }
-      DBG_SYNC("tail");
-      tail_done = true;
-      break;
-    }
     FALLOC(y, n * b.cin);
     char tag[64];
     {
@@ -1033,7 +930,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   DBG_SYNC("local head");
 
   // ---- global head + decoder + GeM (models/minkgl.py:46-60, 207-225; layers/pooling.py:82-86)
-  if (do_global && !tail_done) {
+  if (do_global) {
     FALLOC(g7, P.cap[7] * GLOBAL_CH);
     EGONN_TRY(dense_forward_ex(x[7], bf16, P.cap[7], 128, m->g1x1[7], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0,
                                g7, bf16, st, cnt + 7));
@@ -1168,29 +1065,6 @@ API int egonn_profile_fetch(egonn_ctx* c, int cap, int* n, char* names, float* m
       ms[w] = t;
       bytes[w] = Pn * r.cin * r.es + n_out * r.cout * r.es + (double)r.K * r.cin * r.cout * r.es + 8.0 * Pn;
       flops[w] = 2.0 * Pn * r.cin * r.cout;
-      if (r.kind == PK_TAIL) {
-        // the resident tail (tail.hip): the sum of the same formula over its 11 sparse convolutions (k=2,s=2 + 2 x k=3 of
-        // levels 5-7, the two transposed convolutions of the head) + the dense layers N * (Cin + Cout) * e (1x1 x 3, decoder)
-        double by = 0, fl = 0;
-        auto conv = [&](double pn, double no, int K) {
-          by += pn * 128 * 4 + no * 128 * 4 + (double)K * 128 * 128 * 4 + 8.0 * pn;
-          fl += 2.0 * pn * 128 * 128;
-        };
-        for (int l = 5; l <= 7; ++l) {
-          const double nl = (double)P.lv[l].n;
-          conv((double)P.lv[l - 1].n, nl, 8);
-          conv((double)pairs[l], nl, 27);
-          conv((double)pairs[l], nl, 27);
-          by += nl * 256 * 4; fl += 2.0 * nl * 128 * 128;                   // conv1x1
-        }
-        conv((double)P.lv[6].n, (double)P.lv[6].n, 8);
-        conv((double)P.lv[5].n, (double)P.lv[5].n, 8);
-        const double n5 = (double)P.lv[5].n;
-        by += n5 * (128 + 192) * 4 + n5 * (192 + 256) * 4;
-        fl += 2.0 * n5 * (128.0 * 192 + 192.0 * 256);
-        bytes[w] = by;
-        flops[w] = fl;
-      }
       ++w;
     }
     if (plain) { c->prof.pool.push_back(r.e0); c->prof.pool.push_back(r.e1); }

@@ -1217,6 +1217,56 @@ bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int s
   return level <= (env_level >= 0 ? env_level : split_max_level);
 }
 
+// Offset-split rule (see kernels.h): a function of (map kind, output level) only.
+//   kw      offset parts INSIDE a workgroup (sconv_split_kernel<..., KW>): the small maps are chains of K * Cin/32 dependent steps on
+//           workgroups of one wave per SIMD; KW waves per SIMD walk KW interleaved thirds / quarters of the offsets and hide each
+//           other's LDS and MFMA latencies.  Measured per layer, batch 16 (profiles/r06c_kw_sweep.txt): L4 128->128 70 -> 42 us,
+//           L5 k=3 67 / 62 -> 32 / 30, L5 k=2,s=2 27 -> 16, transposed 25 -> 15, L3 64->64 42 / 37 -> 38 / 35.  The rule stops where
+//           the launches stop gaining: levels 6-7 stay on the per-tile kernels (34 vs 23 us), level 3's 8-slot maps unsplit.
+//   kparts  offset parts as SEPARATE workgroups + a reducer launch (blockIdx.z): built, parity-green, measured
+//           (L5 k=3 65 -> 30 us, L4 128->128 67 -> 48), default off: the partial tiles are 16 MB per level-5 convolution and the step
+//           with four batches in flight loses 4-6 % against 1.5-3 % for the in-workgroup parts at the same serial gain.
+// EGONN_KSPLIT / EGONN_KSPLIT8 (kparts of the k=3 / 8-slot maps), EGONN_KSPLIT_KW / EGONN_KSPLIT_KW8, EGONN_KSPLIT_PARTS (column
+// parts per task, 0 = automatic): measurement overrides, comma lists indexed by the output level.
+void sconv_ksplit_defaults(KsRule* r) {
+  static const KsRule rule = [] {
+    KsRule q = {{{1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1}}, {{0, 0, 0, 2, 3, 4, 0, 0}, {0, 0, 0, 0, 2, 4, 0, 0}}, {0, 0, 0, 0, 0, 0, 0, 0}};
+    auto parse = [](const char* name, int8_t* dst) {
+      const char* e = getenv(name);
+      for (int l = 0; e && *e && l < EGONN_NUM_LEVELS; ++l) {
+        dst[l] = (int8_t)atoi(e);
+        e = strchr(e, ',');
+        if (e) ++e;
+      }
+    };
+    parse("EGONN_KSPLIT", q.kparts[0]);
+    parse("EGONN_KSPLIT8", q.kparts[1]);
+    parse("EGONN_KSPLIT_KW", q.kw[0]);
+    parse("EGONN_KSPLIT_KW8", q.kw[1]);
+    parse("EGONN_KSPLIT_PARTS", q.col_parts);
+    return q;
+  }();
+  *r = rule;
+}
+void sconv_ksplit_rule(const Ctx* ctx, int kind, int level, int* kparts, int* col_parts, int* kw) {
+  const KsRule& rule = ctx->ks_rule;
+  const int l = std::min(std::max(level, 0), EGONN_NUM_LEVELS - 1);
+  const int K = kind == 0 ? 27 : 8, mc = kind == 0 ? 0 : 1;
+  *kparts = std::min(std::max((int)rule.kparts[mc][l], 1), K);
+  *col_parts = rule.col_parts[l];
+  if (kw) *kw = rule.kw[mc][l];
+}
+size_t sconv_ksplit_scratch_floats(const Ctx* ctx) {
+  size_t need = 0;
+  for (int kind = 0; kind <= 2; ++kind)
+    for (int l = (kind == 2 ? 0 : 1); l < EGONN_NUM_LEVELS - (kind == 2 ? 1 : 0); ++l) {
+      int kp, cp;
+      sconv_ksplit_rule(ctx, kind, l, &kp, &cp);
+      if (kp > 1) need = std::max(need, (size_t)kp * rowgroup_cap_groups(ctx->plan, l) * 16 * 128);
+    }
+  return need;
+}
+
 int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, const void* Wp, const void* Wsp, int cin, int cout,
               int bf16, const float* scale, const float* shift, int relu, void* out, float* psum, float* scratch,
               size_t scratch_floats, hipStream_t stream) {
@@ -1246,10 +1296,14 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
       EGONN_TRY(pack_split_weights(W, K, cin, cout, 0, 0, scratch, stream));
       Wsp = scratch;
     }
+    int kparts = 1, col_parts = 0, kw = 0;
+    sconv_ksplit_rule(ctx, kind, level, &kparts, &col_parts, &kw);
+    if (ctx->gated_in2) { kparts = 1; kw = 0; }
+    if (cin < 64) kw = 0;
     return sconv_split_forward(reinterpret_cast<const float*>(in), P.cap[lin], rg, rg.cap_groups, Wsp, cin, cout, scale, shift,
                                relu, reinterpret_cast<float*>(out), psum, stream,
                                ctx->conv_variant >= 1000 ? ctx->conv_variant - 1000 : 0, ctx->split_io, ctx->gated_in2, ctx->gated_gate,
-                               P.batch);
+                               P.batch, kparts, ctx->ks_part, ctx->ks_part_floats, col_parts, kw);
   }
   EGONN_REQUIRE(ctx->split_io == 0 && !ctx->gated_in2, EGONN_ERR_STATE,
                 "sconv: split-form maps and gated inputs are read and written by the split kernel only");

@@ -49,11 +49,13 @@ const char* egonn_last_error(void);
  * HIP kernel (cross-check of the MFMA kernels), on = 2 / 4 force the per-wave / the workgroup-cooperative MFMA kernel (A/B
  * timing); 0 = product choice.  Never set by the product path. */
 int egonn_debug_set_naive_conv(egonn_ctx* ctx, int on);
-/* tests / measurements only: mode 1 (the default, the product path) runs levels 5-7 of the trunk and the global head of
- * egonn_forward as per-layer launches; 0 = fp32 maps: ONE resident launch (csrc/tail.hip: clusters of 8 workgroups per scan,
- * weights streamed once per 16-column tile, epoch flags between stages) — built as a replacement, measured slower (DESIGN.md
- * 3.1e), kept opt-in and tested.  Results of the two paths differ by summation order only (<= 3e-6 of the largest output). */
-int egonn_debug_set_tail(egonn_ctx* ctx, int mode);
+/* tests / measurements only: the offset-split rule of this context's fp32 sparse convolutions on the small maps (the rule is
+ * a function of (map class, output level), never of the batch).  map_class 0 = the k=3 maps, 1 = the 8-slot maps (k=2,s=2 and
+ * transposed); kparts = offset parts as separate workgroups + a fixed-order reducer launch (1 = none); kw = offset parts inside a
+ * workgroup (0 / 1 = none, 2..4); col_parts = column parts per task (0 = automatic); -1 keeps a field.  Every setting sums a
+ * row's offsets in a fixed partition and order: results are deterministic and batch-invariant under each, and differ between
+ * settings by summation order only (<= 3e-6 of the largest output; tests/test_gpu_ksplit.py). */
+int egonn_debug_set_ksplit(egonn_ctx* ctx, int map_class, int level, int kparts, int kw, int col_parts);
 /* measurement hook: buffer for the traced sparse-conv build (debug variant 128): 8 u64 per wave task; NULL = off */
 int egonn_debug_set_trace(void* device_buffer);
 /* measurement hook: device copies of a map's row-group tables (gmask [groups], snbr [groups][K][16], nullable).  [SYNC] */

@@ -385,6 +385,9 @@ def test_split_conv_matches_exact_fp32(gpu):
     ref = gpu._lib.Context(coord_bits=12)
     ref.voxelize(pts, off, 0, [0.1])
     ref.set_naive_conv(True)
+    for mc in (0, 1):                  # (the offset parts of the small maps have their own test: tests/test_gpu_ksplit.py)
+        for lv in range(8):
+            ctx.set_ksplit(mc, lv, kparts=1, kw=0, col_parts=0)
     torch.manual_seed(11)
     worst = 0.0
     plans = [(0, 1, 32, 32), (1, 1, 32, 32), (0, 2, 32, 64), (0, 2, 64, 64), (1, 3, 64, 64), (2, 3, 64, 64), (0, 3, 64, 128),

@@ -297,16 +297,16 @@ __global__ __launch_bounds__(COUT * 2) void sconv_split_reduce_kernel(const Spli
   split_epilogue<COUT>(p, a0, a1, ns, row_v, gw, l15, g4);
 }
 
-template <int NSW, int NW, bool GATED = false, int KW = 1>
+template <int NSW, int NW, bool GATED = false, int D = 2>
 struct SplitGeom {
   static constexpr int NS = NSW;                         // 32-column slices a workgroup owns
   static constexpr int SLAB = NS * 4096;                 // bytes of W[k][cb][its columns]: hi | lo fragments
   static constexpr int NPIECE = NS * 4;                  // 1 KB DMA pieces per slab
   static constexpr int WPP = (NPIECE + NW - 1) / NW;     // pieces a wave issues per step (at most)
   static constexpr int TBL_BYTES = 27 * 64;              // one group's table: 27 offsets x 16 slots
-  static constexpr int WAVE_LDS = 2048 + 2 * 2048 + (GATED ? 2 * 2048 : 0);   // table (padded) + two ring slots of 16 x 128 B (+ two of the second operand)
-  static constexpr int WAVES_AT = KW * 2 * SLAB;         // two slabs per offset part
-  static constexpr int LDS_BYTES = WAVES_AT + NW * KW * WAVE_LDS;
+  static constexpr int WAVE_LDS = 2048 + D * 2048 + (GATED ? 2 * 2048 : 0);   // table (padded) + D ring slots of 16 x 128 B (+ two of the second operand)
+  static constexpr int WAVES_AT = D * SLAB;
+  static constexpr int LDS_BYTES = WAVES_AT + NW * WAVE_LDS;
 };
 
 // NSW: 32-column slices per workgroup (grid.y = COUT/32/NSW column parts).  Small maps (levels 3-4: a few hundred tasks, less
@@ -317,10 +317,16 @@ struct SplitGeom {
 // of the chip: neither the XCD slices nor the longest-first order matter), and NOTHING in front of the header loads: group
 // count, masks, neighbour table and output rows are requested together — the chain in front of the first gather is two
 // global round trips (header, rows) instead of five (count, order, masks, table, rows).
-template <int CIN, int COUT, int NW, int NSW, bool TRACE = false, bool GATED = false, bool KS = false, int KW = 1>
-__global__ __launch_bounds__(NW * KW * 64) void sconv_split_kernel(const SplitArgs p) {
-  using GEO = SplitGeom<NSW, NW, GATED, KW>;
-  static_assert(KW == 1 || (!GATED && !TRACE), "offset parts inside a workgroup: plain instantiations only");
+// D: ring depth (slabs and gathered rows).  D = 2 is the loop described above (requests of step i+1 at the top of step i, drained
+// with vmcnt(0)).  D > 2 (the small maps): requests run D-1 steps ahead and the waits are COUNTED — every wave issues exactly
+// WPP + 2 vector-memory instructions per step (an absent offset / a step past the end is an out-of-range request: zeros, no
+// traffic; these launches are nowhere near the texture path's limit), waits until all but the youngest D-2 steps' worth have
+// landed, and one s_barrier per step both publishes slab i and retires slot i-1, which the requests of step i+D-1 then fill.
+// A step of a small map then costs its arithmetic, not a memory round trip (measured: DESIGN.md §3.1h).
+template <int CIN, int COUT, int NW, int NSW, bool TRACE = false, bool GATED = false, bool KS = false, int D = 2>
+__global__ __launch_bounds__(NW * 64) void sconv_split_kernel(const SplitArgs p) {
+  using GEO = SplitGeom<NSW, NW, GATED, D>;
+  static_assert(D == 2 || (!GATED && !TRACE), "deep rings: plain instantiations only");
   static_assert(!GATED || CIN == 32, "gated input: one channel block");
   constexpr int NS = NSW, NSTOT = COUT / 32, NCB = CIN / 32;
   static_assert(NSTOT % NSW == 0, "column parts");
@@ -330,15 +336,10 @@ __global__ __launch_bounds__(NW * KW * 64) void sconv_split_kernel(const SplitAr
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   typedef __attribute__((address_space(3))) char lds_char;
   const int lane = threadIdx.x & 63;
-  const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // KW > 1: the workgroup's waves are KW offset parts x NW groups.  Part kw walks the offsets k with k % KW == kw of its group's
-  // task in lock-step with the other parts (own slab pair, own ring), so that a SIMD holds KW waves that hide each other's LDS
-  // and MFMA latencies; the parts' accumulators are summed through LDS in fixed order (part 0 + part 1 + ...) after the loop.
-  const int wave = KW == 1 ? wave_id : wave_id % NW;     // group of the task
-  const int kw = KW == 1 ? 0 : wave_id / NW;             // offset part
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, g4 = lane >> 4;
   const int K = p.K;
-  char* const wl = smem + GEO::WAVES_AT + wave_id * GEO::WAVE_LDS;
+  char* const wl = smem + GEO::WAVES_AT + wave * GEO::WAVE_LDS;
   int32_t* const tbl = reinterpret_cast<int32_t*>(wl);
   char* const ring = wl + 2048;
   const uint32_t smem_addr = (uint32_t)(uintptr_t)(lds_char*)smem;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(NW * KW * 64) void sconv_split_kernel(const SplitAr
   const uint32_t rd0 = wl_addr + 2048 + (uint32_t)(l15 * 128 + ((g4 ^ (l15 & 7)) * 16));
   const uint32_t rd1 = wl_addr + 2048 + (uint32_t)(l15 * 128 + (((4 + g4) ^ (l15 & 7)) * 16));
   const uint32_t tb0 = wl_addr + (uint32_t)((lane >> 3) * 4);          // table entry of this lane's DMA rows (L>>3, 8+(L>>3))
-  const uint32_t wrd = smem_addr + (uint32_t)(kw * 2 * SLAB + lane * 16);   // fragment read address inside a slab piece (this part's slab pair)
+  const uint32_t wrd = smem_addr + (uint32_t)(lane * 16);              // fragment read address inside a slab piece
   const int dma_chunk = ((lane & 7) ^ (lane >> 3)) * 16;
   const int w_lane = lane * 16;
 
@@ -405,16 +406,6 @@ __global__ __launch_bounds__(NW * KW * 64) void sconv_split_kernel(const SplitAr
       gm &= rm;
       if (!U) continue;
     }
-    const uint32_t gm_all = gm;                          // (the group's offsets in this launch's range, all parts)
-    int n_steps_wg = 0;                                  // KW > 1: lock-steps of the workgroup = the longest part's
-    if constexpr (KW > 1) {
-      constexpr uint32_t base = KW == 2 ? 0x5555555u : (KW == 3 ? 0x1249249u : 0x1111111u);     // k % KW == 0
-#pragma unroll
-      for (int q = 0; q < KW; ++q) n_steps_wg = max(n_steps_wg, __popc(U & (base << q) & 0x07FFFFFFu) * NCB);
-      U &= base << kw;
-      gm &= base << kw;
-    }
-    (void)gm_all;
     f32x4 gq0 = {0.f, 0.f, 0.f, 0.f}, gq1 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (GATED) {
       // scan of this wave's group (a group never straddles two scans): last b with meta[1 + b] <= gw; the gate of the lane's channels
@@ -442,7 +433,7 @@ __global__ __launch_bounds__(NW * KW * 64) void sconv_split_kernel(const SplitAr
     if constexpr (TRACE) tr[1] = now();
     // ---- step generator (scalar, identical in every wave): set bits of the union x channel blocks
     uint32_t mk = U & 0x07FFFFFFu;
-    const int n_steps = KW == 1 ? __popc(mk) * NCB : n_steps_wg;
+    const int n_steps = __popc(mk) * NCB;
     int gen_k = 0, gen_cb = 0;
     auto gen = [&](int& k, int& cb) {                      // k = 27: past the end
       const bool need = (gen_cb == 0);
@@ -465,7 +456,7 @@ __global__ __launch_bounds__(NW * KW * 64) void sconv_split_kernel(const SplitAr
       for (int q = 0; q < WPP; ++q) {
         const int pc = wave + NW * q;
         if (NPIECE % NW == 0 || pc < NPIECE)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_char*)(smem + (kw * 2 + slot) * SLAB + pc * 1024), 16, w_lane, woff + pc * 1024, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_char*)(smem + slot * SLAB + pc * 1024), 16, w_lane, woff + pc * 1024, 0, 0);
       }
       if ((gm >> k) & 1u) {
         __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(ring + slot * 2048), 16, i0, dma_chunk, cb * 128, 0, 0);
@@ -549,6 +540,66 @@ __global__ __launch_bounds__(NW * KW * 64) void sconv_split_kernel(const SplitAr
       }(std::make_integer_sequence<int, NS>{});
     };
 
+    if constexpr (D > 2) {
+      constexpr int C = WPP + 2;                         // vector-memory instructions per wave and step
+      static_assert(NPIECE % NW == 0, "counted waits need the same number of slab pieces in every wave");
+      static_assert((D - 2) * C <= 63, "vmcnt range");
+      // counted requests of one step: slab pieces + the two row pieces; out of range (zeros, no traffic) past the end / without the offset
+      auto issue_c = [&](int slot, int k, int cb, int32_t j0, int32_t j1) {
+        const int woff = k < 27 ? ((k * NCB + cb) * NSTOT + ns0) * 4096 : 0x7F000000;
+#pragma unroll
+        for (int q = 0; q < WPP; ++q) {
+          const int pc = wave + NW * q;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_char*)(smem + slot * SLAB + pc * 1024), 16, w_lane, woff + pc * 1024, 0, 0);
+        }
+        __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(ring + slot * 2048), 16, j0, dma_chunk, cb * 128, 0, 0);
+        __builtin_amdgcn_struct_ptr_buffer_load_lds(a_rsrc, (lds_char*)(ring + slot * 2048 + 1024), 16, j1, dma_chunk, cb * 128, 0, 0);
+      };
+      // table entries of offset k (always read: the select happens after the wait, never on a register still in flight)
+      auto idx_issue = [&](int k, int32_t& j0, int32_t& j1) {
+        const uint32_t tb = tb0 + (uint32_t)(min(k, 26) * 64);
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:32" : "=&v"(j0), "=&v"(j1) : "v"(tb) : "memory");
+      };
+      // the compute side walks the same (k, cb) sequence D-1 steps behind the requests
+      uint32_t mkc = mk;
+      int c_k = 0, c_cb = 0;
+      auto gen_c = [&]() {
+        if (c_cb == 0) { c_k = __builtin_ctz(mkc | 0x80000000u); mkc &= mkc - 1; }
+        const int k = c_k;
+        c_cb = (c_cb + 1 < NCB) ? c_cb + 1 : 0;
+        return k;
+      };
+      int kn, cbn;
+      int32_t j0, j1;
+#pragma unroll
+      for (int s0 = 0; s0 < D - 1; ++s0) {
+        gen(kn, cbn);
+        idx_issue(kn, j0, j1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(j0), "+v"(j1)::"memory");
+        const bool hs = kn < 27 && ((gm >> kn) & 1u);
+        issue_c(s0, kn, cbn, hs ? j0 : -1, hs ? j1 : -1);
+      }
+      gen(kn, cbn);
+      idx_issue(kn, j0, j1);
+      int slot = 0, islot = D - 1;
+      for (int i = 0; i < n_steps; ++i) {
+        asm volatile("s_waitcnt vmcnt(%2) lgkmcnt(0)" : "+v"(j0), "+v"(j1) : "n"((D - 2) * C) : "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+          const bool hs = kn < 27 && ((gm >> kn) & 1u);
+          issue_c(islot, kn, cbn, hs ? j0 : -1, hs ? j1 : -1);
+        }
+        gen(kn, cbn);
+        idx_issue(kn, j0, j1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int kc = gen_c();
+        if ((gm >> kc) & 1u) compute(slot);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot + 1 == D ? 0 : slot + 1;
+        islot = islot + 1 == D ? 0 : islot + 1;
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(j0), "+v"(j1)::"memory");      // the out-of-range requests past the end
+    } else {
     // ---- prologue: step 0 in flight, rows of step 1 looked up
     int k0, cb0, k1, cb1;
     int32_t i0 = -1, i1 = -1;
@@ -573,7 +624,7 @@ __global__ __launch_bounds__(NW * KW * 64) void sconv_split_kernel(const SplitAr
       idx_read(k2, i0, i1);                              // (the DMA above has read its index registers at issue)
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TRACE) tb = now();
-      const bool has = k0 < 27 && ((gm >> k0) & 1u) != 0;
+      const bool has = ((gm >> k0) & 1u) != 0;
       if (has) compute(slot);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TRACE) tc = now();
@@ -585,34 +636,14 @@ __global__ __launch_bounds__(NW * KW * 64) void sconv_split_kernel(const SplitAr
       }
       k0 = k1; k1 = k2; cb1 = cb2;
     }
+    }
     if constexpr (TRACE) tr[9] = now();
 
-    // ---- KW > 1: the parts' tiles through LDS (the slabs are retired: the loop ended on a barrier), summed in part order
-    if constexpr (KW > 1) {
-      f32x4* const red = reinterpret_cast<f32x4*>(smem);
-      if (kw > 0) {
-#pragma unroll
-        for (int ns = 0; ns < NS; ++ns) {
-          red[(((kw - 1) * NW + wave) * NS * 2 + ns * 2) * 64 + lane] = acc[ns][0];
-          red[(((kw - 1) * NW + wave) * NS * 2 + ns * 2 + 1) * 64 + lane] = acc[ns][1];
-        }
-      }
-      __syncthreads();
-      if (kw == 0) {
-#pragma unroll
-        for (int q = 1; q < KW; ++q)
-#pragma unroll
-          for (int ns = 0; ns < NS; ++ns) {
-            acc[ns][0] += red[(((q - 1) * NW + wave) * NS * 2 + ns * 2) * 64 + lane];
-            acc[ns][1] += red[(((q - 1) * NW + wave) * NS * 2 + ns * 2 + 1) * 64 + lane];
-          }
-      }
-    }
     // ---- epilogue: BN scale/shift (+ReLU), one 16-byte store per tile; optional per-group column sums
-    if (live && kw == 0) {
+    if (live) {
       if constexpr (KS) {
         // offset-split launch: the raw tiles, in accumulator layout (sconv_split_reduce_kernel finishes them)
-        if (gm_all) {
+        if (gm) {
           float* dst = p.part + (((int64_t)blockIdx.z * p.cap_groups + gw) * NSTOT + ns0) * 512 + lane * 4;
 #pragma unroll
           for (int ns = 0; ns < NS; ++ns) {
@@ -648,12 +679,12 @@ static int launch_split_reduce(const SplitArgs& a, int64_t groups_hint, hipStrea
   return EGONN_OK;
 }
 
-template <int CIN, int COUT, int NW, int NSW, bool TRACE = false, bool GATED = false, bool KS = false, int KW = 1>
+template <int CIN, int COUT, int NW, int NSW, bool TRACE = false, bool GATED = false, bool KS = false, int D = 2>
 static int launch_split(const SplitArgs& a, int64_t groups_hint, hipStream_t stream) {
-  using GEO = SplitGeom<NSW, NW, GATED, KW>;
+  using GEO = SplitGeom<NSW, NW, GATED, D>;
   static AttrOnce attr_done;
   if (attr_done.need()) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_split_kernel<CIN, COUT, NW, NSW, TRACE, GATED, KS, KW>),
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_split_kernel<CIN, COUT, NW, NSW, TRACE, GATED, KS, D>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done.mark();
   }
@@ -665,11 +696,11 @@ static int launch_split(const SplitArgs& a, int64_t groups_hint, hipStream_t str
   hipEvent_t ev_stop = nullptr;
   if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch (an offset-split layer: begin of this one .. end of its reducer)
     ev_stop = pev[1];
-    hipExtLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, NSW, TRACE, GATED, KS, KW>), grid, dim3(NW * KW * 64), GEO::LDS_BYTES, stream,
+    hipExtLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, NSW, TRACE, GATED, KS, D>), grid, dim3(NW * 64), GEO::LDS_BYTES, stream,
                           pev[0], a.kp_n > 1 ? nullptr : pev[1], 0, a);
     pev[0] = pev[1] = nullptr;
   } else {
-    hipLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, NSW, TRACE, GATED, KS, KW>), grid, dim3(NW * KW * 64), GEO::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((sconv_split_kernel<CIN, COUT, NW, NSW, TRACE, GATED, KS, D>), grid, dim3(NW * 64), GEO::LDS_BYTES, stream, a);
   }
   HIP_CHECK(hipGetLastError());
   if (a.kp_n > 1) return launch_split_reduce<COUT>(a, groups_hint, stream, ev_stop);
@@ -689,7 +720,7 @@ bool sconv_split_supported(int cin, int cout) {
 int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
                         int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
                         int cfg, int split_io, const float* gated_in2, const float* gated_gate, int B, int kparts, float* part,
-                        size_t part_floats, int col_parts, int kw) {
+                        size_t part_floats, int col_parts, int depth) {
   EGONN_REQUIRE(rg.built, EGONN_ERR_STATE, "sconv: row-group tables not built");
   EGONN_REQUIRE(sconv_split_supported(cin, cout), EGONN_ERR_INVALID, "sconv(split): channel plan %d->%d not supported", cin, cout);
   EGONN_REQUIRE((uint64_t)n_in_cap * cin * 4 < (1ull << 32) - (1ull << 20), EGONN_ERR_INVALID,
@@ -721,8 +752,6 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
   int parts = 1;
   if (parts_sel > 0) parts = std::min(ns_tot, 1 << (parts_sel - 1));
   else if (col_parts > 0) parts = std::min(ns_tot, col_parts);      // the layer's rule (offset-split launches)
-  else if (kw > 1) parts = std::max(1, ns_tot / 2);                 // in-workgroup offset parts: 64 columns per workgroup, whatever the
-                                                                    // capacity (the choice of KW must not depend on the batch)
   else if (ns_tot >= 2 && cdiv(groups_hint, 4) < 700) {  // less than one round of the chip: two column parts per task
     parts = 2;                                           // (measured, profiles/r03i_colparts.txt: L4 128->128 101 / 80 / 93 us
   }                                                      //  with 1 / 2 / 4 parts, 64->128 56 / 45 / 51, L3 64->64 43 / 41; round 5, fp16 kernels:
@@ -734,18 +763,17 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
     a.in2 = gated_in2; a.gate = gated_gate; a.B = B;
     return launch_split<32, 32, 4, 1, false, true>(a, groups_hint, stream);
   }
-#define EGONN_SP_KW(CI, CO, NWW, NSWW, KWW)                                                               \
-  if constexpr (SplitGeom<NSWW, NWW, false, KWW>::LDS_BYTES <= 160 * 1024) {                              \
-    if (kw == KWW && a.kp_n > 1) return launch_split<CI, CO, NWW, NSWW, false, false, true, KWW>(a, groups_hint, stream);  \
-    if (kw == KWW) return launch_split<CI, CO, NWW, NSWW, false, false, false, KWW>(a, groups_hint, stream); \
-  }
 #define EGONN_SP_LOCK1(CI, CO, NWW, NSWW)                                                                 \
   if (cin == CI && cout == CO && shape == 100 + NWW * 10 + 2 && nsw == NSWW && !trace) {                  \
     if constexpr (NWW == 4 && CI >= 64) {                                                                 \
-      EGONN_SP_KW(CI, CO, NWW, NSWW, 2) EGONN_SP_KW(CI, CO, NWW, NSWW, 3) EGONN_SP_KW(CI, CO, NWW, NSWW, 4) \
+      if (a.kp_n > 1 && depth == 6) return launch_split<CI, CO, NWW, NSWW, false, false, true, 6>(a, groups_hint, stream); \
+      if (a.kp_n > 1 && depth == 4) return launch_split<CI, CO, NWW, NSWW, false, false, true, 4>(a, groups_hint, stream); \
+      if (a.kp_n > 1 && depth == 3) return launch_split<CI, CO, NWW, NSWW, false, false, true, 3>(a, groups_hint, stream); \
       if (a.kp_n > 1) return launch_split<CI, CO, NWW, NSWW, false, false, true>(a, groups_hint, stream); \
+      if (depth == 4) return launch_split<CI, CO, NWW, NSWW, false, false, false, 4>(a, groups_hint, stream); \
+      if (depth == 3) return launch_split<CI, CO, NWW, NSWW, false, false, false, 3>(a, groups_hint, stream); \
     }                                                                                                     \
-    EGONN_REQUIRE(a.kp_n == 1 && kw <= 1, EGONN_ERR_INVALID, "sconv(split): no offset-split instantiation for %d->%d (parts %d, kw %d)", cin, cout, a.kp_n, kw); \
+    EGONN_REQUIRE(a.kp_n == 1, EGONN_ERR_INVALID, "sconv(split): no offset-split instantiation for %d->%d", cin, cout); \
     return launch_split<CI, CO, NWW, NSWW>(a, groups_hint, stream);                                       \
   }
 #define EGONN_SP_LOCK(CI, CO, NWW)                                                                        \
