@@ -33,6 +33,7 @@ _SIGS = [
     ("egonn_ctx_reserve", C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
     ("egonn_voxelize_device", C.c_int, [_P, _P, C.c_int64, _P, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     ("egonn_plan_status", C.c_int, [_P, _P]),
+    ("egonn_ctx_set_exact_fp32", C.c_int, [_P, C.c_int]),
     ("egonn_level_capacity", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
     ("egonn_graph_begin", C.c_int, [_P]),
     ("egonn_graph_end", C.c_int, [_P, C.POINTER(_P)]),
@@ -135,9 +136,14 @@ class CapacityError(EgonnError):
     """status 5: the batch did not fit the capacities of egonn_ctx_reserve (the exact-size eager path still works)"""
 
 
+class Fp16RangeError(EgonnError):
+    """status 6: an fp32 sparse convolution on the fp16-split pipe met a non-finite accumulator (activation beyond +-65504 or
+    non-finite input): the batch's outputs are invalid; Context.set_exact_fp32(True) and run it again"""
+
+
 def check(rc: int):
     if rc != 0:
-        cls = CapacityError if rc == 5 else EgonnError
+        cls = CapacityError if rc == 5 else (Fp16RangeError if rc == 6 else EgonnError)
         raise cls(f"libegonn_hip: {_err(load())} (code {rc})", rc)
 
 
@@ -331,6 +337,11 @@ class Context:
     def set_naive_conv(self, on: bool):
         """tests only: route this context's sparse convolutions through the plain (non-MFMA) kernel."""
         check(self.lib.egonn_debug_set_naive_conv(self.h, int(on)))
+
+    def set_exact_fp32(self, on: bool):
+        """fp32 maps: True = every sparse convolution on the exact fp32 kernels (full fp32 range); False (default) = levels <= 5 on
+        the fp16-split matrix pipe (|activation| < 65504, guarded: plan_status raises with code 6)."""
+        check(self.lib.egonn_ctx_set_exact_fp32(self.h, int(bool(on))))
 
     def set_ksplit(self, map_class: int, level: int, kparts: int = -1, kw: int = -1, col_parts: int = -1):
         """tests / A-B only: offset-split rule of the fp32 sparse convolutions (map_class 0: k=3 maps, 1: 8-slot maps); -1 keeps a field."""

@@ -32,6 +32,8 @@ void set_error(const char* fmt, ...);
 #define EGONN_ERR_RANGE 3
 #define EGONN_ERR_STATE 4
 #define EGONN_ERR_CAPACITY 5   // a batch did not fit the capacities of egonn_ctx_reserve (the eager path still works)
+#define EGONN_ERR_FP16_RANGE 6 // an fp32 sparse convolution on the fp16-split pipe met a non-finite accumulator (activation beyond
+                               // +-65504 or non-finite input): rerun with egonn_ctx_set_exact_fp32(ctx, 1)
 
 #define HIP_CHECK(expr)                                                                   \
   do {                                                                                    \
@@ -216,7 +218,8 @@ struct Ctx {
   Plan plan;
   int32_t* host_counts = nullptr;    // pinned staging for the size query
   int32_t* dev_counts = nullptr;
-  int32_t* dev_flags = nullptr;      // bit 0 = out-of-range coordinate seen, bit 1 = batch larger than the reserved capacities
+  int32_t* dev_flags = nullptr;      // bit 0 = out-of-range coordinate seen, bit 1 = batch larger than the reserved capacities,
+                                     // bit 3 = fp16 range guard of the split convolutions (sconv_split.hip)
   bool reserved = false;             // egonn_ctx_reserve: fixed capacities, plans neither allocate nor synchronise
   int64_t reserve_points = 0;
   int reserve_batch = 0;

@@ -769,12 +769,6 @@ int plan_sync(Ctx* ctx, hipStream_t stream) {
     set_error("batch index %d >= batch size %d", ctx->host_counts[NL] - 1, B);
     return EGONN_ERR_RANGE;
   }
-  if (flags & 4) {
-    P.valid = false;
-    set_error("resident tail kernel: a sample-cluster wait timed out (a workgroup of the cluster was never scheduled); the "
-              "outputs of this batch are invalid");
-    return EGONN_ERR_HIP;
-  }
   if (flags & 2) {
     P.valid = false;
     set_error("the batch does not fit the reserved plan (points %d / capacity %lld; level rows %d %d %d %d %d %d %d %d / "
@@ -792,6 +786,12 @@ int plan_sync(Ctx* ctx, hipStream_t stream) {
   }
   P.n_input = ctx->host_counts[NL + 1];
   P.exact = true;
+  if (flags & 8) {             // (the plan itself is fine: the sizes above are valid; the feature maps of the forward are not)
+    set_error("an fp32 sparse convolution on the fp16-split matrix pipe met a non-finite accumulator: an activation beyond +-65504 "
+              "(the range of the fp16 operand parts) or a non-finite input; the outputs of this batch are invalid — "
+              "egonn_ctx_set_exact_fp32(ctx, 1) selects the exact fp32 kernels");
+    return EGONN_ERR_FP16_RANGE;
+  }
   return EGONN_OK;
 }
 

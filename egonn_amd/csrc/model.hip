@@ -230,11 +230,18 @@ API int egonn_plan_status(egonn_ctx* c, void* stream) {
   EGONN_REQUIRE(c && (c->plan.valid || c->plan.built_reserved), EGONN_ERR_STATE,
                 "no coordinate plan (call egonn_voxelize / egonn_coords_set first)");
   HIP_CHECK(hipSetDevice(c->device));
-  if (c->plan.built_reserved) {          // a replayed graph rebuilt the plan behind the host's back: read the state again
-    c->plan.valid = true;
-    c->plan.exact = false;
-  }
-  return plan_sync(c, (hipStream_t)stream);
+  if (c->plan.built_reserved) c->plan.valid = true;   // a replayed graph rebuilt the plan behind the host's back
+  c->plan.exact = false;                 // read the state again: sizes (reserved plans) and the flags launches raise after the
+  return plan_sync(c, (hipStream_t)stream);   // plan was built (range guard of the fp16-split convolutions)
+}
+
+// fp32 feature maps: on = 1 runs every sparse convolution of this context on the exact fp32 kernels (v_mfma_f32_16x16x4_f32, the
+// full fp32 range), on = 0 (default) the levels <= 5 on the fp16-split matrix pipe (sconv_split.hip: |activation| < 65504, guarded:
+// egonn_plan_status reports EGONN_STATUS_FP16_RANGE).  The choice is per context and a function of the layer, never of the batch.
+API int egonn_ctx_set_exact_fp32(egonn_ctx* c, int on) {
+  EGONN_REQUIRE(c && (on == 0 || on == 1), EGONN_ERR_INVALID, "ctx_set_exact_fp32: bad argument");
+  c->split_max_level = on ? -1 : 5;
+  return EGONN_OK;
 }
 
 API int egonn_coords_set(egonn_ctx* c, const int32_t* coords, int64_t n, int B, void* stream) {

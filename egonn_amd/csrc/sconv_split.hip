@@ -156,6 +156,11 @@ struct SplitArgs {
   // boundary, nothing is synchronised in here.
   float* part = nullptr;
   int kp_n = 1;
+  // RANGE GUARD.  fp16 parts hold |x| < 65520: a finite fp32 activation beyond that becomes Inf in split8h, every accumulator
+  // that gathers it becomes Inf or NaN (Inf * 0, Inf - Inf), and the epilogue — which sees every accumulator before BN / ReLU can
+  // hide it — raises bit 3 of the plan's flag word (egonn_plan_status: EGONN_STATUS_FP16_RANGE; egonn_ctx_set_exact_fp32 selects
+  // the exact kernels).  Non-finite INPUTS raise it too: the flag says "this launch's fp32 semantics are not guaranteed".
+  int32_t* flags = nullptr;
 };
 __host__ __device__ static inline uint32_t ks_range_mask(int kp, int kp_n, int K) {      // offsets [kp*K/kp_n, (kp+1)*K/kp_n)
   const int k0 = kp * K / kp_n, k1 = (kp + 1) * K / kp_n;
@@ -197,6 +202,12 @@ __device__ static inline void split_epilogue(const SplitArgs& p, const f32x4& a0
   const float winv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.Wsp) + p.w_bytes);   // 1 / (pack scale): a power of two
   float sums[2][4];
   f32x4 vv[2];
+  {
+    // range guard: (x - x) is 0 for finite x and NaN for Inf / NaN, and NaN is sticky under addition — one test for the eight values
+    const f32x4 z = (a0 - a0) + (a1 - a1);
+    const float zz = (z[0] + z[1]) + (z[2] + z[3]);
+    if (__builtin_expect(zz != 0.f, 0) && p.flags) atomicOr(p.flags, 8);
+  }
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int c0 = ns * 32 + nt * 16 + 4 * g4;
@@ -689,7 +700,7 @@ bool sconv_split_supported(int cin, int cout) {
 int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
                         int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
                         int cfg, int split_io, const float* gated_in2, const float* gated_gate, int B, int kparts, float* part,
-                        size_t part_floats, int col_parts, int kw) {
+                        size_t part_floats, int col_parts, int kw, int32_t* flags) {
   EGONN_REQUIRE(rg.built, EGONN_ERR_STATE, "sconv: row-group tables not built");
   EGONN_REQUIRE(sconv_split_supported(cin, cout), EGONN_ERR_INVALID, "sconv(split): channel plan %d->%d not supported", cin, cout);
   EGONN_REQUIRE((uint64_t)n_in_cap * cin * 4 < (1ull << 32) - (1ull << 20), EGONN_ERR_INVALID,
@@ -703,6 +714,7 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
   a.in_rows = (uint32_t)n_in_cap;
   a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * 4);           // the fragments; the pack scale's inverse sits right behind them
   a.K = rg.K; a.relu = relu ? 1 : 0; a.cap_groups = rg.cap_groups;
+  a.flags = flags;
   a.in_split = (split_io & 1) ? 1 : 0;
   a.out_split = (split_io & 2) ? 1 : 0;
   if (kparts > 1) {

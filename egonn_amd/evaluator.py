@@ -31,6 +31,18 @@ class DescriptorExtractor:
         model = model or self.model
         pc = pc if isinstance(pc, torch.Tensor) else torch.as_tensor(np.asarray(pc), dtype=torch.float32)
         out = self.extract([pc], model=model)
+        ctx = model.context()
+        try:                                           # (the host waits for the results below anyway)
+            ctx.plan_status()
+        except _lib.Fp16RangeError:
+            # an activation left the range of the fp16 operand parts (models/minkgl.py:105 is fp32 arithmetic): this scan again on
+            # the exact fp32 kernels
+            ctx.set_exact_fp32(True)
+            try:
+                out = self.extract([pc], model=model)
+                ctx.plan_status()
+            finally:
+                ctx.set_exact_fp32(False)
         n = int(out['count'][0].item())
         global_embedding = out['global'].cpu().numpy()
         return global_embedding, out['keypoints'][0, :n].cpu(), out['descriptors'][0, :n].cpu()

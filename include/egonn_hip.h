@@ -32,7 +32,10 @@ typedef struct egonn_model egonn_model;   /* EgoNN weights registered by state_d
 enum { EGONN_QUANT_CARTESIAN = 0, EGONN_QUANT_POLAR = 1 };
 /* status codes returned by every entry point (0 = ok; egonn_last_error() holds the text) */
 enum { EGONN_STATUS_OK = 0, EGONN_STATUS_INVALID = 1, EGONN_STATUS_HIP = 2, EGONN_STATUS_RANGE = 3, EGONN_STATUS_STATE = 4,
-       EGONN_STATUS_CAPACITY = 5 };
+       EGONN_STATUS_CAPACITY = 5,
+       /* an fp32 sparse convolution on the fp16-split matrix pipe met a non-finite accumulator (an activation beyond +-65504,
+        * or a non-finite input): the batch's outputs are invalid; egonn_ctx_set_exact_fp32(ctx, 1) and run it again */
+       EGONN_STATUS_FP16_RANGE = 6 };
 enum { EGONN_FLAG_DISABLE_GLOBAL = 1, EGONN_FLAG_DISABLE_LOCAL = 2, EGONN_FLAG_IGNORE_KP_REGRESSOR = 4,
        /* BASELINE configs[2]: feature maps and sparse-conv weights are bf16 in HBM (2 bytes per element), products
         * accumulate in fp32 on v_mfma_f32_16x16x32_bf16; the dense heads, pooling and all outputs stay fp32 */
@@ -89,6 +92,17 @@ int egonn_ctx_reserve(egonn_ctx* ctx, int64_t max_points, int batch_size, const 
 int egonn_voxelize_device(egonn_ctx* ctx, const float* points, int64_t n_rows, const int64_t* scan_offsets_dev,
                           int batch_size, int quant_mode, const float* step, void* stream);
 int egonn_plan_status(egonn_ctx* ctx, void* stream);
+/* Arithmetic of the fp32 sparse convolutions of this context (models/minkgl.py:105 -> ME's fp32 GEMM).  on = 0 (default): the
+ * maps of levels <= 5 run on the fp16 matrix pipe with split operands — x = hi + lo with fp16 parts (|x - hi - lo| <= 2^-22 |x|),
+ * weights scaled by a power of two per kernel, the three products hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32
+ * accumulation: within 3e-6 of the plain fp32 kernel relative to the largest output (tests/test_gpu_graph.py,
+ * tests/test_gpu_ksplit.py), the low part of an activation below 2^-3 carrying an ABSOLUTE error <= 2^-25.  RANGE: an fp16 part
+ * holds |x| < 65504; a finite activation beyond that turns every accumulator that gathers it into Inf / NaN, which the kernels'
+ * epilogues detect before BatchNorm / ReLU can hide it: egonn_plan_status (eager and reserved plans alike) then returns
+ * EGONN_STATUS_FP16_RANGE for that batch — there is no silent overflow.  on = 1: every level on the exact fp32 kernels
+ * (v_mfma_f32_16x16x4_f32: fp32's range, 1/16 of the matrix rate).  Levels 6-7, bf16 maps and channel plans without a split
+ * instantiation always run the exact kernels. */
+int egonn_ctx_set_exact_fp32(egonn_ctx* ctx, int on);
 /* Row capacity of a level of the current plan (= its row count for eager plans).  No sync. */
 int egonn_level_capacity(egonn_ctx* ctx, int level, int64_t* capacity);
 /* hipGraph capture of a sequence of calls on `stream` (hipStreamBeginCapture / EndCapture + Instantiate / hipGraphLaunch):
@@ -130,10 +144,10 @@ int egonn_conv_transpose(egonn_ctx* ctx, int level_in, const float* in, int cin,
  * (egonn_map_groups) — the conv2 epilogue form of MinkowskiGlobalPooling (layers/eca_block.py:16,26).  With bf16 maps the
  * sums are taken over the fp32 values BEFORE they are rounded to bf16 for storage (the pooled mean is then the mean of the
  * unrounded activations: closer to the fp32 path than a mean of the stored bf16 numbers; within the configs[2] tolerance).
- * fp32 maps of levels <= 4 run on the bf16 matrix pipe with exactly split operands (six bf16 products per fp32 product, fp32
- * accumulate: max deviation from the exact fp32 kernel 1.6e-6 of the largest output); egonn_debug_set_naive_conv selects
- * the exact kernels.  Non-finite inputs: the three-way split of +-Inf yields NaN (Inf - Inf), so an Inf activation comes out
- * of these kernels as NaN where the exact fp32 kernels propagate Inf; NaN stays NaN on both. */
+ * fp32 maps of levels <= 5 run on the fp16 matrix pipe with split operands (fp16 hi + lo parts, three products, fp32
+ * accumulate, range guard: see egonn_ctx_set_exact_fp32 above; deviation from the exact fp32 kernel < 3e-6 of the largest
+ * output); the maps of levels 3-5 sum a row's offsets in a fixed partition (egonn_debug_set_ksplit).  Non-finite inputs: Inf
+ * comes out as NaN / Inf and raises the range flag; NaN stays NaN on both paths. */
 int egonn_sparse_conv(egonn_ctx* ctx, int map_kind, int level_out, const void* in, int cin, const float* kernel, int cout,
                       int bf16, const float* scale, const float* shift, int relu, void* out, float* group_sums,
                       void* stream);

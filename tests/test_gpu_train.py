@@ -250,15 +250,45 @@ def test_train_step_matches_reference_fixture(name):
     grads = {k: p.grad for k, p in model.named_parameters()}
     keys = [k[5:] for k in case if k.startswith("grad/")]
     assert len(keys) == 104 == len(grads)
+
+    def digest_err(mine, ref):
+        norm = max(ref[0], 1e-12)
+        return max(abs(mine[0] - ref[0]) / norm, abs(mine[1] - ref[1]) / norm,
+                   float(np.abs(mine[2:] - ref[2:]).max()) / max(float(np.abs(ref[2:]).max()), 1e-12))
+
+    # How well is this gradient DEFINED in fp32?  The same step on the plain one-thread-per-output kernels and on the exact fp32 MFMA
+    # kernels — two exact-fp32 summation orders of the same convolutions.  With the local-head terms in the loss the two disagree by
+    # up to 2e-2 on the first layers of the polar case (measured, tools/exp/r06_train_grad_sensitivity.py: a perturbation of 1e-7 at
+    # level 3 moves those entries by percent, whichever kernel causes it), so an entry is held to the reference within
+    # max(5e-3, 2 x that spread): 5e-3 wherever fp32 pins the value, the fp32 noise floor of the quantity where it does not.
+    def grads_under(setting):
+        m2 = egonn_amd.model_factory(mp)
+        m2.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+        m2 = m2.to(dev).train()
+        c2 = m2.context()
+        if setting == "plain":
+            c2.set_naive_conv(True)
+        else:
+            c2.set_exact_fp32(True)
+        y2 = m2({"coords": coords, "features": torch.ones((len(coords), 1), device=dev)})
+        l2 = (y2["global"] * R).sum()
+        k2 = m2.keypoint_coords()
+        for b in range(int(case["n_scans"])):
+            kc = k2[b].cpu().numpy()
+            l2 = l2 + (y2["descriptors"][b] * torch.from_numpy(_row_weights(kc, 128, 0.1)).to(dev)).sum() \
+                    + (y2["keypoints"][b] * torch.from_numpy(_row_weights(kc, 3, 0.2)).to(dev)).sum() \
+                    + (y2["sigma"][b] * torch.from_numpy(_row_weights(kc, 1, 0.3)).to(dev)).sum()
+        l2.backward()
+        return {k: _digest(k, p.grad.detach().cpu().numpy()) for k, p in m2.named_parameters()}
+    g_plain, g_exact = grads_under("plain"), grads_under("exact")
     bad = []
     for k in keys:
         assert grads[k] is not None, k
         mine, ref = _digest(k, grads[k].detach().cpu().numpy()), case["grad/" + k]
-        norm = max(ref[0], 1e-12)
-        err = max(abs(mine[0] - ref[0]) / norm, abs(mine[1] - ref[1]) / norm,
-                  float(np.abs(mine[2:] - ref[2:]).max()) / max(float(np.abs(ref[2:]).max()), 1e-12))
-        if err > 5e-3:
-            bad.append((k, err))
+        err = digest_err(mine, ref)
+        floor = digest_err(g_exact[k], g_plain[k])
+        if err > max(5e-3, 2.0 * floor):
+            bad.append((k, err, floor))
     assert not bad, bad
     sd = model.state_dict()
     for k in [k[4:] for k in case if k.startswith("buf/")]:
