@@ -251,7 +251,10 @@ def main():
     for _ in range(max(args.warmup, 1)):
         eager_step()
     torch.cuda.synchronize()
-    ctx.profile_enable(1)
+    # exact dispatch timing: the sparse-conv launchers attach the layer's HIP events to the kernel dispatch itself (begin of the
+    # kernel .. end of the kernel, of the reducer for an offset-split pair) — the duration rocprofv3 --kernel-trace reports for
+    # the same dispatch; the other tagged layers (conv0) are bracketed by event records on the stream
+    ctx.profile_enable(2, "/")
     ctx.profile_fetch()
     for _ in range(5):
         eager_step()
@@ -387,7 +390,8 @@ def main():
         "launches": len(recs), "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": by, "flops_per_launch": fl,
         "timing": timing, "batches_in_flight": S,
         "layers": sorted(layers, key=lambda r: -r["us"]),
-        "layers_note": "every tagged layer of one step, one batch in flight (exclusive durations, HIP events around the launch); "
+        "layers_note": "every tagged layer of one step, one batch in flight (exclusive durations; sparse convolutions: HIP events attached "
+                       "to the kernel dispatch = the kernel's own begin..end, what rocprofv3 --kernel-trace reports; conv0: events around the launch); "
                        "frac = hbm_frac = algorithmic bytes / 8 TB/s / measured; mfma_frac = algorithmic flops / dense MFMA peak of the "
                        "arithmetic the kernel runs / measured",
     }
