@@ -156,6 +156,62 @@ def test_batched_voxelize_segmented_sort_variants(gpu, cb, n_scans, max_pts):
         assert np.array_equal(f[perm], oi)                  # first point of every voxel, as an index into its scan
 
 
+@pytest.mark.parametrize("case", ["dense_120k", "polar_120k", "one_voxel", "outliers", "many_tiny", "two_cells"])
+def test_voxelize_sort_stress_inputs(gpu, case):
+    """Stress inputs of the segmented sort behind plans built from points (csrc/sort.hip), through the C ABI: a dense 120 k-point
+    scan at 0.3 m, polar coordinates (all keys share their top digits), every point in ONE voxel (no varying bit), far outliers next
+    to a dense core, 64 scans of 0..300 points, and two occupied cells 200 m apart.  (Written for the MSD-first variant of round 6
+    — tools/exp/r06_sort_msd_first.patch: bit-exact on all of these, slower than the four LSD passes, not shipped — and kept for
+    the LSD passes.)  Per scan: voxel set and first-point index against datasets/quantization.py:29-44,79-85 as restated in
+    oracle/me_ops.py."""
+    from egonn_amd import _lib
+    from oracle import me_ops as ops
+    dev = _lib.require_gpu()
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(case.encode()) % 1000)    # (fixed data: the numpy polar restatement takes atan2 in fp32 and can
+                                                                     #  disagree with the fp64-rounded-once quantiser on a bin edge)
+    mode, step, q = 0, [0.1], 0.1
+    if case == "dense_120k":
+        p = (rng.standard_normal((120000, 3)) * np.array([6.0, 6.0, 0.6])).astype(np.float32)
+        scans, q, step = [p, p[:40000] * 0.5], 0.3, [0.3]
+    elif case == "polar_120k":
+        p = (rng.standard_normal((120000, 3)) * np.array([25.0, 25.0, 1.5])).astype(np.float32)
+        scans, mode, step = [p, p[::3]], 1, [1.0, 0.3, 0.2]
+    elif case == "one_voxel":
+        scans = [(rng.uniform(0.01, 0.09, (5000, 3)) + np.array([3.0, -2.0, 1.0])).astype(np.float32), rng.uniform(-5, 5, (900, 3)).astype(np.float32)]
+    elif case == "outliers":
+        core = (rng.standard_normal((60000, 3)) * np.array([3.0, 3.0, 0.4])).astype(np.float32)
+        far = rng.uniform(-200, 200, (40, 3)).astype(np.float32)
+        scans = [np.concatenate([far[:20], core, far[20:]])]
+    elif case == "many_tiny":
+        scans = [rng.uniform(-40, 40, (int(n), 3)).astype(np.float32) for n in rng.integers(0, 301, size=64)]
+    else:
+        a = rng.uniform(-2, 2, (9000, 3)).astype(np.float32)
+        scans = [np.concatenate([a + np.array([150.0, 150.0, 3.0], np.float32), a - np.array([150.0, 150.0, 3.0], np.float32)])]
+    sizes = [len(x) for x in scans]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ctx = _lib.Context(dev, coord_bits=12)
+    ctx.voxelize(torch.from_numpy(np.ascontiguousarray(np.concatenate(scans))).to(dev), off.tolist(), mode, step)
+    coords = _np(ctx.level_coords(0))
+    first = _np(ctx.input_index())
+    boff = ctx.level_batch_offsets(0)
+    for b in range(len(scans)):
+        c, f = coords[boff[b]:boff[b + 1]], first[boff[b]:boff[b + 1]]
+        if len(scans[b]) == 0:
+            assert len(c) == 0
+            continue
+        if mode == 0:
+            oc, oi = ops.sparse_quantize(scans[b], q)
+        else:
+            from oracle import egonn_ref as ref
+            oc, oi = ref.PolarQuantizer(step)(scans[b])
+            oc, oi = np.asarray(oc), np.asarray(oi)
+        assert len(c) == len(oc), (case, b, len(c), len(oc))
+        perm = H.join_perm(c, np.c_[np.full(len(oc), b, np.int32), oc])
+        assert np.array_equal(c[perm][:, 1:], oc)
+        assert np.array_equal(f[perm], oi)
+
+
 # ------------------------------------------------------------------------------------ coordinate pyramid (a3)
 @pytest.mark.parametrize("name", H.CASES)
 def test_pyramid_matches_reference(gpu, name):
