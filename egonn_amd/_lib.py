@@ -34,6 +34,7 @@ _SIGS = [
     ("egonn_voxelize_device", C.c_int, [_P, _P, C.c_int64, _P, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     ("egonn_plan_status", C.c_int, [_P, _P]),
     ("egonn_ctx_set_exact_fp32", C.c_int, [_P, C.c_int]),
+    ("egonn_ctx_set_operand_autoscale", C.c_int, [_P, C.c_int]),
     ("egonn_level_capacity", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
     ("egonn_graph_begin", C.c_int, [_P]),
     ("egonn_graph_end", C.c_int, [_P, C.POINTER(_P)]),
@@ -342,6 +343,11 @@ class Context:
         """fp32 maps: True = every sparse convolution on the exact fp32 kernels (full fp32 range); False (default) = levels <= 5 on
         the fp16-split matrix pipe (|activation| < 65504, guarded: plan_status raises with code 6)."""
         check(self.lib.egonn_ctx_set_exact_fp32(self.h, int(bool(on))))
+
+    def set_operand_autoscale(self, on: bool):
+        """fp16-split convolutions scale their input by a power of two per launch (max |in| -> [2^13, 2^14)): small operands
+        (input gradients) keep their low parts.  Eager plans only."""
+        check(self.lib.egonn_ctx_set_operand_autoscale(self.h, int(bool(on))))
 
     def set_ksplit(self, map_class: int, level: int, kparts: int = -1, kw: int = -1, col_parts: int = -1):
         """tests / A-B only: offset-split rule of the fp32 sparse convolutions (map_class 0: k=3 maps, 1: 8-slot maps); -1 keeps a field."""

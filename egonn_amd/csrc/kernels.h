@@ -40,7 +40,8 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
                         int kparts = 1, float* part = nullptr, size_t part_floats = 0,   // offset-split launch: parts, scratch for the partial tiles
                         int col_parts = 0,                                                // column parts per task (0 = automatic)
                         int kw = 0,                                                       // offset parts INSIDE a workgroup (0 / 1: none; 2, 3, 4)
-                        int32_t* flags = nullptr);                                        // the plan's flag word (bit 3: fp16 range guard)
+                        int32_t* flags = nullptr,                                         // the plan's flag word (bit 3: fp16 range guard)
+                        uint32_t* in_absmax = nullptr, int64_t in_elems = 0);             // operand autoscale: 8 bytes of scratch, elements of `in`
 size_t sconv_split_part_floats(const RowGroups& rg, int cout, int kparts);
 // Offset-split rule of the fp32 lock-step kernels: parts of the map's K offsets (1 = unsplit) and column parts per task for
 // (map kind, output level) — a function of the LAYER only (the partition changes the summation order of a row)

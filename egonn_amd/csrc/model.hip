@@ -238,6 +238,16 @@ API int egonn_plan_status(egonn_ctx* c, void* stream) {
 // fp32 feature maps: on = 1 runs every sparse convolution of this context on the exact fp32 kernels (v_mfma_f32_16x16x4_f32, the
 // full fp32 range), on = 0 (default) the levels <= 5 on the fp16-split matrix pipe (sconv_split.hip: |activation| < 65504, guarded:
 // egonn_plan_status reports EGONN_STATUS_FP16_RANGE).  The choice is per context and a function of the layer, never of the batch.
+// on = 1: every fp32 sparse convolution of this context on the fp16-split pipe first takes max |input| (one reduction launch) and scales
+// the gathered rows by the power of two that puts it into [2^13, 2^14), undone exactly in the epilogue — what the kernels do to their
+// weights.  For operands far below 1 (the input-gradient convolutions of a training step, egonn_amd/train.py): an fp16 low part
+// flushes below 2^-25 and carries 2^-25 absolute error below 2^-14.  Eager plans only (the element count comes from the host).
+API int egonn_ctx_set_operand_autoscale(egonn_ctx* c, int on) {
+  EGONN_REQUIRE(c && (on == 0 || on == 1), EGONN_ERR_INVALID, "ctx_set_operand_autoscale: bad argument");
+  c->operand_autoscale = on;
+  return EGONN_OK;
+}
+
 API int egonn_ctx_set_exact_fp32(egonn_ctx* c, int on) {
   EGONN_REQUIRE(c && (on == 0 || on == 1), EGONN_ERR_INVALID, "ctx_set_exact_fp32: bad argument");
   c->split_max_level = on ? -1 : 5;

@@ -1303,7 +1303,9 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
     return sconv_split_forward(reinterpret_cast<const float*>(in), P.cap[lin], rg, rg.cap_groups, Wsp, cin, cout, scale, shift,
                                relu, reinterpret_cast<float*>(out), psum, stream,
                                ctx->conv_variant >= 1000 ? ctx->conv_variant - 1000 : 0, ctx->split_io, ctx->gated_in2, ctx->gated_gate,
-                               P.batch, kparts, ctx->ks_part, ctx->ks_part_floats, col_parts, kw, ctx->dev_flags);
+                               P.batch, kparts, ctx->ks_part, ctx->ks_part_floats, col_parts, kw, ctx->dev_flags,
+                               ctx->operand_autoscale ? reinterpret_cast<uint32_t*>(ctx->dev_counts + 24) : nullptr,
+                               ctx->operand_autoscale ? P.lv[lin].n * cin : 0);
   }
   EGONN_REQUIRE(ctx->split_io == 0 && !ctx->gated_in2, EGONN_ERR_STATE,
                 "sconv: split-form maps and gated inputs are read and written by the split kernel only");

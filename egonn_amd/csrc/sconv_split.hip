@@ -161,6 +161,10 @@ struct SplitArgs {
   // hide it — raises bit 3 of the plan's flag word (egonn_plan_status: EGONN_STATUS_FP16_RANGE; egonn_ctx_set_exact_fp32 selects
   // the exact kernels).  Non-finite INPUTS raise it too: the flag says "this launch's fp32 semantics are not guaranteed".
   int32_t* flags = nullptr;
+  // OPERAND SCALE (the input-gradient convolutions of a training step: gradients of 1e-6 .. 1e-8 would lose their low parts): the bits
+  // of max |in| (split_absmax_kernel); the gathered rows are multiplied by the power of two that puts the maximum into
+  // [2^13, 2^14) before they are split — what pack_split_weights does to the kernel — and the epilogue divides it out (both exact).
+  const uint32_t* in_maxbits = nullptr;
 };
 __host__ __device__ static inline uint32_t ks_range_mask(int kp, int kp_n, int K) {      // offsets [kp*K/kp_n, (kp+1)*K/kp_n)
   const int k0 = kp * K / kp_n, k1 = (kp + 1) * K / kp_n;
@@ -199,7 +203,8 @@ __device__ static inline void split8h(const f32x4& a0, const f32x4& a1, f16x8_t&
 template <int COUT>
 __device__ static inline void split_epilogue(const SplitArgs& p, const f32x4& a0, const f32x4& a1, int ns, int32_t row, int gw,
                                              int l15, int g4) {
-  const float winv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.Wsp) + p.w_bytes);   // 1 / (pack scale): a power of two
+  float winv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.Wsp) + p.w_bytes);   // 1 / (pack scale): a power of two
+  if (p.in_maxbits) winv *= 1.f / split_scale_of(p.in_maxbits[0]);                                     // (uniform) 1 / (operand scale)
   float sums[2][4];
   f32x4 vv[2];
   {
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(NW * KW * 64) void sconv_split_kernel(const SplitAr
   constexpr int NS = NSW, NSTOT = COUT / 32, NCB = CIN / 32;
   static_assert(NSTOT % NSW == 0, "column parts");
   const int ns0 = blockIdx.y * NSW;                      // first column slice of this workgroup
+  const float in_sc = p.in_maxbits ? split_scale_of(__builtin_amdgcn_readfirstlane((int)p.in_maxbits[0])) : 1.f;   // operand scale (a power of two)
   constexpr int SLAB = GEO::SLAB, NPIECE = GEO::NPIECE, WPP = GEO::WPP;
   static_assert(GEO::LDS_BYTES <= 160 * 1024, "LDS budget");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -540,7 +546,10 @@ __global__ __launch_bounds__(NW * KW * 64) void sconv_split_kernel(const SplitAr
         }
         split8h(ra0, ra1, ah, al);
       } else if (p.in_split) { ah = __builtin_bit_cast(f16x8_t, ra0); al = __builtin_bit_cast(f16x8_t, ra1); }   // (uniform branch)
-      else split8h(ra0, ra1, ah, al);
+      else {
+        if (in_sc != 1.f) { ra0 *= in_sc; ra1 *= in_sc; }                                                       // (uniform branch)
+        split8h(ra0, ra1, ah, al);
+      }
       [&]<int... NSI>(std::integer_sequence<int, NSI...>) {
         (([&] {
            f32x4 wn[4];
@@ -700,7 +709,7 @@ bool sconv_split_supported(int cin, int cout) {
 int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
                         int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
                         int cfg, int split_io, const float* gated_in2, const float* gated_gate, int B, int kparts, float* part,
-                        size_t part_floats, int col_parts, int kw, int32_t* flags) {
+                        size_t part_floats, int col_parts, int kw, int32_t* flags, uint32_t* in_absmax, int64_t in_elems) {
   EGONN_REQUIRE(rg.built, EGONN_ERR_STATE, "sconv: row-group tables not built");
   EGONN_REQUIRE(sconv_split_supported(cin, cout), EGONN_ERR_INVALID, "sconv(split): channel plan %d->%d not supported", cin, cout);
   EGONN_REQUIRE((uint64_t)n_in_cap * cin * 4 < (1ull << 32) - (1ull << 20), EGONN_ERR_INVALID,
@@ -716,6 +725,12 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
   a.K = rg.K; a.relu = relu ? 1 : 0; a.cap_groups = rg.cap_groups;
   a.flags = flags;
   a.in_split = (split_io & 1) ? 1 : 0;
+  if (in_absmax) {                                       // operand autoscale: max |in| -> in_absmax[1] (one memset + one launch)
+    EGONN_REQUIRE(!(split_io & 1) && !gated_in2 && in_elems > 0, EGONN_ERR_INVALID, "sconv(split): operand scale on a plain fp32 input only");
+    HIP_CHECK(hipMemsetAsync(in_absmax, 0, 8, stream));
+    hipLaunchKernelGGL(split_absmax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(in_elems, 1024), 1024)), dim3(256), 0, stream, in, in_elems, in_absmax);
+    a.in_maxbits = in_absmax + 1;
+  }
   a.out_split = (split_io & 2) ? 1 : 0;
   if (kparts > 1) {
     EGONN_REQUIRE(kparts <= rg.K && !gated_in2, EGONN_ERR_INVALID, "sconv(split): %d offset parts on a %d-slot map", kparts, rg.K);

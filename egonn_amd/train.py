@@ -31,9 +31,6 @@ from . import _lib
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2, 3
 
 
-_NO_GRAD_SCALE = bool(os.environ.get("EGONN_NO_GRAD_SCALE"))
-
-
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -65,23 +62,19 @@ class SparseConvFn(Function):
                 dx = ctx.dense(g, _c(k), out_in=True)
             elif ks in (2, 3):
                 # The input-gradient convolutions run on the fp16-split kernels like the forward ones, and gradients are SMALL
-                # (1e-6 .. 1e-8 is ordinary): an fp16 part flushes below 2^-25 and carries 2^-25 absolute error below 2^-14.
-                # The operand is therefore scaled by a power of two (exact) so that max |g| sits in [2^13, 2^14) — the treatment the
-                # kernels give their weights — and the result is scaled back (exact).  All on the device, no synchronisation.
-                m = torch.linalg.vector_norm(g, ord=float('inf'))
-                e = torch.frexp(m)[1]
-                sc = torch.ldexp(torch.ones_like(m), 14 - e)
-                sc = torch.where((m > 0) & torch.isfinite(m), sc, torch.ones_like(m))
-                if _NO_GRAD_SCALE:                        # measurement switch
-                    sc = torch.ones_like(m)
-                gs = g * sc
-                if ks == 3:                               # nbr[o][k] = j  <=>  nbr[j][26-k] = o
-                    dx = ctx.conv(lin, lin, 3, gs, _c(k.flip(0).transpose(1, 2)))
-                elif not transposed:                      # strided conv  <->  transposed conv on the same map
-                    dx = ctx.conv_transpose(lout, gs, _c(k.transpose(1, 2)))
-                else:
-                    dx = ctx.conv(lout, lin, 2, gs, _c(k.transpose(1, 2)))
-                dx = dx / sc
+                # (1e-6 .. 1e-8 is ordinary): an fp16 part flushes below 2^-25 and carries 2^-25 absolute error below 2^-14.  The
+                # library therefore scales this operand by a power of two per launch (max |g| -> [2^13, 2^14), exact, undone in
+                # the epilogue: egonn_ctx_set_operand_autoscale) — the treatment the kernels give their weights.
+                ctx.set_operand_autoscale(True)
+                try:
+                    if ks == 3:                           # nbr[o][k] = j  <=>  nbr[j][26-k] = o
+                        dx = ctx.conv(lin, lin, 3, g, _c(k.flip(0).transpose(1, 2)))
+                    elif not transposed:                  # strided conv  <->  transposed conv on the same map
+                        dx = ctx.conv_transpose(lout, g, _c(k.transpose(1, 2)))
+                    else:
+                        dx = ctx.conv(lout, lin, 2, g, _c(k.transpose(1, 2)))
+                finally:
+                    ctx.set_operand_autoscale(False)
             else:
                 raise NotImplementedError(f"input gradient of a k={ks} convolution")
         if fctx.needs_input_grad[1]:

@@ -103,6 +103,11 @@ int egonn_plan_status(egonn_ctx* ctx, void* stream);
  * (v_mfma_f32_16x16x4_f32: fp32's range, 1/16 of the matrix rate).  Levels 6-7, bf16 maps and channel plans without a split
  * instantiation always run the exact kernels. */
 int egonn_ctx_set_exact_fp32(egonn_ctx* ctx, int on);
+/* on = 1: the fp16-split convolutions of this context scale their INPUT map by a power of two per launch (max |in| -> [2^13, 2^14),
+ * one reduction launch, undone exactly in the epilogue) — for operands far below 1: the input-gradient convolutions of a training
+ * step (training/trainer.py:160-175 -> loss.backward()), whose entries of 1e-6 .. 1e-8 would otherwise lose their fp16 low parts.
+ * Eager plans only.  Default 0 (activations of a forward pass sit well inside the range). */
+int egonn_ctx_set_operand_autoscale(egonn_ctx* ctx, int on);
 /* Row capacity of a level of the current plan (= its row count for eager plans).  No sync. */
 int egonn_level_capacity(egonn_ctx* ctx, int level, int64_t* capacity);
 /* hipGraph capture of a sequence of calls on `stream` (hipStreamBeginCapture / EndCapture + Instantiate / hipGraphLaunch):
