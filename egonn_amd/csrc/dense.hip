@@ -1052,10 +1052,227 @@ __global__ __launch_bounds__(LH_WAVES * 64) void local_heads_kernel(const LocalH
     }
   }
 }
+// ------------------------------------------------------------------ the three heads on the fp16 matrix pipe (round 6)
+// local_heads_kernel above is bound by v_mfma_f32_16x16x4_f32: 432 MFMAs of 32 cycles per 16-row tile, two waves per SIMD —
+// 1 831 tiles x 13.8 k cycles / 1 024 SIMDs = 10 us of the 36 us launch at best.  The heads' six Linear layers here run with
+// the two-way fp16 split of sconv_split.hip instead (weights packed ONCE per model as hi | lo fragments in the contraction
+// order of the register chain, one power-of-two scale per matrix; activations split in registers; three products on
+// v_mfma_f32_16x16x32_f16, small terms first): 138 MFMAs of 16 cycles.  The lateral 1x1 convolution in front stays on the exact
+// pipe in the accumulation order of the dense kernel (the fused / unfused switch stays bitwise).  Deviation of the outputs from
+// the exact kernel: < 3e-6 of the largest value per output (tests/test_gpu_fusions.py); non-finite head outputs raise the range
+// flag of the plan (an input beyond the fp16 range cannot pass silently).  egonn_ctx_set_exact_fp32 selects the kernel above.
+typedef _Float16 lh_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lh_f16x2 __attribute__((ext_vector_type(2)));
+typedef float lh_f32x2 __attribute__((ext_vector_type(2)));
+__host__ __device__ static inline int lh_chan(int g, int e) { return e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4); }
+// fragments (1 KB hi + 1 KB lo each) per matrix: NT * CIN / 32
+constexpr int LHS_DW0 = 0, LHS_DW1 = LHS_DW0 + 6 * 2, LHS_KW0 = LHS_DW1 + 8 * 3, LHS_KW1 = LHS_KW0 + 2 * 2, LHS_SW0 = LHS_KW1 + 1 * 1,
+              LHS_SW1 = LHS_SW0 + 2 * 2, LHS_FRAGS = LHS_SW1 + 1 * 1;                                   // 46 fragment pairs = 92 KB
+struct LhsMat { int cin, nout, nt, first; };
+__constant__ LhsMat lhs_mats[6] = {{64, 96, 6, LHS_DW0}, {96, 128, 8, LHS_DW1}, {64, 32, 2, LHS_KW0}, {32, 3, 1, LHS_KW1},
+                                   {64, 32, 2, LHS_SW0}, {32, 1, 1, LHS_SW1}};
+__global__ void lhs_absmax_kernel(const float* const* __restrict__ W, uint32_t* __restrict__ trailer) {
+  const int mi = blockIdx.x;
+  const LhsMat M = lhs_mats[mi];
+  const float* w = W[mi];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < M.cin * M.nout; i += blockDim.x) {
+    const float v = fabsf(w[i]);
+    m = (v == v && v < INFINITY) ? fmaxf(m, v) : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(trailer + 8 + mi, __float_as_uint(m));
+}
+__device__ static inline float lhs_scale_of(uint32_t maxbits) {        // power of two s with s * max in [2^13, 2^14)
+  const int e = (int)(maxbits >> 23) - 127;
+  const int se = min(max(13 - e, -100), 100);
+  return __uint_as_float((uint32_t)(se + 127) << 23);
+}
+// out[(first + nt * KB + kb) * 2 + part][lane][e] = part(s * W[16 nt + (lane & 15)][32 kb + lh_chan(lane >> 4, e)]) (fp16),
+// rows beyond nout: zeros; behind the fragments: float 1/s per matrix [0..5], max bits [8..13]
+__global__ void lhs_pack_kernel(const float* const* __restrict__ W, uint16_t* __restrict__ out, uint32_t* __restrict__ trailer) {
+  const int mi = blockIdx.y;
+  const LhsMat M = lhs_mats[mi];
+  const int KB = M.cin / 32;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const float sc = lhs_scale_of(trailer[8 + mi]);
+  if (t == 0) reinterpret_cast<float*>(trailer)[mi] = 1.f / sc;
+  if (t >= M.nt * KB * 2 * 64 * 8) return;
+  int r = t;
+  const int e = r & 7; r >>= 3;
+  const int lane = r & 63; r >>= 6;
+  const int part = r & 1; r >>= 1;
+  const int kb = r % KB, nt = r / KB;
+  const int unit = 16 * nt + (lane & 15), k = 32 * kb + lh_chan(lane >> 4, e);
+  const float v = unit < M.nout ? sc * W[mi][(int64_t)unit * M.cin + k] : 0.f;
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  out[(int64_t)M.first * 2 * 512 + t] = __builtin_bit_cast(uint16_t, part == 0 ? hi : lo);
+}
+size_t local_heads_pack_bytes() { return (size_t)LHS_FRAGS * 2048 + 64; }
+int local_heads_pack(const float* const* w6_dev /*device array of the six weight pointers*/, void* out, hipStream_t stream) {
+  uint32_t* trailer = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(out) + (size_t)LHS_FRAGS * 2048);
+  HIP_CHECK(hipMemsetAsync(trailer, 0, 64, stream));
+  hipLaunchKernelGGL(lhs_absmax_kernel, dim3(6), dim3(256), 0, stream, w6_dev, trailer);
+  hipLaunchKernelGGL(lhs_pack_kernel, dim3((8 * 3 * 2 * 64 * 8 + 255) / 256, 6), dim3(256), 0, stream, w6_dev,
+                     reinterpret_cast<uint16_t*>(out), trailer);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+__device__ static inline void lhs_split8(const f32x4& a0, const f32x4& a1, lh_f16x8& hi, lh_f16x8& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = q < 2 ? a0[2 * q] : a1[2 * q - 4], x1 = q < 2 ? a0[2 * q + 1] : a1[2 * q - 3];
+    const lh_f16x2 h = __builtin_convertvector((lh_f32x2){x0, x1}, lh_f16x2);
+    const lh_f32x2 hf = __builtin_convertvector(h, lh_f32x2);
+    const lh_f16x2 l = __builtin_convertvector((lh_f32x2){x0 - hf[0], x1 - hf[1]}, lh_f16x2);
+    hi[2 * q] = h[0]; hi[2 * q + 1] = h[1];
+    lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
+  }
+}
+// out[nt] = winv * sum_kb (W_lo ah + W_hi al + W_hi ah): in = f32x4 per 16 input channels (the register chain's layout)
+template <int CIN, int NT>
+__device__ static inline void lhs_layer(const f32x4* __restrict__ frags /* pairs: hi, lo */, const f32x4* __restrict__ in, int lane,
+                                        float winv, f32x4* __restrict__ out) {
+  constexpr int KB = CIN / 32;
+  lh_f16x8 ah[KB], al[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) lhs_split8(in[2 * kb], in[2 * kb + 1], ah[kb], al[kb]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const lh_f16x8 wh = __builtin_bit_cast(lh_f16x8, frags[((nt * KB + kb) * 2) * 64 + lane]);
+      const lh_f16x8 wl = __builtin_bit_cast(lh_f16x8, frags[((nt * KB + kb) * 2 + 1) * 64 + lane]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[kb], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[kb], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[kb], acc, 0, 0, 0);
+    }
+    out[nt] = acc * winv;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+struct LocalHeadsSplitArgs {
+  LocalHeadsArgs a;
+  const void* pack;          // local_heads_pack
+  int32_t* flags;            // the plan's flag word (bit 3: non-finite head output)
+};
+__global__ __launch_bounds__(LH_WAVES * 64) void local_heads_split_kernel(const LocalHeadsSplitArgs q) {
+  const LocalHeadsArgs& p = q.a;
+  extern __shared__ __attribute__((aligned(16))) f32x4 lh_frags[];      // [LHS_FRAGS * 2][64] split fragments, then the lateral's 16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(q.pack);
+    for (int i = tid; i < LHS_FRAGS * 2 * 64; i += LH_WAVES * 64) lh_frags[i] = src[i];
+  }
+  f32x4* const lat = lh_frags + LHS_FRAGS * 2 * 64;
+  if (p.lw) stage_frags_t<64, 4>(p.lw, 64, lat, tid, LH_WAVES * 64);
+  const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(q.pack) + (size_t)LHS_FRAGS * 2048);
+  const float wi0 = winv[0], wi1 = winv[1], wi2 = winv[2], wi3 = winv[3], wi4 = winv[4], wi5 = winv[5];
+  __syncthreads();
+  int64_t n = p.n;
+  if (p.n_dev) n = min((int64_t)*p.n_dev, n);
+  const int64_t ntiles = (n + 15) >> 4;
+  for (int64_t tile = (int64_t)blockIdx.x * LH_WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * LH_WAVES) {
+    const int64_t row = tile * 16 + l15;
+    const bool ok = row < n;
+    f32x4 x[4];
+    auto load4 = [&](const float* base, int t) -> f32x4 {
+      if (!ok) return (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.in_bf16) {
+        const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + row * 64 + 16 * t + 4 * g4);
+        return (f32x4){bf2f(h.x & 0xFFFFu), bf2f(h.x >> 16), bf2f(h.y & 0xFFFFu), bf2f(h.y >> 16)};
+      }
+      return *reinterpret_cast<const f32x4*>(base + row * 64 + 16 * t + 4 * g4);
+    };
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = load4(p.x, t);
+    if (p.lw) {                                              // the lateral: exact pipe, the dense kernel's order (bitwise)
+      f32x4 r[4], l[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) r[t] = load4(p.lres, t);
+      mlp_layer<64, 4>(lat, x, lane, l);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) x[t] = l[t] + r[t];
+    }
+    float guard = 0.f;                                       // (v - v) is NaN for a non-finite v: sticky under addition
+    // ---- descriptor decoder + L2 normalisation
+    {
+      f32x4 h[6], o[8];
+      lhs_layer<64, 6>(lh_frags + LHS_DW0 * 2 * 64, x, lane, wi0, h);
+#pragma unroll
+      for (int nt = 0; nt < 6; ++nt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.db0 + 16 * nt + 4 * g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[nt][r] = fmaxf(h[nt][r] + b[r], 0.f);
+      }
+      lhs_layer<96, 8>(lh_frags + LHS_DW1 * 2 * 64, h, lane, wi1, o);
+      float ss = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.db1 + 16 * nt + 4 * g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[nt][r] += b[r];
+          ss += o[nt][r] * o[nt][r];
+        }
+      }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      guard += ss - ss;
+      const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+      if (ok) {
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+          *reinterpret_cast<f32x4*>(p.out_desc + row * 128 + 16 * nt + 4 * g4) = o[nt] * inv;
+      }
+    }
+    // ---- keypoint regressor -> position of the keypoint in metres
+    {
+      f32x4 h[2], o[1];
+      lhs_layer<64, 2>(lh_frags + LHS_KW0 * 2 * 64, x, lane, wi2, h);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.kb0 + 16 * nt + 4 * g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[nt][r] = fmaxf(h[nt][r] + b[r], 0.f);
+      }
+      lhs_layer<32, 1>(lh_frags + LHS_KW1 * 2 * 64, h, lane, wi3, o);
+      if (ok && g4 == 0) {
+        guard += (o[0][0] - o[0][0]) + (o[0][1] - o[0][1]) + (o[0][2] - o[0][2]);
+        const float ox = p.ignore_offsets ? 0.f : tanhf(o[0][0] + p.kb1[0]);
+        const float oy = p.ignore_offsets ? 0.f : tanhf(o[0][1] + p.kb1[1]);
+        const float oz = p.ignore_offsets ? 0.f : tanhf(o[0][2] + p.kb1[2]);
+        keypoint_position(p.keys[row], p.level, p.cb, ox, oy, oz, p.mode, p.s0, p.s1, p.s2, p.out_kp + row * 3);
+      }
+    }
+    // ---- sigma regressor
+    {
+      f32x4 h[2], o[1];
+      lhs_layer<64, 2>(lh_frags + LHS_SW0 * 2 * 64, x, lane, wi4, h);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.sb0 + 16 * nt + 4 * g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[nt][r] = fmaxf(h[nt][r] + b[r], 0.f);
+      }
+      lhs_layer<32, 1>(lh_frags + LHS_SW1 * 2 * 64, h, lane, wi5, o);
+      if (ok && g4 == 0) {
+        guard += o[0][0] - o[0][0];
+        p.out_sigma[row] = apply_act(o[0][0] + p.sb1[0], ACT_SOFTPLUS);
+      }
+    }
+    if (ok && guard != 0.f && q.flags) atomicOr(q.flags, 8);
+  }
+}
+
 int local_heads_forward(const float* x, int64_t n, const int32_t* n_dev, const float* const* w /*12 pointers*/,
                         const uint64_t* keys, int level, int cb, int mode, const float* step, int ignore_offsets,
                         float* out_desc, float* out_kp, float* out_sigma, hipStream_t stream, const float* lateral_w,
-                        const float* lateral_res, int in_bf16) {
+                        const float* lateral_res, int in_bf16, const void* split_pack, int32_t* flags) {
   if (n == 0) return EGONN_OK;
   EGONN_REQUIRE((lateral_w == nullptr) == (lateral_res == nullptr), EGONN_ERR_INVALID, "local heads: lateral kernel and residual go together");
   LocalHeadsArgs a;
@@ -1077,6 +1294,19 @@ int local_heads_forward(const float* x, int64_t n, const int32_t* n_dev, const f
     attr_done.mark(); 
   }
   const unsigned grid = (unsigned)std::min<int64_t>(cdiv(tiles, LH_WAVES), 256);      // one workgroup per CU holds the weights
+  if (split_pack) {
+    static AttrOnce attr2;
+    if (attr2.need()) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&local_heads_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr2.mark();
+    }
+    LocalHeadsSplitArgs q;
+    q.a = a; q.pack = split_pack; q.flags = flags;
+    const size_t lds2 = (size_t)(LHS_FRAGS * 2 + (lateral_w ? 16 : 0)) * 64 * sizeof(f32x4);
+    hipLaunchKernelGGL(local_heads_split_kernel, dim3(grid), dim3(LH_WAVES * 64), lds2, stream, q);
+    HIP_CHECK(hipGetLastError());
+    return EGONN_OK;
+  }
   hipLaunchKernelGGL(local_heads_kernel, dim3(grid), dim3(LH_WAVES * 64), lds, stream, a);
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;

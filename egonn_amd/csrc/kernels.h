@@ -104,7 +104,11 @@ int keypoint_positions(const uint64_t* keys, int64_t n, int level, int cb, const
 int local_heads_forward(const float* x, int64_t n, const int32_t* n_dev, const float* const* w, const uint64_t* keys,
                         int level, int cb, int mode, const float* step, int ignore_offsets, float* out_desc, float* out_kp,
                         float* out_sigma, hipStream_t stream, const float* lateral_w = nullptr, const float* lateral_res = nullptr,
-                        int in_bf16 = 0);
+                        int in_bf16 = 0, const void* split_pack = nullptr, int32_t* flags = nullptr);
+// the heads' six Linear kernels as fp16 hi | lo fragments (local_heads_split_kernel): w6_dev = DEVICE array of the six weight
+// pointers (dw0, dw1, kw0, kw1, sw0, sw1)
+size_t local_heads_pack_bytes();
+int local_heads_pack(const float* const* w6_dev, void* out, hipStream_t stream);
 // top-k smallest sigma per sample, ascending, ties by row (= Z-order) — eval/evaluate.py:352-361 — and the gather of the
 // selected keypoints / descriptors, one launch (workgroup = scan); out_kp / out_desc nullable
 int select_topk(const float* sigma, const int32_t* boff_dev, int B, int k, const float* kp, const float* desc, int dc,

@@ -72,6 +72,8 @@ struct egonn_model {
   float* packed = nullptr;
   size_t packed_cap = 0;
   void* conv0_unit = nullptr;   // conv0_pack_unit(conv0): 24 KB
+  void* lh_pack = nullptr;      // local_heads_pack: the heads' six Linear kernels as fp16 hi | lo fragments (92 KB)
+  const float** lh_ptrs = nullptr;   // device array of the six weight pointers (the packer's input)
   const float *p_convs[8] = {}, *p_c1[8] = {}, *p_c2[8] = {}, *p_gt[8] = {}, *p_lt[8] = {};
   // the same kernels packed as bf16 (EGONN_FLAG_BF16): [0] = fp32 set, [1] = bf16 set
   const float *q_convs[8] = {}, *q_c1[8] = {}, *q_c2[8] = {}, *q_gt[8] = {}, *q_lt[8] = {};
@@ -545,6 +547,8 @@ API void egonn_model_destroy(egonn_model* m) {
   if (m->folded) (void)hipFree(m->folded);
   if (m->packed) (void)hipFree(m->packed);
   if (m->conv0_unit) (void)hipFree(m->conv0_unit);
+  if (m->lh_pack) (void)hipFree(m->lh_pack);
+  if (m->lh_ptrs) (void)hipFree(m->lh_ptrs);
   delete m;
 }
 
@@ -706,6 +710,15 @@ API int egonn_model_finalize(egonn_model* m, void* stream) {
   }
   if (!m->conv0_unit) HIP_CHECK(hipMalloc(&m->conv0_unit, 2 * 4 * 3 * 64 * 16));
   EGONN_TRY(conv0_pack_unit(m->conv0, m->conv0_unit, st));
+  if (m->ldec.cin == 64 && m->ldec.mid == 96 && m->ldec.cout == 128 && m->kp.mid == 32 && m->sg.mid == 32 && m->kp.cin == 64 &&
+      m->sg.cin == 64) {       // the local heads of models/minkgl.py:175-225 in their shipped sizes: split-fp16 fragments
+    if (!m->lh_pack) HIP_CHECK(hipMalloc(&m->lh_pack, local_heads_pack_bytes()));
+    if (!m->lh_ptrs) HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->lh_ptrs), 6 * sizeof(float*)));
+    const float* hp[6] = {m->ldec.w0, m->ldec.w1, m->kp.w0, m->kp.w1, m->sg.w0, m->sg.w1};
+    HIP_CHECK(hipMemcpyAsync(m->lh_ptrs, hp, sizeof(hp), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));                    // (hp lives on this stack frame)
+    EGONN_TRY(local_heads_pack(m->lh_ptrs, m->lh_pack, st));
+  }
   EGONN_TRY(fold(m->bn[0], st));
   for (int i = 1; i <= 7; ++i) {
     EGONN_TRY(fold(m->bn[i], st));
@@ -833,18 +846,22 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     const float* hw[12] = {m->ldec.w0, m->ldec.b0, m->ldec.w1, m->ldec.b1, m->kp.w0, m->kp.b0, m->kp.w1, m->kp.b1,
                            m->sg.w0, m->sg.b0, m->sg.w1, m->sg.b1};
     static const bool fuse_lateral = getenv("EGONN_NO_FUSED_LATERAL") == nullptr;      // measurement switch
+    static const bool heads_split_ok = getenv("EGONN_NO_SPLIT_HEADS") == nullptr;      // measurement switch
+    // the heads' Linear layers on the fp16 matrix pipe (dense.hip), unless this context asked for exact fp32 arithmetic
+    const void* lh_pack = (heads_split_ok && m->lh_pack && c->split_max_level >= 0 && c->conv_variant == 0) ? m->lh_pack : nullptr;
     if (fuse_lateral && LOCAL_CH == 64) {
       // the level-3 lateral 1x1 convolution + the transposed convolution's output are the first layer of the heads' kernel — the
       // 64-channel map they read is never written (bitwise the rows of the dense launch this replaces; bf16 maps are widened on load)
       EGONN_TRY(local_heads_forward(reinterpret_cast<const float*>(x[3]), n3, cnt + 3, hw, P.lv[3].keys, 3, P.coord_bits, quant_mode,
                                     step, (flags & EGONN_FLAG_IGNORE_KP_REGRESSOR) ? 1 : 0, out_desc, out_kp, out_sigma, st,
-                                    m->l1x1[3], reinterpret_cast<const float*>(u3), bf16));
+                                    m->l1x1[3], reinterpret_cast<const float*>(u3), bf16, lh_pack, c->dev_flags));
       return EGONN_OK;
     }
     WALLOC(l3, n3 * LOCAL_CH);
     EGONN_TRY(dense_forward_ex(x[3], bf16, n3, 64, m->l1x1[3], 0, LOCAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u3, bf16, l3, 0, st, cnt + 3));
     EGONN_TRY(local_heads_forward(l3, n3, cnt + 3, hw, P.lv[3].keys, 3, P.coord_bits, quant_mode, step,
-                                  (flags & EGONN_FLAG_IGNORE_KP_REGRESSOR) ? 1 : 0, out_desc, out_kp, out_sigma, st));
+                                  (flags & EGONN_FLAG_IGNORE_KP_REGRESSOR) ? 1 : 0, out_desc, out_kp, out_sigma, st, nullptr, nullptr, 0,
+                                  lh_pack, c->dev_flags));
     return EGONN_OK;
   };
   static const bool presplit_ok = getenv("EGONN_NO_PRESPLIT") == nullptr;     // measurement switch: conv2 splits in its loop

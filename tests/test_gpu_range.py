@@ -120,3 +120,39 @@ def test_small_gradients_keep_their_relative_accuracy(gpu):
         rel = ((dx - want).abs() / want.abs())[big]
         assert float(rel.median()) < 1e-6 and float(rel.max()) < 1e-2, (ks, float(rel.median()), float(rel.max()))
     ctx.plan_status()
+
+
+@pytest.mark.gpu
+def test_split_pipe_against_exact_mode_end_to_end(gpu):
+    """The whole extraction on the fp16-split pipe (sparse convolutions of levels <= 5 with their offset parts, the three local heads
+    of models/minkgl.py:175-225 on split Linear kernels) against egonn_ctx_set_exact_fp32(1) (every kernel exact fp32) on the same
+    scans: global descriptor 1 - cos < 1e-6, every local descriptor 1 - cos < 1e-6, keypoints within 1e-4 m, sigma within 1e-4
+    relative — the two differ by fp32-class rounding only, far inside the 1e-4 cosine bar of the north star."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import helpers as H
+    from egonn_amd.synth import lidar_scan
+    mp = gpu.ModelParams(model="egonn", coordinates="cartesian", quantization_step=0.1)
+    m = gpu.model_factory(mp)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in H.seeded_weights(5).items()})
+    m = m.to("cuda").eval()
+    ex = gpu.DescriptorExtractor(m, n_k=128)
+    scans = [torch.from_numpy(lidar_scan(900 + i, 20000)) for i in range(3)]
+    ctx = m.context()
+
+    def run():
+        out = ex.extract(scans)
+        d, k, s = m._last_local
+        ctx.plan_status()
+        return out["global"].clone(), d.clone(), k.clone(), s.clone()
+    g0, d0, k0, s0 = run()
+    ctx.set_exact_fp32(True)
+    try:
+        g1, d1, k1, s1 = run()
+    finally:
+        ctx.set_exact_fp32(False)
+    cos = lambda a, b: 1.0 - (a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1))
+    assert float(cos(g0, g1).max()) < 1e-6
+    assert d0.shape == d1.shape and float(cos(d0, d1).max()) < 1e-6
+    assert float((k0 - k1).abs().max()) < 1e-4
+    assert torch.allclose(s0, s1, rtol=1e-4, atol=1e-6)
