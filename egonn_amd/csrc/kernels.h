@@ -19,7 +19,8 @@ const char* sconv_kernel_name(const Ctx* ctx, int kind, int level, int cin, int 
 // level: output level of the map (selects the prefetch depth / kernel family: a function of the LAYER, never of a capacity)
 int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wp, int cin,
                      int cout, int bf16, const float* scale, const float* shift, int relu, void* out, float* psum,
-                     hipStream_t stream, int variant = 0, int level = 0);
+                     hipStream_t stream, int variant = 0, int level = 0,
+                     int split = 0, int32_t* flags = nullptr);   // split: Wp = pack_split_weights form, fp16-split arithmetic (128->128 fp32 maps)
 // Convolution over a map of the plan.  kind 0: k=3 on `level`; 1: k=2,s=2 from level-1 into `level`; 2: transposed from
 // level+1 onto `level`.  Wp: kernel already packed for this precision (or null: W is packed into `scratch` first).
 // bf16: feature maps in/out and weights are bf16.  psum (nullable): [groups][cout] per-group column sums of the output.

@@ -122,7 +122,24 @@ struct SconvArgs {
   const int32_t* order4 = nullptr;       // dispatch order of tasks of 4 consecutive groups (rowgroup.hip: longest first inside
                                          // every XCD's eighth); used by the kernels whose task is exactly such a quadruple
   unsigned long long* trace = nullptr;   // measurement builds only (tools/sconv_trace.py): 8 u64 per wave task
+  int32_t* flags = nullptr;              // SPLIT instantiation: the plan's flag word (bit 3: fp16 range guard, sconv_split.hip)
 };
+
+// fp32 x 8 -> (hi, lo) fp16 x 8 (the two-way split of sconv_split.hip, same rounding)
+typedef _Float16 rg_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 rg_f16x2 __attribute__((ext_vector_type(2)));
+typedef float rg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ static inline void rg_split8h(const f32x4& a0, const f32x4& a1, rg_f16x8& hi, rg_f16x8& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = q < 2 ? a0[2 * q] : a1[2 * q - 4], x1 = q < 2 ? a0[2 * q + 1] : a1[2 * q - 3];
+    const rg_f16x2 h = __builtin_convertvector((rg_f32x2){x0, x1}, rg_f16x2);
+    const rg_f32x2 hf = __builtin_convertvector(h, rg_f32x2);
+    const rg_f16x2 l = __builtin_convertvector((rg_f32x2){x0 - hf[0], x1 - hf[1]}, rg_f16x2);
+    hi[2 * q] = h[0]; hi[2 * q + 1] = h[1];
+    lo[2 * q] = l[0]; lo[2 * q + 1] = l[1];
+  }
+}
 
 // KSP > 1 (layers with >= 64 input channels): the KSP waves of a workgroup that share one (group, 32-column) tile each
 // take 1/KSP of the input-channel blocks and the partial accumulators are summed through LDS in fixed order — shorter
@@ -134,8 +151,13 @@ struct SconvArgs {
 // (6 loads x 16 cycles x 4 waves per 512 MFMA cycles); G = 2 makes it 8 loads per 1024 MFMA cycles.  A group that lacks
 // the offset skips the item's MFMAs (wave-uniform branch; its gather rows are "-1" and cost no memory traffic).  The sum
 // order of every output row is unchanged (ascending k, ascending channel) => results are bitwise identical for every G.
-template <int CIN, int COUT, bool BF16, int D, int KSP, int G, int NW>
+// SPLIT (fp32 maps of levels 6-7, round 6): the item's arithmetic is the two-way fp16 split of sconv_split.hip — p.Wp is the
+// pack_split_weights form, whose 4 KB item (hi nt0 | hi nt1 | lo nt0 | lo nt1 fragments) sits where the fp32 item sat, the gathered
+// fragment is split in registers and six MFMAs of 16 cycles replace sixteen of 32: a wave's chain of 27 items was 5.8 of the launch's
+// 14.5 us in exact-fp32 MFMAs.  Same partition and order of the sum as the exact instantiation; epilogue * 1 / (pack scale); range guard.
+template <int CIN, int COUT, bool BF16, int D, int KSP, int G, int NW, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) void sconv_rg_kernel(const SconvArgs p) {
+  static_assert(!SPLIT || !BF16, "split arithmetic is for fp32 maps");
   constexpr int NS = COUT / 32, NCB = CIN / 32;
   constexpr int NCBL = NCB / KSP;                        // channel blocks per wave
   constexpr int TPW = NW / KSP;                          // tiles per workgroup
@@ -175,6 +197,11 @@ __global__ __launch_bounds__(NW * 64) void sconv_rg_kernel(const SconvArgs p) {
     for (int nt = 0; nt < 2; ++nt) {
       const int c0 = ns * 32 + nt * 16 + 4 * g4;
       f32x4 v = acc[nt];
+      if constexpr (SPLIT) {
+        const f32x4 z = v - v;                               // NaN for a non-finite accumulator (range guard)
+        if (__builtin_expect((z[0] + z[1]) + (z[2] + z[3]) != 0.f, 0) && p.flags) atomicOr(p.flags, 8);
+        v = v * *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.Wp) + p.w_bytes);      // 1 / (pack scale)
+      }
       if (p.scale) v = v * sc[nt] + sh[nt];
       if (p.relu) {
 #pragma unroll
@@ -324,7 +351,18 @@ __global__ __launch_bounds__(NW * 64) void sconv_rg_kernel(const SconvArgs p) {
 #pragma unroll
         for (int j = 0; j < G; ++j) {
           if (G > 1 && !((gm[j] >> bitring[rs]) & 1u)) continue;        // wave-uniform
-          if constexpr (BF16) {
+          if constexpr (SPLIT) {
+            rg_f16x8 ah, al;
+            rg_split8h(aring[rs][j][0], aring[rs][j][1], ah, al);
+            const rg_f16x8 w0 = __builtin_bit_cast(rg_f16x8, wring[rs][0]), w1 = __builtin_bit_cast(rg_f16x8, wring[rs][1]);
+            const rg_f16x8 w2 = __builtin_bit_cast(rg_f16x8, wring[rs][2]), w3 = __builtin_bit_cast(rg_f16x8, wring[rs][3]);
+            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, ah, acc[j][0], 0, 0, 0);      // small terms first
+            acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3, ah, acc[j][1], 0, 0, 0);
+            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, al, acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, al, acc[j][1], 0, 0, 0);
+            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, ah, acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, ah, acc[j][1], 0, 0, 0);
+          } else if constexpr (BF16) {
             const bf16x8_t av = __builtin_bit_cast(bf16x8_t, aring[rs][j][0]);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -1058,7 +1096,7 @@ static int launch_wg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
 }
 
 // ------------------------------------------------------------------ launcher
-template <int CIN, int COUT, bool BF16, int KSP, int D, int G>
+template <int CIN, int COUT, bool BF16, int KSP, int D, int G, bool SPLIT = false>
 static int launch_rg_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stream) {
   constexpr int NS = COUT / 32;
   constexpr int NW = KSP;                                // a workgroup = the waves that share a tile (see launch_dma_d)
@@ -1066,7 +1104,7 @@ static int launch_rg_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stre
   const size_t lds = NW * (NPIECE * 256 + 16) * sizeof(int32_t) + (KSP > 1 ? 2 * NW * 2 * G * 64 * sizeof(f32x4) : 0);
   static AttrOnce attr_done;                         // per instantiation; idempotent
   if (attr_done.need() && lds > 48 * 1024) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G, NW>),
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G, NW, SPLIT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done.mark(); 
   }
@@ -1077,10 +1115,10 @@ static int launch_rg_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stre
   grid = (grid + 7) / 8 * 8;
   hipEvent_t* pev = prof_kernel_events();
   if (pev[0]) {      // bench.py roofline leg: time exactly this dispatch
-    hipExtLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, pev[0], pev[1], 0, a);
+    hipExtLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G, NW, SPLIT>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, pev[0], pev[1], 0, a);
     pev[0] = pev[1] = nullptr;
   } else {
-    hipLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL((sconv_rg_kernel<CIN, COUT, BF16, D, KSP, G, NW, SPLIT>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
   }
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
@@ -1088,7 +1126,7 @@ static int launch_rg_d(const SconvArgs& a, int64_t groups_hint, hipStream_t stre
 // sel (tests / A-B measurements; every choice gives bitwise-identical results): 0 = product choice, 1 = register-ring
 // kernel, 2 = register-ring kernel with two groups per wave, 3 = LDS-DMA kernel (fp32 maps; split-phase LDS fetch, 4 ring slots), 4 = LDS-DMA kernel with the fetch inside the item (3 slots), 9 = traced build
 template <int CIN, int COUT, bool BF16>
-static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream, int sel, int level) {
+static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream, int sel, int level, int split) {
   constexpr int NS = COUT / 32, NCB = CIN / 32;
   // the input-channel blocks are always split over the waves of a workgroup (a function of the shape only, so results
   // never depend on launch sizes): measured faster at every level, 12 % on the 84 k-row 64->64 layer, 40 % on level 4.
@@ -1100,6 +1138,11 @@ static int launch_rg(const SconvArgs& a, int64_t groups_hint, hipStream_t stream
   // capacity: eager plans, reserved (graph) plans, the per-layer table and rocprof all see the same kernel.  bf16 maps are the
   // batch-64 configuration (BASELINE configs[2]): level 5 still fills the chip there
   const bool small = level >= (BF16 ? 6 : 5);
+  if constexpr (!BF16 && CIN == 128 && COUT == 128) {      // the tail levels' plan on split arithmetic (a.Wp = the split pack)
+    // (ring depth 9 / 12 instead of 6: L6 k=3 21.7 / 22.5 vs 18.1 us, L6 k2s2 13.2 / 14.7 vs 8.8 — profiles/r06c_kw_sweep.txt)
+    if (split) return launch_rg_d<CIN, COUT, false, KSP, 6, 1, true>(a, groups_hint, stream);
+  }
+  EGONN_REQUIRE(!split, EGONN_ERR_INVALID, "sconv: the per-tile kernel has split arithmetic for fp32 128->128 maps only");
   if constexpr (!BF16) {
     {
       if (sel == 3 || (sel == 0 && !small)) return launch_dma_d<CIN, COUT, KSP, 4, false, true>(a, groups_hint, stream);
@@ -1130,7 +1173,7 @@ bool sconv_rg_supported(int cin, int cout) {
 // the groups in use (sizes the persistent grid only; the kernel reads the true count from rg.meta[0]).
 int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wp, int cin,
                      int cout, int bf16, const float* scale, const float* shift, int relu, void* out, float* psum,
-                     hipStream_t stream, int variant, int level) {
+                     hipStream_t stream, int variant, int level, int split, int32_t* flags) {
   EGONN_REQUIRE(rg.built, EGONN_ERR_STATE, "sconv: row-group tables not built");
   EGONN_REQUIRE(sconv_rg_supported(cin, cout), EGONN_ERR_INVALID, "sconv: channel plan %d->%d not supported (32/64/128/256)", cin, cout);
   const uint64_t ib = (uint64_t)n_in_cap * cin * (bf16 ? 2 : 4);
@@ -1146,6 +1189,7 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
   static const bool no_order = getenv("EGONN_NO_TASK_ORDER") != nullptr;   // (measurement switch)
   a.order4 = no_order ? nullptr : rg.order4;
   a.trace = variant == 9 ? g_sconv_trace : nullptr;
+  a.flags = flags;
 
   // Measured (profiles/r02b_sconv.json, batch 16): in fp32 the per-wave kernel wins everywhere (the lock-step of the
   // cooperative kernel costs more than its saved W traffic when an item is 16-64 MFMAs of 32 cycles); with bf16 maps the
@@ -1155,7 +1199,7 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
 #define EGONN_RG_CASE(CI, CO)                                                                      \
   if (cin == CI && cout == CO) {                                                                   \
     if (coop) return bf16 ? launch_wg<CI, CO, true>(a, groups_hint, stream) : launch_wg<CI, CO, false>(a, groups_hint, stream); \
-    return bf16 ? launch_rg<CI, CO, true>(a, groups_hint, stream, gsel, level) : launch_rg<CI, CO, false>(a, groups_hint, stream, gsel, level); \
+    return bf16 ? launch_rg<CI, CO, true>(a, groups_hint, stream, gsel, level, split) : launch_rg<CI, CO, false>(a, groups_hint, stream, gsel, level, split); \
   }
   EGONN_RG_CASE(32, 32)
   EGONN_RG_CASE(32, 64)
@@ -1230,7 +1274,7 @@ bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int s
 // parts per task, 0 = automatic): measurement overrides, comma lists indexed by the output level.
 void sconv_ksplit_defaults(KsRule* r) {
   static const KsRule rule = [] {
-    KsRule q = {{{1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1}}, {{0, 0, 0, 2, 3, 4, 0, 0}, {0, 0, 0, 0, 2, 4, 0, 0}}, {0, 0, 0, 0, 0, 0, 0, 0}};
+    KsRule q = {{{1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1}}, {{0, 0, 0, 2, 3, 4, 0, 0}, {0, 0, 0, 2, 2, 4, 0, 0}}, {0, 0, 0, 0, 0, 0, 0, 0}};
     auto parse = [](const char* name, int8_t* dst) {
       const char* e = getenv(name);
       for (int l = 0; e && *e && l < EGONN_NUM_LEVELS; ++l) {
@@ -1309,6 +1353,19 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
   }
   EGONN_REQUIRE(ctx->split_io == 0 && !ctx->gated_in2, EGONN_ERR_STATE,
                 "sconv: split-form maps and gated inputs are read and written by the split kernel only");
+  // fp32 maps of the tail levels (above split_max_level): the per-tile kernel on split arithmetic (a function of the layer)
+  static const bool tail_split_ok = getenv("EGONN_NO_TAIL_SPLIT") == nullptr;          // measurement switch
+  if (tail_split_ok && !bf16 && cin == 128 && cout == 128 && ctx->conv_variant == 0 && ctx->split_max_level >= 0 &&
+      level > ctx->split_max_level && !ctx->operand_autoscale) {
+    if (!Wsp) {
+      const size_t wn = (split_weights_bytes(K, cin, cout) + 3) / 4;
+      EGONN_REQUIRE(W && scratch && scratch_floats >= wn, EGONN_ERR_STATE, "sconv: no scratch to pack the kernel into");
+      EGONN_TRY(pack_split_weights(W, K, cin, cout, 0, 0, scratch, stream));
+      Wsp = scratch;
+    }
+    return sconv_rg_forward(in, P.cap[lin], rg, rg.cap_groups, Wsp, cin, cout, 0, scale, shift, relu, out, psum, stream, 0, level, 1,
+                            ctx->dev_flags);
+  }
   if (!Wp) {      // stand-alone operator call: pack into the caller's scratch
     const size_t wn = (size_t)K * cin * cout;
     EGONN_REQUIRE(W && scratch && scratch_floats >= wn, EGONN_ERR_STATE, "sconv: no scratch to pack the kernel into");
