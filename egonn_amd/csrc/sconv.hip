@@ -1263,10 +1263,13 @@ bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int s
 
 // Offset-split rule (see kernels.h): a function of (map kind, output level) only.
 //   kw      offset parts INSIDE a workgroup (sconv_split_kernel<..., KW>): the small maps are chains of K * Cin/32 dependent steps on
-//           workgroups of one wave per SIMD; KW waves per SIMD walk KW interleaved thirds / quarters of the offsets and hide each
-//           other's LDS and MFMA latencies.  Measured per layer, batch 16 (profiles/r06c_kw_sweep.txt): L4 128->128 70 -> 42 us,
-//           L5 k=3 67 / 62 -> 32 / 30, L5 k=2,s=2 27 -> 16, transposed 25 -> 15, L3 64->64 42 / 37 -> 38 / 35.  The rule stops where
-//           the launches stop gaining: levels 6-7 stay on the per-tile kernels (34 vs 23 us), level 3's 8-slot maps unsplit.
+//           workgroups of one wave per SIMD; KW waves per SIMD walk KW interleaved shares of the offsets and hide each other's LDS
+//           and MFMA latencies.  Measured per layer, batch 16 (profiles/r06c_kw_sweep.txt): KW 1 / 2 / 3 / 4: L4 128->128 70 / 50 / 42 /
+//           40 us, L5 k=3 67 / 40 / 35 / 32, L5 k=2,s=2 27 / 19 / 17 / 16, L3 64->64 42 -> 27 (KW 2, 64 columns per workgroup).
+//           The rule is KW = 2 on levels 3-5, both map classes: a KW 3-4 workgroup (12-16 waves, 120-160 KB of LDS) needs an empty
+//           CU, and with four batches in flight the step pays for it — one box, scans/s / one-batch latency / aggregate: no parts
+//           27.9 k / 1.196 ms / 0.209, KW 2 27.1 k / 1.060 / 0.263, KW (2,3,4) 25.7 k / 1.048 / 0.276.  Levels 6-7 stay on the
+//           per-tile kernel (KW 3 on the lock-step kernel: 34 vs 23 us).
 //   kparts  offset parts as SEPARATE workgroups + a reducer launch (blockIdx.z): built, parity-green, measured
 //           (L5 k=3 65 -> 30 us, L4 128->128 67 -> 48), default off: the partial tiles are 16 MB per level-5 convolution and the step
 //           with four batches in flight loses 4-6 % against 1.5-3 % for the in-workgroup parts at the same serial gain.
@@ -1274,7 +1277,7 @@ bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int s
 // parts per task, 0 = automatic): measurement overrides, comma lists indexed by the output level.
 void sconv_ksplit_defaults(KsRule* r) {
   static const KsRule rule = [] {
-    KsRule q = {{{1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1}}, {{0, 0, 0, 2, 3, 4, 0, 0}, {0, 0, 0, 2, 2, 4, 0, 0}}, {0, 0, 0, 0, 0, 0, 0, 0}};
+    KsRule q = {{{1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1}}, {{0, 0, 0, 2, 2, 2, 0, 0}, {0, 0, 0, 2, 2, 2, 0, 0}}, {0, 0, 0, 0, 0, 0, 0, 0}};
     auto parse = [](const char* name, int8_t* dst) {
       const char* e = getenv(name);
       for (int l = 0; e && *e && l < EGONN_NUM_LEVELS; ++l) {
