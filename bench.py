@@ -498,8 +498,10 @@ def main():
     rccl_ranks_seen = ranks_seen(dist if distributed else None, dev)
     if rank == 0:
         total_scans = args.batch * world * args.steps
-        tail_desc = ("per-layer launches on exact v_mfma_f32_16x16x4_f32; the maps of levels 3-5 split their offsets over 2-4 waves "
-                     "per SIMD inside a workgroup (fixed partition, fixed order: deterministic and batch-invariant)")
+        tail_desc = ("the same split arithmetic on the per-tile kernel; the global head's 1x1 convolutions and decoder on exact "
+                     "v_mfma_f32_16x16x4_f32; the local heads' Linear layers on the split pipe; the maps of levels 3-5 split their offsets "
+                     "over 2 waves per SIMD inside a workgroup (fixed partition, fixed order: deterministic and batch-invariant); an "
+                     "activation beyond the fp16 range raises EGONN_STATUS_FP16_RANGE (checked after the timed regions)")
         cfg = "configs[1]" if (args.dtype == "f32" and args.batch == 16) else \
               ("configs[2]" if (args.dtype == "bf16" and args.batch == 64 and args.mode == "graph") else "configs[1] variant")
         line = {
@@ -530,7 +532,7 @@ def main():
                                            "fp32 in / fp32 out; sparse convs of levels 1-5 (a function of the layer, not of the batch): operands "
                                            "split into fp16 hi + lo (weights scaled by a power of two per kernel), 3 products on "
                                            "v_mfma_f32_16x16x32_f16 with fp32 accumulation (deviation from the plain fp32 kernel < 3e-6 of the "
-                                           "largest output, tests/test_gpu_graph.py); levels 6-7 and the global head: " + tail_desc + "; conv_variant="
+                                           "largest output, tests/test_gpu_graph.py); levels 6-7: " + tail_desc + "; conv_variant="
                                            + str(args.conv_variant))},
             "repeats": {"timed_regions": len(elapsed_all), "reported": "median",
                         "scans_per_s": [round(total_scans / e, 1) for e in elapsed_all],
