@@ -131,12 +131,12 @@ __global__ __launch_bounds__(256) void dense_kernel(const void* __restrict__ in_
 
 // dense_small_kernel: the same tile arithmetic for launches too small to hide latency (n < 8192 rows) — see its first comment.
 template <int W_OUT_IN, int CIN, bool IN_BF16>
-__global__ __launch_bounds__(256) void dense_small_kernel(const void* __restrict__ in_v, int64_t n,
-                                                    const float* __restrict__ W, int cout,
-                                                    const float* __restrict__ bias, const float* __restrict__ scale,
-                                                    const float* __restrict__ shift, int act,
-                                                    const void* __restrict__ residual_v, void* __restrict__ out_v, int io,
-                                                    const int32_t* __restrict__ n_dev) {
+__device__ static inline void dense_small_body(const void* __restrict__ in_v, int64_t n,
+                                               const float* __restrict__ W, int cout,
+                                               const float* __restrict__ bias, const float* __restrict__ scale,
+                                               const float* __restrict__ shift, int act,
+                                               const void* __restrict__ residual_v, void* __restrict__ out_v, int io,
+                                               const int32_t* __restrict__ n_dev, const int block_x, const int block_y) {
   // ONE memory round trip per wave: the live row count, the 16 input rows, the weights of all four 16-column tiles,
   // the epilogue vectors and the residual values are all requested before anything is waited for (the first version
   // walked a chain of five dependent round trips — count, rows, weights of pass 0, its epilogue vectors, weights of
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const void* __restrict
   constexpr int KS = CIN / 16;                                                  // branch and a partial wait per load)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g4 = lane >> 4;
-  const int64_t row_base = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  const int64_t row_base = ((int64_t)block_x * 4 + wave) * 16;
   if (row_base >= ncap) return;
   const int64_t row = min(row_base + l15, ncap - 1);
   float4 a[KS];
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const void* __restrict
       a[t] = *reinterpret_cast<const float4*>(in + row * CIN + 16 * t + 4 * g4);
     }
   }
-  const int ncol0 = blockIdx.y * 64;
+  const int ncol0 = block_y * 64;
   float4 b[4][KS];
   float bi[4], sc[4], sh[4];
   const float* bias_p = bias ? bias : W;
@@ -250,6 +250,34 @@ __global__ __launch_bounds__(256) void dense_small_kernel(const void* __restrict
 }
 
 // sample (scan) of row r: last b with boff[b] <= r
+template <int W_OUT_IN, int CIN, bool IN_BF16>
+__global__ __launch_bounds__(256) void dense_small_kernel(const void* __restrict__ in_v, int64_t n,
+                                                    const float* __restrict__ W, int cout,
+                                                    const float* __restrict__ bias, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, int act,
+                                                    const void* __restrict__ residual_v, void* __restrict__ out_v, int io,
+                                                    const int32_t* __restrict__ n_dev) {
+  dense_small_body<W_OUT_IN, CIN, IN_BF16>(in_v, n, W, cout, bias, scale, shift, act, residual_v, out_v, io, n_dev, (int)blockIdx.x,
+                                           (int)blockIdx.y);
+}
+// Up to three INDEPENDENT small products of one shape in one launch (the three lateral 1x1 convolutions of MinkHead,
+// models/minkgl.py:46-60: they depend on the trunk only, not on each other): block ranges of one grid, the body of the kernel above.
+struct DenseGroup3 {
+  const void* in[3];
+  const float* W[3];
+  void* out[3];
+  const int32_t* n_dev[3];
+  int64_t n[3];
+  int bx0[4];                // first block of every problem along grid.x
+};
+template <int W_OUT_IN, int CIN, bool IN_BF16>
+__global__ __launch_bounds__(256) void dense_small3_kernel(const DenseGroup3 g, int cout, int io) {
+  const int b = (int)blockIdx.x;
+  const int q = b >= g.bx0[2] ? 2 : (b >= g.bx0[1] ? 1 : 0);
+  dense_small_body<W_OUT_IN, CIN, IN_BF16>(g.in[q], g.n[q], g.W[q], cout, nullptr, nullptr, nullptr, ACT_NONE, nullptr, g.out[q], io,
+                                           g.n_dev[q], b - g.bx0[q], (int)blockIdx.y);
+}
+
 __device__ static inline int sample_of_row(const int32_t* __restrict__ boff, int B, int32_t r) {
   int lo = 0, hi = B;   // boff[lo] <= r < boff[hi]
   while (hi - lo > 1) {
@@ -484,6 +512,24 @@ int dense_forward_ex(const void* in, int in_bf16, int64_t n, int cin, const floa
   HIP_CHECK(hipGetLastError());
   return EGONN_OK;
 }
+// Three (n_i, 128) @ (128, 128) products ((cin, cout) kernels, no bias / BN / activation) in ONE launch of dense_small3_kernel;
+// fp32 rows in and out.  Every n_i must be below the 8192 rows up to which the small kernel is the product choice.
+int dense_small_group3(const float* const* in, const int64_t* n, const int32_t* const* n_dev, const float* const* W, float* const* out,
+                       hipStream_t stream) {
+  DenseGroup3 g;
+  int bx = 0;
+  for (int q = 0; q < 3; ++q) {
+    EGONN_REQUIRE(n[q] < 8192, EGONN_ERR_INVALID, "dense(group): %lld rows", (long long)n[q]);
+    g.in[q] = in[q]; g.W[q] = W[q]; g.out[q] = out[q]; g.n_dev[q] = n_dev[q]; g.n[q] = n[q];
+    g.bx0[q] = bx;
+    bx += (int)cdiv(std::max<int64_t>(n[q], 1), 64);
+  }
+  g.bx0[3] = bx;
+  hipLaunchKernelGGL((dense_small3_kernel<0, 128, false>), dim3((unsigned)bx, 2), dim3(256), 0, stream, g, 128, 0);
+  HIP_CHECK(hipGetLastError());
+  return EGONN_OK;
+}
+
 int dense_forward(const float* in, int64_t n, int cin, const float* W, int w_out_in, int cout, const float* bias,
                   const float* scale, const float* shift, int act, const float* residual, float* out,
                   hipStream_t stream) {

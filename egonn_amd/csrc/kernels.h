@@ -20,7 +20,11 @@ const char* sconv_kernel_name(const Ctx* ctx, int kind, int level, int cin, int 
 int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wp, int cin,
                      int cout, int bf16, const float* scale, const float* shift, int relu, void* out, float* psum,
                      hipStream_t stream, int variant = 0, int level = 0,
-                     int split = 0, int32_t* flags = nullptr);   // split: Wp = pack_split_weights form, fp16-split arithmetic (128->128 fp32 maps)
+                     int split = 0, int32_t* flags = nullptr,    // split: Wp = pack_split_weights form, fp16-split arithmetic (128->128 fp32 maps)
+                     const float* residual = nullptr);           // out += residual (fp32 maps) in the epilogue
+// three independent (n_i, 128) @ (128, 128) products in one launch (dense.hip)
+int dense_small_group3(const float* const* in, const int64_t* n, const int32_t* const* n_dev, const float* const* W, float* const* out,
+                       hipStream_t stream);
 // Convolution over a map of the plan.  kind 0: k=3 on `level`; 1: k=2,s=2 from level-1 into `level`; 2: transposed from
 // level+1 onto `level`.  Wp: kernel already packed for this precision (or null: W is packed into `scratch` first).
 // bf16: feature maps in/out and weights are bf16.  psum (nullable): [groups][cout] per-group column sums of the output.
@@ -42,7 +46,8 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
                         int col_parts = 0,                                                // column parts per task (0 = automatic)
                         int kw = 0,                                                       // offset parts INSIDE a workgroup (0 / 1: none; 2, 3, 4)
                         int32_t* flags = nullptr,                                         // the plan's flag word (bit 3: fp16 range guard)
-                        uint32_t* in_absmax = nullptr, int64_t in_elems = 0);             // operand autoscale: 8 bytes of scratch, elements of `in`
+                        uint32_t* in_absmax = nullptr, int64_t in_elems = 0,              // operand autoscale: 8 bytes of scratch, elements of `in`
+                        const float* residual = nullptr);                                 // out += residual ([n_out][cout] fp32) in the epilogue
 size_t sconv_split_part_floats(const RowGroups& rg, int cout, int kparts);
 // Offset-split rule of the fp32 lock-step kernels: parts of the map's K offsets (1 = unsplit) and column parts per task for
 // (map kind, output level) — a function of the LAYER only (the partition changes the summation order of a row)

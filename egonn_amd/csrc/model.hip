@@ -964,7 +964,39 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
   DBG_SYNC("local head");
 
   // ---- global head + decoder + GeM (models/minkgl.py:46-60, 207-225; layers/pooling.py:82-86)
+  static const bool fuse_ghead = getenv("EGONN_NO_FUSED_GHEAD") == nullptr;      // measurement switch
+  void* g5_fused = nullptr;
+  if (do_global && fuse_ghead && !bf16 && c->conv_variant == 0 && P.cap[5] < 8192 && P.cap[6] < 8192 && P.cap[7] < 8192) {
+    // MinkHead (models/minkgl.py:46-60) in three launches instead of five: the three lateral 1x1 convolutions depend on the trunk
+    // only — ONE grouped launch — and every FPN step `tconv(y) + lateral` is the transposed convolution with the lateral as its
+    // epilogue residual.  a + b = b + a: bitwise the five-launch result (tools/check_bitwise_switches.py).
+    WALLOC(l7, P.cap[7] * GLOBAL_CH);
+    WALLOC(l6, P.cap[6] * GLOBAL_CH);
+    WALLOC(l5, P.cap[5] * GLOBAL_CH);
+    WALLOC(g6f, P.cap[6] * GLOBAL_CH);
+    WALLOC(g5f, P.cap[5] * GLOBAL_CH);
+    const float* gin[3] = {reinterpret_cast<const float*>(x[7]), reinterpret_cast<const float*>(x[6]), reinterpret_cast<const float*>(x[5])};
+    const int64_t gn[3] = {P.cap[7], P.cap[6], P.cap[5]};
+    const int32_t* gnd[3] = {cnt + 7, cnt + 6, cnt + 5};
+    const float* gw[3] = {m->g1x1[7], m->g1x1[6], m->g1x1[5]};
+    float* gout[3] = {l7, l6, l5};
+    EGONN_TRY(dense_small_group3(gin, gn, gnd, gw, gout, st));
+    for (int lv = 6; lv >= 5; --lv) {
+      char tag[64];
+      snprintf(tag, sizeof(tag), "%s<%d,%d>/L%d/tconv", sconv_kernel_name(c, 2, lv, GLOBAL_CH, GLOBAL_CH, 0), GLOBAL_CH, GLOBAL_CH, lv);
+      ProfScope ps(c, st, tag, PK_TCONV, lv, 8, GLOBAL_CH, GLOBAL_CH, 4);
+      c->conv_residual = lv == 6 ? l6 : l5;
+      const int rc = sconv_map(c, 2, lv, lv == 6 ? l7 : g6f, nullptr, m->p_gt[lv + 1], m->s_gt[lv + 1], GLOBAL_CH, GLOBAL_CH, 0, nullptr, nullptr, 0,
+                               lv == 6 ? g6f : g5f, nullptr, nullptr, 0, st);
+      c->conv_residual = nullptr;
+      EGONN_TRY(rc);
+    }
+    g5_fused = g5f;
+    DBG_SYNC("global head (fused)");
+  }
   if (do_global) {
+    const float* g5 = reinterpret_cast<const float*>(g5_fused);
+    if (!g5) {
     FALLOC(g7, P.cap[7] * GLOBAL_CH);
     EGONN_TRY(dense_forward_ex(x[7], bf16, P.cap[7], 128, m->g1x1[7], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, nullptr, 0,
                                g7, bf16, st, cnt + 7));
@@ -989,10 +1021,12 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
       EGONN_TRY(sconv_map(c, 2, 5, g6, nullptr, bf16 ? m->q_gt[6] : m->p_gt[6], m->s_gt[6], GLOBAL_CH, GLOBAL_CH, bf16, nullptr, nullptr, 0, u5,
                           nullptr, nullptr, 0, st));
     }
-    WALLOC(g5, P.cap[5] * GLOBAL_CH);
+    WALLOC(g5u, P.cap[5] * GLOBAL_CH);
     EGONN_TRY(dense_forward_ex(x[5], bf16, P.cap[5], 128, m->g1x1[5], 0, GLOBAL_CH, nullptr, nullptr, nullptr, ACT_NONE, u5, bf16,
-                               g5, 0, st, cnt + 5));
+                               g5u, 0, st, cnt + 5));
+    g5 = g5u;
     DBG_SYNC("global head");
+    }
     WALLOC(gh, P.cap[5] * m->gdec.mid);
     WALLOC(gd, P.cap[5] * GLOBAL_DIM);
     EGONN_TRY(run_mlp(m->gdec, g5, P.cap[5], ACT_NONE, gh, gd, st, cnt + 5));

@@ -123,6 +123,7 @@ struct SconvArgs {
                                          // every XCD's eighth); used by the kernels whose task is exactly such a quadruple
   unsigned long long* trace = nullptr;   // measurement builds only (tools/sconv_trace.py): 8 u64 per wave task
   int32_t* flags = nullptr;              // SPLIT instantiation: the plan's flag word (bit 3: fp16 range guard, sconv_split.hip)
+  const float* res = nullptr;            // fp32 maps: out += res[row] in the epilogue (MinkHead's FPN step, models/minkgl.py:46-60)
 };
 
 // fp32 x 8 -> (hi, lo) fp16 x 8 (the two-way split of sconv_split.hip, same rounding)
@@ -206,6 +207,9 @@ __global__ __launch_bounds__(NW * 64) void sconv_rg_kernel(const SconvArgs p) {
       if (p.relu) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+      }
+      if constexpr (!BF16) {
+        if (p.res && row >= 0) v += *reinterpret_cast<const f32x4*>(p.res + (int64_t)row * COUT + c0);
       }
       if (row >= 0) {
         if constexpr (BF16) {
@@ -1173,7 +1177,7 @@ bool sconv_rg_supported(int cin, int cout) {
 // the groups in use (sizes the persistent grid only; the kernel reads the true count from rg.meta[0]).
 int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wp, int cin,
                      int cout, int bf16, const float* scale, const float* shift, int relu, void* out, float* psum,
-                     hipStream_t stream, int variant, int level, int split, int32_t* flags) {
+                     hipStream_t stream, int variant, int level, int split, int32_t* flags, const float* residual) {
   EGONN_REQUIRE(rg.built, EGONN_ERR_STATE, "sconv: row-group tables not built");
   EGONN_REQUIRE(sconv_rg_supported(cin, cout), EGONN_ERR_INVALID, "sconv: channel plan %d->%d not supported (32/64/128/256)", cin, cout);
   const uint64_t ib = (uint64_t)n_in_cap * cin * (bf16 ? 2 : 4);
@@ -1190,6 +1194,9 @@ int sconv_rg_forward(const void* in, int64_t n_in_cap, const RowGroups& rg, int6
   a.order4 = no_order ? nullptr : rg.order4;
   a.trace = variant == 9 ? g_sconv_trace : nullptr;
   a.flags = flags;
+  a.res = residual;
+  EGONN_REQUIRE(!residual || (!bf16 && level >= 5 && (variant == 0 || variant == 1)), EGONN_ERR_INVALID,
+                "sconv: the epilogue residual exists in the per-tile kernel of fp32 maps (levels >= 5) and in the split kernel");
 
   // Measured (profiles/r02b_sconv.json, batch 16): in fp32 the per-wave kernel wins everywhere (the lock-step of the
   // cooperative kernel costs more than its saved W traffic when an item is 16-64 MFMAs of 32 cycles); with bf16 maps the
@@ -1330,7 +1337,7 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
     EGONN_REQUIRE(W, EGONN_ERR_INVALID, "sconv: the plain kernel needs the reference-layout kernel");
     if (kind == 2 && level == 0) EGONN_TRY(ensure_level0_parent_table(ctx, stream));
     const int32_t* nbr = kind == 0 ? V.nbr27 : (kind == 1 ? V.nbr8 : V.nbrT);
-    EGONN_REQUIRE(!psum, EGONN_ERR_INVALID, "sconv: group sums are produced by the MFMA kernel only");
+    EGONN_REQUIRE(!psum && !ctx->conv_residual, EGONN_ERR_INVALID, "sconv: group sums / epilogue residuals are produced by the MFMA kernels only");
     return sconv_naive(reinterpret_cast<const float*>(in), nbr, W, scale, shift, relu, reinterpret_cast<float*>(out), V.n, K,
                        cin, cout, stream);
   }
@@ -1352,7 +1359,7 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
                                ctx->conv_variant >= 1000 ? ctx->conv_variant - 1000 : 0, ctx->split_io, ctx->gated_in2, ctx->gated_gate,
                                P.batch, kparts, ctx->ks_part, ctx->ks_part_floats, col_parts, kw, ctx->dev_flags,
                                ctx->operand_autoscale ? reinterpret_cast<uint32_t*>(ctx->dev_counts + 24) : nullptr,
-                               ctx->operand_autoscale ? P.lv[lin].n * cin : 0);
+                               ctx->operand_autoscale ? P.lv[lin].n * cin : 0, ctx->conv_residual);
   }
   EGONN_REQUIRE(ctx->split_io == 0 && !ctx->gated_in2, EGONN_ERR_STATE,
                 "sconv: split-form maps and gated inputs are read and written by the split kernel only");
@@ -1367,7 +1374,7 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
       Wsp = scratch;
     }
     return sconv_rg_forward(in, P.cap[lin], rg, rg.cap_groups, Wsp, cin, cout, 0, scale, shift, relu, out, psum, stream, 0, level, 1,
-                            ctx->dev_flags);
+                            ctx->dev_flags, ctx->conv_residual);
   }
   if (!Wp) {      // stand-alone operator call: pack into the caller's scratch
     const size_t wn = (size_t)K * cin * cout;
@@ -1376,7 +1383,7 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
     Wp = scratch;
   }
   return sconv_rg_forward(in, P.cap[lin], rg, rg.cap_groups, Wp, cin, cout, bf16, scale, shift, relu, out, psum, stream,
-                          ctx->conv_variant, level);
+                          ctx->conv_variant, level, 0, nullptr, ctx->conv_residual);
 }
 
 }  // namespace egonn

@@ -165,6 +165,9 @@ struct SplitArgs {
   // of max |in| (split_absmax_kernel); the gathered rows are multiplied by the power of two that puts the maximum into
   // [2^13, 2^14) before they are split — what pack_split_weights does to the kernel — and the epilogue divides it out (both exact).
   const uint32_t* in_maxbits = nullptr;
+  // RESIDUAL (nullable): out[row] = epilogue value + res[row] ([n_out][COUT] fp32) — the FPN step of MinkHead, `tconv(y) + conv1x1(x)`
+  // (models/minkgl.py:46-60), as the transposed convolution's epilogue
+  const float* res = nullptr;
 };
 __host__ __device__ static inline uint32_t ks_range_mask(int kp, int kp_n, int K) {      // offsets [kp*K/kp_n, (kp+1)*K/kp_n)
   const int k0 = kp * K / kp_n, k1 = (kp + 1) * K / kp_n;
@@ -226,6 +229,7 @@ __device__ static inline void split_epilogue(const SplitArgs& p, const f32x4& a0
 #pragma unroll
       for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
     }
+    if (p.res && row >= 0) v += *reinterpret_cast<const f32x4*>(p.res + (int64_t)row * COUT + c0);
     if (row >= 0 && !p.out_split) *reinterpret_cast<f32x4*>(p.out + (int64_t)row * COUT + c0) = v;
     vv[nt] = v;
 #pragma unroll
@@ -709,7 +713,7 @@ bool sconv_split_supported(int cin, int cout) {
 int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, int64_t groups_hint, const void* Wsp, int cin,
                         int cout, const float* scale, const float* shift, int relu, float* out, float* psum, hipStream_t stream,
                         int cfg, int split_io, const float* gated_in2, const float* gated_gate, int B, int kparts, float* part,
-                        size_t part_floats, int col_parts, int kw, int32_t* flags, uint32_t* in_absmax, int64_t in_elems) {
+                        size_t part_floats, int col_parts, int kw, int32_t* flags, uint32_t* in_absmax, int64_t in_elems, const float* residual) {
   EGONN_REQUIRE(rg.built, EGONN_ERR_STATE, "sconv: row-group tables not built");
   EGONN_REQUIRE(sconv_split_supported(cin, cout), EGONN_ERR_INVALID, "sconv(split): channel plan %d->%d not supported", cin, cout);
   EGONN_REQUIRE((uint64_t)n_in_cap * cin * 4 < (1ull << 32) - (1ull << 20), EGONN_ERR_INVALID,
@@ -724,6 +728,7 @@ int sconv_split_forward(const float* in, int64_t n_in_cap, const RowGroups& rg, 
   a.w_bytes = (uint32_t)((uint64_t)rg.K * cin * cout * 4);           // the fragments; the pack scale's inverse sits right behind them
   a.K = rg.K; a.relu = relu ? 1 : 0; a.cap_groups = rg.cap_groups;
   a.flags = flags;
+  a.res = residual;
   a.in_split = (split_io & 1) ? 1 : 0;
   if (in_absmax) {                                       // operand autoscale: max |in| -> in_absmax[1] (one memset + one launch)
     EGONN_REQUIRE(!(split_io & 1) && !gated_in2 && in_elems > 0, EGONN_ERR_INVALID, "sconv(split): operand scale on a plain fp32 input only");

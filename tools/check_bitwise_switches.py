@@ -3,6 +3,8 @@
   EGONN_NO_FUSED_DOWN=1  1x1 downsample branch + BatchNorm and the gated residual + ReLU as two launches instead of one (dense.hip)
   EGONN_NO_FUSED_LATERAL=1  the local head's level-3 lateral 1x1 convolution as its own launch instead of the heads' first layer
   EGONN_NO_GATED_K2S2=1  level 1's block tail as its own launch + a 23 MB map instead of being evaluated by level 2's strided convolution
+  EGONN_NO_FUSED_GHEAD=1  MinkHead's three lateral 1x1 convolutions as three launches and every FPN add inside the next lateral (round 5) instead of
+                          one grouped launch + the lateral as the transposed convolution's epilogue residual (fp32 maps)
 fp32 maps (4 scans) and bf16 maps."""
 import os, subprocess, sys, hashlib
 import numpy as np
@@ -40,7 +42,7 @@ else:
     ok = True
     for prec in ("fp32", "bf16"):
         d = []
-        for env in ({}, {"EGONN_NO_PRESPLIT": "1"}, {"EGONN_NO_FUSED_DOWN": "1"}, {"EGONN_NO_FUSED_LATERAL": "1"}, {"EGONN_NO_GATED_K2S2": "1"}):
+        for env in ({}, {"EGONN_NO_PRESPLIT": "1"}, {"EGONN_NO_FUSED_DOWN": "1"}, {"EGONN_NO_FUSED_LATERAL": "1"}, {"EGONN_NO_GATED_K2S2": "1"}, {"EGONN_NO_FUSED_GHEAD": "1"}):
             r = subprocess.run([sys.executable, __file__, "child"], capture_output=True, text=True,
                                env=dict(os.environ, CHECK_PRECISION=prec, **env))
             line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")]
