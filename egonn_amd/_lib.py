@@ -26,6 +26,7 @@ _SIGS = [
     ("egonn_last_error", C.c_char_p, []),
     ("egonn_debug_set_naive_conv", C.c_int, [_P, C.c_int]),
     ("egonn_debug_set_ksplit", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("egonn_debug_keep_level_features", C.c_int, [_P, C.c_int]),
     ("egonn_debug_set_trace", C.c_int, [_P]),
     ("egonn_prepare_maps", C.c_int, [_P, C.c_int, _P]),
     ("egonn_debug_rowgroup_tables", C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int64), _P]),
@@ -338,6 +339,10 @@ class Context:
     def set_naive_conv(self, on: bool):
         """tests only: route this context's sparse convolutions through the plain (non-MFMA) kernel."""
         check(self.lib.egonn_debug_set_naive_conv(self.h, int(on)))
+
+    def keep_level_features(self, on: bool):
+        """tests only: materialise every level's block output (forward_level_features(1) then works)."""
+        check(self.lib.egonn_debug_keep_level_features(self.h, int(bool(on))))
 
     def set_exact_fp32(self, on: bool):
         """fp32 maps: True = every sparse convolution on the exact fp32 kernels (full fp32 range); False (default) = levels <= 5 on

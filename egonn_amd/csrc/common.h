@@ -210,6 +210,7 @@ struct Ctx {
   const float* gated_gate = nullptr;  // relu(in[r] * gate[scan] + in2[r]) — the tail of the ECA block below, never materialised
   float* ks_part = nullptr;   // scratch for the partial tiles of the offset-split launches (sconv_split.hip): carved from the work arena
   size_t ks_part_floats = 0;  // by egonn_forward / the stand-alone operator entry points (sconv_ksplit_scratch_floats)
+  int keep_level_features = 0;   // egonn_debug_keep_level_features: no fusion that leaves a level's block output unmaterialised
   const float* conv_residual = nullptr;   // set by egonn_forward around ONE sconv_map call (fp32 maps): out += residual in the epilogue
   int operand_autoscale = 0;  // egonn_ctx_set_operand_autoscale: the fp16-split convolutions scale their INPUT by a power of two per launch
                               // (max |in| -> [2^13, 2^14), undone in the epilogue): the input-gradient convolutions of a training step

@@ -250,6 +250,14 @@ API int egonn_ctx_set_operand_autoscale(egonn_ctx* c, int on) {
   return EGONN_OK;
 }
 
+// on = 1: egonn_forward materialises the block output of EVERY level (egonn_forward_level_features(ctx, 1, ...) then has a map to
+// return): level 1's block tail runs as its own launch instead of inside level 2's strided convolution (bitwise the same result).
+API int egonn_debug_keep_level_features(egonn_ctx* c, int on) {
+  EGONN_REQUIRE(c && (on == 0 || on == 1), EGONN_ERR_INVALID, "debug_keep_level_features: bad argument");
+  c->keep_level_features = on;
+  return EGONN_OK;
+}
+
 API int egonn_ctx_set_exact_fp32(egonn_ctx* c, int on) {
   EGONN_REQUIRE(c && (on == 0 || on == 1), EGONN_ERR_INVALID, "ctx_set_exact_fp32: bad argument");
   c->split_max_level = on ? -1 : 5;
@@ -921,7 +929,7 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
     DBG_SYNC("L%d eca gate", i);
     const void* res = y;
     static const bool gated_ok = getenv("EGONN_NO_GATED_K2S2") == nullptr;        // measurement switch
-    if (i == 1 && gated_ok && !bf16 && !b.down && c->conv_variant == 0 && b.cout == 32 && m->blk[2].cin == 32 &&
+    if (i == 1 && gated_ok && !c->keep_level_features && !bf16 && !b.down && c->conv_variant == 0 && b.cout == 32 && m->blk[2].cin == 32 &&
         sconv_uses_split(32, 32, 0, 2, c->conv_variant, c->split_max_level, 1)) {
       // level 1's block output has ONE reader, the strided convolution into level 2, which reads every row exactly once: it
       // evaluates relu(t2 * gate[scan] + y) on the rows it gathers (sconv_split_kernel<32,32,...,GATED>) — the 23 MB map is neither
@@ -1052,7 +1060,8 @@ API int egonn_forward(egonn_ctx* c, egonn_model* m, const float* features, int q
 API int egonn_forward_level_features(egonn_ctx* c, int level, float* out, int channels, void* stream) {
   REQUIRE_PLAN(c);
   EGONN_REQUIRE(level >= 0 && level < EGONN_NUM_LEVELS && c->level_feat[level], EGONN_ERR_STATE,
-                "no features for level %d (run egonn_forward first)", level);
+                "no features for level %d (run egonn_forward first; level 1 of fp32 maps is materialised only after "
+                "egonn_debug_keep_level_features(ctx, 1))", level);
   EGONN_REQUIRE(channels == c->level_ch[level], EGONN_ERR_INVALID, "level %d has %d channels, caller expects %d", level,
                 c->level_ch[level], channels);
   const int64_t cnt = c->plan.lv[level].n * channels;

@@ -59,6 +59,10 @@ int egonn_debug_set_naive_conv(egonn_ctx* ctx, int on);
  * row's offsets in a fixed partition and order: results are deterministic and batch-invariant under each, and differ between
  * settings by summation order only (<= 3e-6 of the largest output; tests/test_gpu_ksplit.py). */
 int egonn_debug_set_ksplit(egonn_ctx* ctx, int map_class, int level, int kparts, int kw, int col_parts);
+/* tests only: on = 1 makes egonn_forward materialise the block output of every level, so that egonn_forward_level_features(ctx, 1, ...)
+ * has a map to return (by default level 1's block tail of fp32 maps is evaluated inside level 2's strided convolution and its
+ * 23 MB output never exists; bitwise the same results either way) */
+int egonn_debug_keep_level_features(egonn_ctx* ctx, int on);
 /* measurement hook: buffer for the traced sparse-conv build (debug variant 128): 8 u64 per wave task; NULL = off */
 int egonn_debug_set_trace(void* device_buffer);
 /* measurement hook: device copies of a map's row-group tables (gmask [groups], snbr [groups][K][16], nullable).  [SYNC] */

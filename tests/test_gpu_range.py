@@ -156,3 +156,33 @@ def test_split_pipe_against_exact_mode_end_to_end(gpu):
     assert d0.shape == d1.shape and float(cos(d0, d1).max()) < 1e-6
     assert float((k0 - k1).abs().max()) < 1e-4
     assert torch.allclose(s0, s1, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_level1_features_on_request(gpu):
+    """egonn_forward_level_features(1): by default level 1's block output of fp32 maps is never materialised (its tail runs inside
+    level 2's strided convolution) and the call says so; after egonn_debug_keep_level_features(ctx, 1) the map exists, and the
+    descriptors are bitwise the same either way."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import helpers as H
+    from egonn_amd.synth import lidar_scan
+    mp = gpu.ModelParams(model="egonn", coordinates="cartesian", quantization_step=0.1)
+    m = gpu.model_factory(mp)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in H.seeded_weights(9).items()})
+    m = m.to("cuda").eval()
+    ex = gpu.DescriptorExtractor(m, n_k=64)
+    scans = [torch.from_numpy(lidar_scan(40 + i, 15000)) for i in range(2)]
+    ctx = m.context()
+    a = ex.extract(scans)
+    with pytest.raises(gpu._lib.EgonnError):
+        ctx.forward_level_features(1, 32)
+    ctx.keep_level_features(True)
+    try:
+        b = ex.extract(scans)
+        f1 = ctx.forward_level_features(1, 32)
+    finally:
+        ctx.keep_level_features(False)
+    assert f1.shape == (ctx.level_count(1), 32) and bool(torch.isfinite(f1).all()) and float(f1.min()) >= 0.0
+    for k in ("global", "descriptors", "keypoints"):
+        assert torch.equal(a[k], b[k]), k
