@@ -701,11 +701,12 @@ __device__ static inline void nbr8T_all_body(const Nbr8TArgs& a, uint32_t vblock
 struct PlanTablesArgs {
   MaskArgs ma;
   Adj27Args adj;
+  Adj27Args adj2;            // levels 6-7 by search as well (a few thousand rows: one nbr27 launch of the chain less)
   Nbr8TArgs na;
   const int32_t *parent0, *parent1;     // grandparent: g0[i] = parent1[parent0[i]]
   int32_t* g0;
   int32_t cap0;
-  uint32_t b_mask, b_adj, b_gp, b_n8;   // workgroups of every part, in this order
+  uint32_t b_mask, b_adj, b_adj2, b_gp, b_n8;   // workgroups of every part, in this order
 };
 __global__ __launch_bounds__(256) void plan_tables_kernel(const PlanTablesArgs a) {
   uint32_t b = blockIdx.x;
@@ -713,6 +714,8 @@ __global__ __launch_bounds__(256) void plan_tables_kernel(const PlanTablesArgs a
   b -= a.b_mask;
   if (b < a.b_adj) { adj27_search_body(a.adj, b); return; }
   b -= a.b_adj;
+  if (b < a.b_adj2) { adj27_search_body(a.adj2, b); return; }
+  b -= a.b_adj2;
   if (b < a.b_gp) {
     const int32_t i = (int32_t)(b * 256 + threadIdx.x);
     if (i < level_rows(a.ma.counts, 0, a.cap0)) a.g0[i] = a.parent1[a.parent0[i]];
@@ -905,6 +908,19 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
     ta.adj = Adj27Args{V.keys, V1.keys, counts, NL - 2, NL - 1, cb - (NL - 2), cb - (NL - 1), nv, nv1, V.nbr27, V1.nbr27};
     ta.b_adj = (unsigned)cdiv(((int64_t)nv + nv1) * 27, 256);
   }
+  // levels 6 and 7 (1 488 + 682 rows at batch 16) by search too: bitwise the tables nbr27_kernel derives from levels 8 / 9, and the
+  // chain of dependent nbr27 launches is three instead of four.  (Capped: a level beyond 8 192 rows keeps the derived path.)
+  static const bool search67_ok = getenv("EGONN_NO_SEARCH67") == nullptr;              // measurement switch
+  const int search_from = (search67_ok && P.cap[NL - 4] <= 8192 && P.cap[NL - 3] <= 8192) ? NL - 4 : NL - 2;
+  ta.b_adj2 = 0;
+  ta.adj2 = ta.adj;
+  if (search_from == NL - 4) {
+    Level& V = P.lv[NL - 4];
+    Level& V1 = P.lv[NL - 3];
+    const int32_t nv = (int32_t)P.cap[NL - 4], nv1 = (int32_t)P.cap[NL - 3];
+    ta.adj2 = Adj27Args{V.keys, V1.keys, counts, NL - 4, NL - 3, cb - (NL - 4), cb - (NL - 3), nv, nv1, V.nbr27, V1.nbr27};
+    ta.b_adj2 = (unsigned)cdiv(((int64_t)nv + nv1) * 27, 256);
+  }
   const int32_t n0 = (int32_t)P.cap[0], n2 = (int32_t)P.cap[2];
   {   // first-layer (k=5) helpers
     P.g0 = A.alloc<int32_t>(n0);
@@ -937,7 +953,7 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
     ta.b_n8 = (unsigned)cdiv(na.prefix[EGONN_NUM_LEVELS], 256);
   }
   {
-    const unsigned nb = ta.b_mask + ta.b_adj + ta.b_gp + ta.b_n8;
+    const unsigned nb = ta.b_mask + ta.b_adj + ta.b_adj2 + ta.b_gp + ta.b_n8;
     if (nb > 0) hipLaunchKernelGGL(plan_tables_kernel, dim3(nb), dim3(256), 0, stream, ta);
   }
 
@@ -967,7 +983,7 @@ static int build_plan_from_sorted_input(Ctx* ctx, uint64_t* keys_raw, uint32_t* 
     if (g0 + g1 + extra > 0) hipLaunchKernelGGL(nbr27_kernel, dim3(g0 + g1 + extra), dim3(256), 0, stream, pair);
     npair = 0;
   };
-  for (int l = NL - 3; l >= 1; --l) {
+  for (int l = search_from - 1; l >= 1; --l) {
     Level& V = P.lv[l];
     const int32_t nv = (int32_t)P.cap[l];
     if (nv == 0) continue;
