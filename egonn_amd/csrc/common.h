@@ -210,6 +210,7 @@ struct Ctx {
   const float* gated_gate = nullptr;  // relu(in[r] * gate[scan] + in2[r]) — the tail of the ECA block below, never materialised
   float* ks_part = nullptr;   // scratch for the partial tiles of the offset-split launches (sconv_split.hip): carved from the work arena
   size_t ks_part_floats = 0;  // by egonn_forward / the stand-alone operator entry points (sconv_ksplit_scratch_floats)
+  const void* sort_prezeroed = nullptr;   // the per-scan histograms of the segmented sort were zeroed by the kernel in front of it
   int keep_level_features = 0;   // egonn_debug_keep_level_features: no fusion that leaves a level's block output unmaterialised
   const float* conv_residual = nullptr;   // set by egonn_forward around ONE sconv_map call (fp32 maps): out += residual in the epilogue
   int operand_autoscale = 0;  // egonn_ctx_set_operand_autoscale: the fp16-split convolutions scale their INPUT by a power of two per launch
@@ -268,6 +269,9 @@ int radix_sort_segments(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t
                         const int64_t* off_dev, int B, int nbits, hipStream_t stream, uint64_t** keys_res, uint32_t** vals_res,
                         int idx_bits = 0);
 size_t radix_sort_segments_scratch_bytes(int64_t n, int B);
+int radix_sort_segments_layout(Ctx* ctx, int64_t n, int B, int32_t** tilehist, int32_t** scanhist);
+int radix_sort_segments_passes(int nbits);
+int radix_sort_segments_digits();
 
 // ------------------------------------------------------------------ coords.hip
 int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets, int64_t n_cap, int offsets_on_device,

@@ -136,8 +136,13 @@ __device__ static inline bool encode_key(int32_t b, int32_t cx, int32_t cy, int3
 // the scan), no value array: the batch index is implied by the segment and restored by the sort's last pass.
 __global__ void points_to_keys_kernel(const float* __restrict__ pts, int64_t n_cap, const int64_t* __restrict__ scan_off,
                                       int B, QuantParams qp, int cb, uint64_t* __restrict__ keys,
-                                      uint32_t* __restrict__ vals, int32_t* __restrict__ flags, int idx_bits) {
+                                      uint32_t* __restrict__ vals, int32_t* __restrict__ flags, int idx_bits,
+                                      int64_t* __restrict__ off_copy, int32_t* __restrict__ zero_ptr, int zero_words) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // riders (graph nodes saved): the plan's own copy of the scan offsets, and the zeroing of the sort's per-scan histograms —
+  // both are read by LATER launches only
+  if (off_copy && i <= B) off_copy[i] = scan_off[i];
+  for (int64_t w = i; w < zero_words; w += (int64_t)gridDim.x * blockDim.x) zero_ptr[w] = 0;
   const int64_t nn = scan_off[B];
   if (i == 0 && nn > n_cap) atomicOr(flags, 2);         // more points than the plan was reserved for
   // the segmented sort moves only rows inside [off[b], off[b+1]): offsets that do not start at 0 or that decrease would leave
@@ -1110,15 +1115,23 @@ int plan_from_points(Ctx* ctx, const float* points, const int64_t* scan_offsets,
     int64_t* stage = reinterpret_cast<int64_t*>(ctx->host_counts + 32 + (size_t)EGONN_NUM_LEVELS * (EGONN_MAX_BATCH + 1));
     memcpy(stage, scan_offsets, sizeof(int64_t) * (B + 1));
     HIP_CHECK(hipMemcpyAsync(doff, stage, sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice, stream));
-  } else {
-    HIP_CHECK(hipMemcpyAsync(doff, scan_offsets, sizeof(int64_t) * (B + 1), hipMemcpyDeviceToDevice, stream));
   }
+  // (device offsets: the key kernel copies them into the plan's array itself)
   ctx->plan.scan_off = doff;
   HIP_CHECK(hipMemsetAsync(ctx->dev_flags, 0, sizeof(int32_t), stream));
   QuantParams qp{mode, step[0], mode ? step[1] : step[0], mode ? step[2] : step[0]};
   const int idx_bits = plan_packed_idx_bits(ctx->coord_bits, n);
-  hipLaunchKernelGGL(points_to_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, points, n, doff, B, qp,
-                     ctx->coord_bits, k0, v0, ctx->dev_flags, idx_bits);
+  int32_t *tilehist = nullptr, *scanhist = nullptr;
+  int zero_words = 0;
+  ctx->sort_prezeroed = nullptr;
+  if (!plan_flat_sort()) {       // the segmented sort follows: its per-scan histograms are zeroed by the key kernel
+    EGONN_TRY(radix_sort_segments_layout(ctx, n, B, &tilehist, &scanhist));
+    zero_words = radix_sort_segments_passes(3 * ctx->coord_bits) * B * radix_sort_segments_digits();
+    ctx->sort_prezeroed = scanhist;
+  }
+  hipLaunchKernelGGL(points_to_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, points, n,
+                     offsets_on_device ? scan_offsets : doff, B, qp, ctx->coord_bits, k0, v0, ctx->dev_flags, idx_bits,
+                     offsets_on_device ? doff : (int64_t*)nullptr, scanhist, zero_words);
   return build_plan_from_sorted_input(ctx, k0, v0, k1, v1, n, doff + B, doff, B, offsets_on_device != 0, stream, idx_bits);
 }
 

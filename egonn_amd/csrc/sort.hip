@@ -507,6 +507,19 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_seg_scatter_kernel(
   }
 }
 
+// scratch of the segmented sort inside ctx->sort_arena (deterministic for (n, B)): per-tile and per-scan digit histograms
+int radix_sort_segments_layout(Ctx* ctx, int64_t n, int B, int32_t** tilehist, int32_t** scanhist) {
+  const int64_t tiles = cdiv(n > 0 ? n : 1, SORT_TILE) + B;
+  EGONN_TRY(ctx->sort_arena.ensure(radix_sort_segments_scratch_bytes(n, B)));
+  ctx->sort_arena.reset();
+  *tilehist = ctx->sort_arena.alloc<int32_t>(tiles * SEG_DIGITS);
+  *scanhist = ctx->sort_arena.alloc<int32_t>((size_t)8 * B * SEG_DIGITS);
+  EGONN_REQUIRE(*tilehist && *scanhist, EGONN_ERR_STATE, "radix_sort: scratch arena too small");
+  return EGONN_OK;
+}
+int radix_sort_segments_passes(int nbits) { return (nbits + SEG_BITS - 1) / SEG_BITS; }
+int radix_sort_segments_digits() { return SEG_DIGITS; }
+
 size_t radix_sort_segments_scratch_bytes(int64_t n, int B) {
   const int64_t tiles = cdiv(n > 0 ? n : 1, SORT_TILE) + B;
   return (size_t)(tiles * SEG_DIGITS + 8 * (int64_t)B * SEG_DIGITS) * sizeof(int32_t) + 1024;
@@ -528,12 +541,11 @@ int radix_sort_segments(Ctx* ctx, uint64_t* keys_in, uint32_t* vals_in, uint64_t
   *vals_res = vals_out;
   if (n == 0) return EGONN_OK;
   const int64_t tiles = cdiv(n, SORT_TILE) + B;
-  EGONN_TRY(ctx->sort_arena.ensure(radix_sort_segments_scratch_bytes(n, B)));
-  ctx->sort_arena.reset();
-  int32_t* tilehist = ctx->sort_arena.alloc<int32_t>(tiles * SEG_DIGITS);
-  int32_t* scanhist = ctx->sort_arena.alloc<int32_t>((size_t)8 * B * SEG_DIGITS);
-  EGONN_REQUIRE(tilehist && scanhist, EGONN_ERR_STATE, "radix_sort: scratch arena too small");
-  HIP_CHECK(hipMemsetAsync(scanhist, 0, sizeof(int32_t) * passes * B * SEG_DIGITS, stream));
+  int32_t *tilehist = nullptr, *scanhist = nullptr;
+  EGONN_TRY(radix_sort_segments_layout(ctx, n, B, &tilehist, &scanhist));
+  // (plans built from points: the key kernel in front of the sort has zeroed the per-scan histograms already — one memset node less)
+  if (ctx->sort_prezeroed != scanhist) HIP_CHECK(hipMemsetAsync(scanhist, 0, sizeof(int32_t) * passes * B * SEG_DIGITS, stream));
+  ctx->sort_prezeroed = nullptr;
   uint64_t* kb[2] = {keys_in, keys_out};
   uint32_t* vb[2] = {vals_in, vals_out};
   int src = 0;
