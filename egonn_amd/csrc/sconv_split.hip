@@ -9,17 +9,19 @@
 // Why.  v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (157 TFLOP/s, 1/16 of the 16-bit matrix rate) and was the binding
 // roof of every fp32 layer with >= 64 channels.  Round 3 ran these layers on v_mfma_f32_16x16x32_bf16 with
 // both operands split EXACTLY into three bf16 parts and six products; the kernels then turned out to be bound by their own
-// instruction stream (44 of 68 vector instructions per group and step were the split).  Round 5: fp16 parts.
+// instruction stream (44 of 68 vector instructions per group and step were the split, profiles/r03c_pmc_wide.txt).  Round 5: fp16 parts.
 // An fp16 number carries 11 significand bits, so  x = hi + lo + r  with hi = rn16(x), lo = rn16(x - hi), |r| <= 2^-22 |x|
 // (fp32 itself rounds at 2^-24), an fp16 x fp16 product is exact in fp32, and
 //     a * w = ah*wh + ah*wl + al*wh  (+ al*wl + cross terms with r: <= 3 * 2^-22 |a w|, dropped)
 // is THREE products on v_mfma_f32_16x16x32_f16 (same rate as bf16) instead of six, a 24-instruction split instead of 44, and
 // 4 bytes per weight instead of 6.  Range: fp16 holds |x| < 65504.  Weights are scaled by a power of two per kernel at pack
 // time (max |W| -> [2^13, 2^14); exact, undone exactly in the epilogue) so that their low parts stay normal numbers;
-// activations are used as they are: an fp32 activation beyond +-65504 becomes Inf (documented in egonn_hip.h; the exact fp32
-// kernels of sconv.hip stay selectable), and the low part of an activation below 2^-3 is a subnormal with an ABSOLUTE error
-// <= 2^-25 — nothing next to the rounding of the sums these layers produce.  Measured against the plain fp32 kernel
-// (tests/test_gpu_graph.py::test_split_conv_matches_exact_fp32): see DESIGN.md §3.1a.
+// activations are used as they are: an fp32 activation beyond +-65504 becomes Inf in the split — every accumulator that gathers it
+// then is Inf / NaN and the epilogue raises the plan's range flag (SplitArgs::flags; egonn_plan_status: EGONN_STATUS_FP16_RANGE;
+// egonn_ctx_set_exact_fp32 selects the exact kernels of sconv.hip) — and the low part of an activation below 2^-3 is a subnormal
+// with an ABSOLUTE error <= 2^-25: nothing next to the rounding of the sums these layers produce (operands far below 1 — input
+// gradients — are scaled per launch: SplitArgs::in_maxbits).  Measured against the plain fp32 kernel
+// (tests/test_gpu_graph.py::test_split_conv_matches_exact_fp32, tests/test_gpu_range.py): DESIGN.md §3.1.
 //
 // Decomposition (unchanged from round 3):
 //   * a WORKGROUP of NW waves owns NW consecutive row groups (rowgroup.hip: 16 output rows each, sorted by neighbour mask
