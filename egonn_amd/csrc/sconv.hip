@@ -1252,20 +1252,23 @@ const char* sconv_kernel_name(const Ctx* ctx, int kind, int level, int cin, int 
 // kernel wins from ~4 000 row groups up (L1 k3 60 -> 54 us, L2 64->64 89 -> 79) and loses below; with batches in flight it
 // pays much earlier because it leaves the matrix pipe to the other batches: scans/s with the split kernel on launches of
 // >= inf / 4096 / 2000 / 700 / 200 groups = 21.8 k / 23.3 k / 24.3 k / 24.8 k / 23.6 k, i.e. levels <= 0 / 2 / 3 / 4 / 6.
+static int split_level_limit(int split_max_level) {      // the context's limit, or EGONN_SPLIT_MAX_LEVEL (measurement override)
+  static const int env_level = [] {
+    const char* e = getenv("EGONN_SPLIT_MAX_LEVEL");
+    return e ? atoi(e) : -1;
+  }();
+  return (env_level >= 0 && split_max_level >= 0) ? env_level : split_max_level;
+}
 bool sconv_uses_split(int cin, int cout, int bf16, int level, int variant, int split_max_level, int kind) {
   if (bf16 || !sconv_split_supported(cin, cout)) return false;
   if (variant >= 1000) return true;
   if (variant != 0) return false;
-  static const int env_level = [] {                       // EGONN_SPLIT_MAX_LEVEL: measurement override
-    const char* e = getenv("EGONN_SPLIT_MAX_LEVEL");
-    return e ? atoi(e) : -1;
-  }();
   static const int env_k8 = [] {                          // EGONN_SPLIT_MAX_LEVEL_K8: measurement override for the 8-slot maps
     const char* e = getenv("EGONN_SPLIT_MAX_LEVEL_K8");
     return e ? atoi(e) : -1;
   }();
   if (kind != 0 && env_k8 >= 0) return level <= env_k8;
-  return level <= (env_level >= 0 ? env_level : split_max_level);
+  return level <= split_level_limit(split_max_level);
 }
 
 // Offset-split rule (see kernels.h): a function of (map kind, output level) only.
@@ -1366,7 +1369,7 @@ int sconv_map(Ctx* ctx, int kind, int level, const void* in, const float* W, con
   // fp32 maps of the tail levels (above split_max_level): the per-tile kernel on split arithmetic (a function of the layer)
   static const bool tail_split_ok = getenv("EGONN_NO_TAIL_SPLIT") == nullptr;          // measurement switch
   if (tail_split_ok && !bf16 && cin == 128 && cout == 128 && ctx->conv_variant == 0 && ctx->split_max_level >= 0 &&
-      level > ctx->split_max_level && !ctx->operand_autoscale) {
+      level > split_level_limit(ctx->split_max_level) && !ctx->operand_autoscale) {
     if (!Wsp) {
       const size_t wn = (split_weights_bytes(K, cin, cout) + 3) / 4;
       EGONN_REQUIRE(W && scratch && scratch_floats >= wn, EGONN_ERR_STATE, "sconv: no scratch to pack the kernel into");
